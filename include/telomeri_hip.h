@@ -1,0 +1,191 @@
+/* include/telomeri_hip.h -- C ABI of libtelomeri_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the overlap-graph path-construction hot path of lirfu/Telomeri.
+ * The reference has no FFI layer; its boundary is the C++ class surface main() calls
+ * (SURVEY.md §8b).  Each entry point below replaces the body of one of those members; the host
+ * classes in telomeri_amd/host/ keep the reference's signatures and call these.
+ *
+ *   reference interface (file:line)                                   entry point(s)
+ *   ------------------------------------------------------------------------------------------
+ *   OverlapGraph::filter            src/OverlapGraph.cpp:156-202      tlm_filter_score
+ *   OverlapGraph::buildFrom scores  src/OverlapGraph.cpp:221-231      tlm_filter_score
+ *   OverlapGraph::load / buildFrom  src/OverlapGraph.cpp:97-154,204-258
+ *       (node numbering, anchor flags, per-node edge lists)           tlm_graph_build, tlm_graph_*
+ *   PathManager::buildMonteCarlo    src/PathManager.cpp:12-177        tlm_walk_mc
+ *   PathManager::buildDeterministic src/PathManager.cpp:179-386       tlm_walk_det
+ *   Path / Path::updateLength       include/Path.hpp:7-21, src/Path.cpp:6-16   tlm_pathset_*
+ *   Utils::Metrics / getMetric      include/Utils.hpp:43-60           `metric` argument
+ *   PathManager::Parameters         include/PathManager.hpp:27-40     tlm_walk_params
+ *   OverlapGraph::FilterParameters  include/OverlapGraph.hpp:67-78    tlm_filter_params
+ *
+ * Conventions: plain C types, no exceptions cross the ABI.  Every function returning int returns
+ * 0 (TLM_OK) on success or a negative TLM_E* code; tlm_last_error() gives the message of the last
+ * failure on the calling thread.  One host thread per context.  "dev" pointers are HIP device
+ * pointers on the context's device, "host" pointers ordinary memory.  There is NO CPU fallback:
+ * every entry point that computes runs on the GPU or fails.
+ */
+#ifndef TELOMERI_HIP_H
+#define TELOMERI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TLM_ABI_VERSION 1
+
+enum {
+    TLM_OK = 0,
+    TLM_EINVAL = -1,     /* bad argument */
+    TLM_EHIP = -2,       /* a HIP runtime call failed (no device, out of memory, launch failure) */
+    TLM_ELIMIT = -3,     /* a size limit of the device layout was exceeded */
+    TLM_EINTERNAL = -4
+};
+
+/* OverlapGraph::LengthCalculationMode (include/OverlapGraph.hpp:56-65), same numbering */
+enum { TLM_MODE_MIN = 0, TLM_MODE_MAX = 1, TLM_MODE_AVG = 2, TLM_MODE_SUM = 3 };
+/* Utils::Metrics (include/Utils.hpp:43-45): EXTENSION_SCORE, OVERLAP_SCORE, *_SQRT */
+enum { TLM_METRIC_ES = 0, TLM_METRIC_OS = 1, TLM_METRIC_ES_SQRT = 2, TLM_METRIC_OS_SQRT = 3 };
+/* per-unit walk outcome (tlm_unit_stat.status) */
+enum { TLM_UNIT_ABANDONED = 0, TLM_UNIT_ACCEPTED = 1, TLM_UNIT_NEGATIVE = 2 };
+
+typedef struct {
+    int32_t mode;
+    uint64_t min_overlap_length;
+    float min_overlap_percentage;
+    uint64_t max_overhang_length;
+    float max_overhang_percentage;
+} tlm_filter_params;
+
+typedef struct {
+    int32_t rebuild_attempts;      /* Monte-Carlo trials per anchor */
+    int32_t backtrack_attempts;
+    int64_t len_threshold;
+} tlm_walk_params;
+
+typedef struct {
+    uint64_t units;                /* walk units executed */
+    uint64_t steps;                /* selection scans (MC) / ranked steps (DET) */
+    uint64_t evals;                /* adjacency entries examined by those scans: the "edge-extension evals" */
+    uint64_t draws;                /* uniform doubles drawn */
+    uint64_t accepted;             /* paths in the result */
+    double kernel_ms;              /* duration of the walk kernel(s), HIP events on the context's stream */
+    uint32_t kernel_launches;      /* walk-kernel launches behind kernel_ms (re-runs after an overflow count) */
+    uint32_t waves;                /* persistent wavefronts of the first launch */
+} tlm_counters;
+
+typedef struct {
+    uint8_t status;
+    uint32_t n_nodes;              /* nodes on the path when the walk ended */
+    uint32_t steps;
+    uint64_t evals;
+    uint32_t draws;
+    int64_t length;                /* last Path::length() */
+} tlm_unit_stat;
+
+/* One PAF file as device-resident integer columns (SoA), `n` records each.
+ * Names are ids into one name table shared by all files of a graph; the host tokeniser assigns
+ * them (any injective numbering works: node indices are re-derived on the device in the
+ * reference's first-seen order; "same name" (OverlapGraph.cpp:157) is q_id == t_id).  `anchors` is OverlapGraph::load's second argument. */
+typedef struct {
+    uint64_t n;
+    const int32_t *q_id, *t_id;                         /* dev */
+    const int32_t *q_len, *q_start, *q_end;             /* dev */
+    const int32_t *t_len, *t_start, *t_end;             /* dev */
+    const int32_t *matches;                             /* dev */
+    const uint8_t *strand;                              /* dev: 1 = relative strand '-' */
+    int32_t anchors;
+} tlm_records;
+
+typedef struct tlm_ctx tlm_ctx;
+typedef struct tlm_graph tlm_graph;
+typedef struct tlm_pathset tlm_pathset;
+
+int tlm_abi_version(void);
+const char *tlm_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int tlm_ctx_create(int device, tlm_ctx **out);
+void tlm_ctx_destroy(tlm_ctx *ctx);
+/* The HIP stream all work of the context is queued on (a hipStream_t). */
+void *tlm_ctx_stream(tlm_ctx *ctx);
+int tlm_ctx_synchronize(tlm_ctx *ctx);
+/* Tuning: persistent wavefronts per CU for the walk kernels (0 = default) and the capacity, in
+ * nodes, of a wave's path buffer before a walk is re-run with a full-size buffer (0 = default). */
+int tlm_ctx_set_walk_tuning(tlm_ctx *ctx, int waves_per_cu, uint32_t path_capacity);
+
+/* ---- a2 + a3: filter decision and SI/OS/ES per record -------------------------------------- */
+/* keep[n] (1 = passes OverlapGraph::filter), si/os/es[n] written for EVERY record; any output
+ * pointer may be NULL.  n_kept (host, may be NULL) receives the number of kept records. */
+int tlm_filter_score(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *rec, uint8_t *keep_dev,
+                     float *si_dev, float *os_dev, float *es_dev, uint64_t *n_kept);
+
+/* ---- a4: the graph -------------------------------------------------------------------------- */
+/* OverlapGraph::load for `n_files` files in order (Main.cpp:223 loads rr then cr into one graph):
+ * filter, score, first-seen node numbering among kept records (query before target), anchor flag
+ * and length fixed at node creation, two adjacency entries per kept record, per-node order =
+ * record order.  `name_is_ctg[n_names]` (dev, uint8): name starts with "ctg", case-insensitive. */
+int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *files, int n_files,
+                    uint32_t n_names, const uint8_t *name_is_ctg_dev, tlm_graph **out);
+/* Adopt a finished CSR given in HOST memory (tests; hosts that build adjacency themselves).
+ * Entry k of node i: nbr[row_ptr[i]+k]; q_end/t_end/si/strand may be NULL. */
+int tlm_graph_from_csr(tlm_ctx *ctx, uint32_t n_nodes, uint64_t n_adj, const uint64_t *row_ptr,
+                       const uint32_t *nbr, const uint32_t *q_start, const uint32_t *q_end,
+                       const uint32_t *t_start, const uint32_t *t_end, const float *os, const float *si,
+                       const float *es, const uint8_t *strand, const uint32_t *node_len,
+                       const uint8_t *node_anchor, tlm_graph **out);
+void tlm_graph_destroy(tlm_graph *g);
+
+typedef struct {
+    uint32_t n_nodes;
+    uint32_t n_anchors;
+    uint64_t n_adj;                /* adjacency entries = 2 * kept records */
+    uint64_t n_records;            /* records seen by tlm_graph_build, all files */
+    uint64_t n_kept;               /* edges_.size() */
+    uint64_t n_kept_per_file[4];
+    uint32_t max_degree;
+    uint32_t unsafe_nodes[4];      /* per metric: nodes whose roulette sums are not order-independent */
+    double build_ms;               /* device time of tlm_graph_build */
+    double filter_ms;              /* of which: the filter_score kernel */
+} tlm_graph_info;
+int tlm_graph_get_info(const tlm_graph *g, tlm_graph_info *out);
+
+/* Copy the graph to HOST arrays (each pointer may be NULL to skip it).  Sizes from tlm_graph_info.
+ * node_name_id[i] is the name id that created node i (-1 for tlm_graph_from_csr graphs). */
+int tlm_graph_download(const tlm_graph *g, uint64_t *row_ptr, uint32_t *nbr, uint32_t *q_start, uint32_t *q_end,
+                       uint32_t *t_start, uint32_t *t_end, float *os, float *si, float *es, uint8_t *strand,
+                       uint32_t *node_len, uint8_t *node_anchor, int32_t *node_name_id);
+
+/* ---- a7 / a8: walks ------------------------------------------------------------------------- */
+/* Walk units.  MC: unit = anchor_rank * rebuild_attempts + r, anchors in node
+ * order.  DET: units enumerate, anchor by anchor, the first-edge positions the reference's loop
+ * visits (it stops after the first edge that leads straight to an anchor, PathManager.cpp:224-229). */
+uint64_t tlm_mc_units(const tlm_graph *g, const tlm_walk_params *p);
+uint64_t tlm_det_units(const tlm_graph *g);
+/* Seed of the std::mt19937 owned by MC walk (anchor node, trial r) under `metric`. */
+uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r);
+
+/* Run units [unit_begin, unit_end) and return the accepted paths, ordered by unit. */
+int tlm_walk_mc(tlm_ctx *ctx, const tlm_graph *g, int metric, const tlm_walk_params *p, uint64_t unit_begin,
+                uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr);
+int tlm_walk_det(tlm_ctx *ctx, const tlm_graph *g, int metric, uint64_t unit_begin, uint64_t unit_end,
+                 tlm_pathset **out, tlm_counters *ctr);
+
+/* ---- a9: packed Path set -------------------------------------------------------------------- */
+/* path i = nodes[off[i] .. off[i+1]); slots[k] = position, inside nodes[k]'s list, of the edge to
+ * nodes[k+1] (0xFFFFFFFF at a path's last node); unit[i] ascending; length[i] = Path::length(). */
+int tlm_pathset_sizes(const tlm_pathset *ps, uint64_t *n_paths, uint64_t *n_nodes_total, uint64_t *n_units);
+/* Copy into caller buffers, device (dst_is_device != 0) or host; NULL pointers are skipped.
+ * unit/length/off: uint64/int64/uint64 [n_paths], off has n_paths+1; nodes/slots: uint32 [n_nodes_total]. */
+int tlm_pathset_export(const tlm_pathset *ps, int dst_is_device, uint64_t *unit, int64_t *length, uint64_t *off,
+                       uint32_t *nodes, uint32_t *slots);
+/* Per-unit outcomes, HOST buffer of n_units entries. */
+int tlm_pathset_unit_stats(const tlm_pathset *ps, tlm_unit_stat *stats_host);
+void tlm_pathset_destroy(tlm_pathset *ps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

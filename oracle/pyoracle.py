@@ -187,9 +187,12 @@ class Graph:
         self.records: List[int] = []
 
     def __del__(self) -> None:
-        if getattr(self, "_g", None):
-            lib().tlo_graph_free(self._g)
-            self._g = None
+        try:
+            if getattr(self, "_g", None):
+                lib().tlo_graph_free(self._g)
+                self._g = None
+        except Exception:      # interpreter shutdown
+            pass
 
     def load_paf(self, path: str, anchors: bool, fp: FilterParams, test_load_num: int = 0) -> bool:
         n = C.c_uint64(0)

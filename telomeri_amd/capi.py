@@ -1,0 +1,360 @@
+"""ctypes binding of libtelomeri_hip.so (include/telomeri_hip.h) for the Python harness.
+
+This is plumbing for tests/ and bench.py: device memory comes from torch tensors, every compute call
+goes through the C ABI into the HIP kernels.  There is no CPU fallback here: if the library is
+missing or no gfx950 device is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtelomeri_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+MODE = {"min": 0, "max": 1, "avg": 2, "sum": 3}
+METRIC_ES, METRIC_OS, METRIC_ES_SQRT, METRIC_OS_SQRT = 0, 1, 2, 3
+ULONG_MAX = (1 << 64) - 1
+
+
+class TlmError(RuntimeError):
+    pass
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("min_overlap_length", C.c_uint64), ("min_overlap_percentage", C.c_float),
+                ("max_overhang_length", C.c_uint64), ("max_overhang_percentage", C.c_float)]
+
+    @staticmethod
+    def default(mode: str = "avg", min_oll: int = 0, min_olp: float = 0.0, max_ohl: int = ULONG_MAX,
+                max_ohp: float = 1.0) -> "FilterParams":      # reference Main.cpp:56-62
+        return FilterParams(MODE[mode], min_oll, min_olp, max_ohl, max_ohp)
+
+
+class WalkParams(C.Structure):
+    _fields_ = [("rebuild_attempts", C.c_int32), ("backtrack_attempts", C.c_int32), ("len_threshold", C.c_int64)]
+
+    @staticmethod
+    def default(rb_att: int = 2000, bt_att: int = 60, len_thr: int = 4_700_000) -> "WalkParams":   # Main.cpp:63-66
+        return WalkParams(rb_att, bt_att, len_thr)
+
+
+class Counters(C.Structure):
+    _fields_ = [("units", C.c_uint64), ("steps", C.c_uint64), ("evals", C.c_uint64), ("draws", C.c_uint64),
+                ("accepted", C.c_uint64), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
+                ("waves", C.c_uint32)]
+
+
+class _Records(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("q_id", C.c_void_p), ("t_id", C.c_void_p), ("q_len", C.c_void_p),
+                ("q_start", C.c_void_p), ("q_end", C.c_void_p), ("t_len", C.c_void_p), ("t_start", C.c_void_p),
+                ("t_end", C.c_void_p), ("matches", C.c_void_p), ("strand", C.c_void_p), ("anchors", C.c_int32)]
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_anchors", C.c_uint32), ("n_adj", C.c_uint64), ("n_records", C.c_uint64),
+                ("n_kept", C.c_uint64), ("n_kept_per_file", C.c_uint64 * 4), ("max_degree", C.c_uint32),
+                ("unsafe_nodes", C.c_uint32 * 4), ("build_ms", C.c_double), ("filter_ms", C.c_double)]
+
+
+UNIT_STAT_DTYPE = np.dtype([("status", np.uint8), ("n_nodes", np.uint32), ("steps", np.uint32), ("evals", np.uint64),
+                            ("draws", np.uint32), ("length", np.int64)], align=True)
+
+_lib = None
+
+
+def build_library() -> None:
+    """hipcc cross-compiles for gfx950 without a GPU (telomeri_amd/csrc/Makefile)."""
+    subprocess.run(["make", "-s", "-C", CSRC, "-j4"], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TlmError("libtelomeri_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C telomeri_amd/csrc` -- there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    V = C.c_void_p
+    L.tlm_abi_version.restype = C.c_int
+    L.tlm_last_error.restype = C.c_char_p
+    L.tlm_ctx_create.argtypes = [C.c_int, P(V)]
+    L.tlm_ctx_destroy.argtypes = [V]
+    L.tlm_ctx_stream.argtypes = [V]
+    L.tlm_ctx_stream.restype = V
+    L.tlm_ctx_synchronize.argtypes = [V]
+    L.tlm_ctx_set_walk_tuning.argtypes = [V, C.c_int, C.c_uint32]
+    L.tlm_filter_score.argtypes = [V, P(FilterParams), P(_Records), V, V, V, V, P(C.c_uint64)]
+    L.tlm_graph_build.argtypes = [V, P(FilterParams), P(_Records), C.c_int, C.c_uint32, V, P(V)]
+    L.tlm_graph_from_csr.argtypes = [V, C.c_uint32, C.c_uint64] + [V] * 12 + [P(V)]
+    L.tlm_graph_destroy.argtypes = [V]
+    L.tlm_graph_get_info.argtypes = [V, P(GraphInfo)]
+    L.tlm_graph_download.argtypes = [V] + [V] * 13
+    L.tlm_mc_units.argtypes = [V, P(WalkParams)]
+    L.tlm_mc_units.restype = C.c_uint64
+    L.tlm_det_units.argtypes = [V]
+    L.tlm_det_units.restype = C.c_uint64
+    L.tlm_walk_seed.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    L.tlm_walk_seed.restype = C.c_uint32
+    L.tlm_walk_mc.argtypes = [V, V, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, P(V), P(Counters)]
+    L.tlm_walk_det.argtypes = [V, V, C.c_int, C.c_uint64, C.c_uint64, P(V), P(Counters)]
+    L.tlm_pathset_sizes.argtypes = [V, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+    L.tlm_pathset_export.argtypes = [V, C.c_int, V, V, V, V, V]
+    L.tlm_pathset_unit_stats.argtypes = [V, V]
+    L.tlm_pathset_destroy.argtypes = [V]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise TlmError("%s failed (%d): %s" % (what, rc, lib().tlm_last_error().decode()))
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclasses.dataclass
+class HostPaths:
+    """Packed Path set on the host (same layout as oracle.pyoracle.PathSet)."""
+    unit: np.ndarray
+    length: np.ndarray
+    off: np.ndarray
+    nodes: np.ndarray
+    slots: np.ndarray
+
+    def __len__(self) -> int:
+        return int(self.unit.shape[0])
+
+    def path(self, i: int):
+        a, b = int(self.off[i]), int(self.off[i + 1])
+        return int(self.length[i]), self.nodes[a:b], self.slots[a:b - 1]
+
+
+class PathSet:
+    def __init__(self, handle, counters: Counters) -> None:
+        self._h = handle
+        self.counters = counters
+        n_paths, n_nodes, n_units = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().tlm_pathset_sizes(self._h, C.byref(n_paths), C.byref(n_nodes), C.byref(n_units)), "tlm_pathset_sizes")
+        self.n_paths, self.n_nodes_total, self.n_units = int(n_paths.value), int(n_nodes.value), int(n_units.value)
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().tlm_pathset_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown
+            pass
+
+    def to_host(self) -> HostPaths:
+        unit = np.zeros(self.n_paths, np.uint64)
+        length = np.zeros(self.n_paths, np.int64)
+        off = np.zeros(self.n_paths + 1, np.uint64)
+        nodes = np.zeros(self.n_nodes_total, np.uint32)
+        slots = np.zeros(self.n_nodes_total, np.uint32)
+        _check(lib().tlm_pathset_export(self._h, 0, _np_ptr(unit), _np_ptr(length), _np_ptr(off), _np_ptr(nodes),
+                                        _np_ptr(slots)), "tlm_pathset_export")
+        return HostPaths(unit, length, off, nodes, slots)
+
+    def to_device_tensors(self, device):
+        """(unit, length, off, nodes, slots) as torch tensors on `device` (int64 / int64 / int64 / int32 / int32)."""
+        import torch
+        unit = torch.empty(self.n_paths, dtype=torch.int64, device=device)
+        length = torch.empty(self.n_paths, dtype=torch.int64, device=device)
+        off = torch.empty(self.n_paths + 1, dtype=torch.int64, device=device)
+        nodes = torch.empty(self.n_nodes_total, dtype=torch.int32, device=device)
+        slots = torch.empty(self.n_nodes_total, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        _check(lib().tlm_pathset_export(self._h, 1, unit.data_ptr(), length.data_ptr(), off.data_ptr(), nodes.data_ptr(),
+                                        slots.data_ptr()), "tlm_pathset_export")
+        return unit, length, off, nodes, slots
+
+    def unit_stats(self) -> np.ndarray:
+        st = np.zeros(max(self.n_units, 1), UNIT_STAT_DTYPE)
+        _check(lib().tlm_pathset_unit_stats(self._h, _np_ptr(st)), "tlm_pathset_unit_stats")
+        return st[:self.n_units]
+
+
+@dataclasses.dataclass
+class HostCsr:
+    n_nodes: int
+    n_adj: int
+    row_ptr: np.ndarray
+    nbr: np.ndarray
+    q_start: np.ndarray
+    q_end: np.ndarray
+    t_start: np.ndarray
+    t_end: np.ndarray
+    os: np.ndarray
+    si: np.ndarray
+    es: np.ndarray
+    strand: np.ndarray
+    node_len: np.ndarray
+    node_anchor: np.ndarray
+    node_name_id: np.ndarray
+
+
+class Graph:
+    def __init__(self, ctx: "Context", handle) -> None:
+        self.ctx = ctx
+        self._h = handle
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().tlm_graph_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown
+            pass
+
+    def info(self) -> GraphInfo:
+        gi = GraphInfo()
+        _check(lib().tlm_graph_get_info(self._h, C.byref(gi)), "tlm_graph_get_info")
+        return gi
+
+    def download(self, cold: bool = True) -> HostCsr:
+        gi = self.info()
+        n, a = int(gi.n_nodes), int(gi.n_adj)
+        row_ptr = np.zeros(n + 1, np.uint64)
+        nbr = np.zeros(a, np.uint32)
+        qs = np.zeros(a, np.uint32)
+        ts = np.zeros(a, np.uint32)
+        qe = np.zeros(a, np.uint32) if cold else None
+        te = np.zeros(a, np.uint32) if cold else None
+        si = np.zeros(a, np.float32) if cold else None
+        strand = np.zeros(a, np.uint8) if cold else None
+        os_ = np.zeros(a, np.float32)
+        es = np.zeros(a, np.float32)
+        node_len = np.zeros(n, np.uint32)
+        node_anchor = np.zeros(n, np.uint8)
+        name_id = np.zeros(n, np.int32)
+        _check(lib().tlm_graph_download(self._h, _np_ptr(row_ptr), _np_ptr(nbr), _np_ptr(qs), _np_ptr(qe), _np_ptr(ts),
+                                        _np_ptr(te), _np_ptr(os_), _np_ptr(si), _np_ptr(es), _np_ptr(strand),
+                                        _np_ptr(node_len), _np_ptr(node_anchor), _np_ptr(name_id)), "tlm_graph_download")
+        return HostCsr(n, a, row_ptr, nbr, qs, qe, ts, te, os_, si, es, strand, node_len, node_anchor, name_id)
+
+    def mc_units(self, wp: WalkParams) -> int:
+        return int(lib().tlm_mc_units(self._h, C.byref(wp)))
+
+    def det_units(self) -> int:
+        return int(lib().tlm_det_units(self._h))
+
+    def walk_mc(self, metric: int, wp: WalkParams, unit_begin: int = 0, unit_end: Optional[int] = None) -> PathSet:
+        if unit_end is None:
+            unit_end = self.mc_units(wp)
+        h = C.c_void_p()
+        ctr = Counters()
+        _check(lib().tlm_walk_mc(self.ctx._h, self._h, metric, C.byref(wp), unit_begin, unit_end, C.byref(h),
+                                 C.byref(ctr)), "tlm_walk_mc")
+        return PathSet(h, ctr)
+
+    def walk_det(self, metric: int, unit_begin: int = 0, unit_end: Optional[int] = None) -> PathSet:
+        if unit_end is None:
+            unit_end = self.det_units()
+        h = C.c_void_p()
+        ctr = Counters()
+        _check(lib().tlm_walk_det(self.ctx._h, self._h, metric, unit_begin, unit_end, C.byref(h), C.byref(ctr)),
+               "tlm_walk_det")
+        return PathSet(h, ctr)
+
+
+def _records_struct(rec, anchors: bool) -> _Records:
+    """rec: telomeri_amd.synth.Records (or anything with those int32 device tensors)."""
+    import torch
+    cols = {}
+    for name in ("q_id", "t_id", "q_len", "q_start", "q_end", "t_len", "t_start", "t_end", "matches"):
+        t = getattr(rec, name)
+        assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous(), name
+        cols[name] = t.data_ptr()
+    strand = rec.strand
+    if strand.dtype != torch.uint8:
+        strand = strand.to(torch.uint8)
+        rec._strand_u8 = strand          # keep it alive
+    return _Records(len(rec), cols["q_id"], cols["t_id"], cols["q_len"], cols["q_start"], cols["q_end"], cols["t_len"],
+                    cols["t_start"], cols["t_end"], cols["matches"], strand.data_ptr(), int(anchors))
+
+
+class Context:
+    def __init__(self, device: int = 0) -> None:
+        h = C.c_void_p()
+        _check(lib().tlm_ctx_create(device, C.byref(h)), "tlm_ctx_create")
+        self._h = h
+        self.device = device
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().tlm_ctx_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown
+            pass
+
+    def set_walk_tuning(self, waves_per_cu: int = 0, path_capacity: int = 0) -> None:
+        _check(lib().tlm_ctx_set_walk_tuning(self._h, waves_per_cu, path_capacity), "tlm_ctx_set_walk_tuning")
+
+    def filter_score(self, fp: FilterParams, rec, want_scores: bool = True):
+        """-> (keep uint8, si, os, es float32) device tensors, n_kept."""
+        import torch
+        dev = rec.q_id.device
+        n = len(rec)
+        keep = torch.empty(n, dtype=torch.uint8, device=dev)
+        si = torch.empty(n, dtype=torch.float32, device=dev) if want_scores else None
+        os_ = torch.empty(n, dtype=torch.float32, device=dev) if want_scores else None
+        es = torch.empty(n, dtype=torch.float32, device=dev) if want_scores else None
+        rs = _records_struct(rec, False)
+        torch.cuda.synchronize(dev)
+        nk = C.c_uint64()
+        _check(lib().tlm_filter_score(self._h, C.byref(fp), C.byref(rs), keep.data_ptr(),
+                                      si.data_ptr() if want_scores else None, os_.data_ptr() if want_scores else None,
+                                      es.data_ptr() if want_scores else None, C.byref(nk)), "tlm_filter_score")
+        return keep, si, os_, es, int(nk.value)
+
+    def build_graph(self, fp: FilterParams, files: Sequence, anchors: Sequence[bool], n_names: int, name_is_ctg) -> Graph:
+        """files: Records on this device, in load order (reference Main.cpp:223: rr then cr)."""
+        import torch
+        arr = (_Records * len(files))(*[_records_struct(f, a) for f, a in zip(files, anchors)])
+        ctg = name_is_ctg.to(device=files[0].q_id.device, dtype=torch.uint8).contiguous()
+        torch.cuda.synchronize(files[0].q_id.device)
+        h = C.c_void_p()
+        _check(lib().tlm_graph_build(self._h, C.byref(fp), arr, len(files), n_names, ctg.data_ptr(), C.byref(h)),
+               "tlm_graph_build")
+        return Graph(self, h)
+
+    def graph_from_csr(self, row_ptr, nbr, q_start, t_start, os_, es, node_len, node_anchor, q_end=None, t_end=None,
+                       si=None, strand=None) -> Graph:
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
+        u32 = lambda x: None if x is None else np.ascontiguousarray(x, np.uint32)
+        f32 = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)
+        u8 = lambda x: None if x is None else np.ascontiguousarray(x, np.uint8)
+        nbr, q_start, t_start, q_end, t_end = u32(nbr), u32(q_start), u32(t_start), u32(q_end), u32(t_end)
+        os_, es, si = f32(os_), f32(es), f32(si)
+        node_len, node_anchor, strand = u32(node_len), u8(node_anchor), u8(strand)
+        h = C.c_void_p()
+        _check(lib().tlm_graph_from_csr(self._h, row_ptr.shape[0] - 1, nbr.shape[0], _np_ptr(row_ptr), _np_ptr(nbr),
+                                        _np_ptr(q_start), _np_ptr(q_end), _np_ptr(t_start), _np_ptr(t_end), _np_ptr(os_),
+                                        _np_ptr(si), _np_ptr(es), _np_ptr(strand), _np_ptr(node_len), _np_ptr(node_anchor),
+                                        C.byref(h)), "tlm_graph_from_csr")
+        return Graph(self, h)
+
+
+def walk_seed(metric: int, anchor_node: int, r: int) -> int:
+    return int(lib().tlm_walk_seed(metric, anchor_node, r))
+
+
+def declared_symbols() -> List[str]:
+    """Every function include/telomeri_hip.h declares."""
+    import re
+    hdr = os.path.join(HERE, "..", "include", "telomeri_hip.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tlm_[a-z0-9_]+)\s*\(", txt)))

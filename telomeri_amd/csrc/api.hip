@@ -1,0 +1,626 @@
+// telomeri_amd/csrc/api.hip -- the extern "C" surface of include/telomeri_hip.h: context, graph
+// adoption / download, walk orchestration (work queue, overflow re-runs, packing), path sets.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+
+#include "tlm_common.h"
+#include "walk_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void tlm_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *tlm_last_error(void) { return g_err; }
+extern "C" int tlm_abi_version(void) { return TLM_ABI_VERSION; }
+
+extern "C" uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r) {
+    return 5489u + 0x9E3779B9u * (anchor_node + 1u) + 0x85EBCA6Bu * r + 0xC2B2AE35u * (uint32_t) metric;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+
+struct Workspace {   // walk scratch kept across calls (bench loops); bitmaps stay all-zero between walks
+    uint32_t waves = 0, cap = 0, bm_words = 0;
+    uint32_t *sc_nodes = nullptr, *sc_edges = nullptr, *sc_log = nullptr, *bitmaps = nullptr;
+    uint64_t ar_cap = 0;
+    uint32_t *ar_nodes = nullptr, *ar_slots = nullptr;
+    uint32_t *cursor = nullptr;              // [4]: work cursor (u32) + pad, arena cursor (u64)
+    void release_scratch() {
+        (void) hipFree(sc_nodes); (void) hipFree(sc_edges); (void) hipFree(sc_log); (void) hipFree(bitmaps);
+        sc_nodes = sc_edges = sc_log = bitmaps = nullptr;
+        waves = cap = bm_words = 0;
+    }
+    void release_arena() {
+        (void) hipFree(ar_nodes); (void) hipFree(ar_slots);
+        ar_nodes = ar_slots = nullptr;
+        ar_cap = 0;
+    }
+};
+
+struct CtxImpl : tlm_ctx {
+    Workspace ws;
+};
+
+extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
+    TLM_CHECK(out, TLM_EINVAL, "tlm_ctx_create: null out");
+    int n = 0;
+    TLM_HIP(hipGetDeviceCount(&n));
+    TLM_CHECK(device >= 0 && device < n, TLM_EINVAL, "tlm_ctx_create: device %d of %d", device, n);
+    TLM_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TLM_HIP(hipGetDeviceProperties(&prop, device));
+    TLM_CHECK(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 || getenv("TLM_ALLOW_ANY_ARCH"), TLM_EHIP,
+              "tlm_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    CtxImpl *c = new CtxImpl();
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+        || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
+        || hipMalloc((void **) &c->ws.cursor, 32) != hipSuccess) {
+        tlm_set_error("tlm_ctx_create: stream/event creation failed");
+        delete c;
+        return TLM_EHIP;
+    }
+    *out = c;
+    return TLM_OK;
+}
+
+extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
+    if (!ctx) return;
+    CtxImpl *c = static_cast<CtxImpl *>(ctx);
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    c->ws.release_scratch();
+    c->ws.release_arena();
+    (void) hipFree(c->ws.cursor);
+    (void) hipEventDestroy(c->ev0);
+    (void) hipEventDestroy(c->ev1);
+    (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void *tlm_ctx_stream(tlm_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+extern "C" int tlm_ctx_synchronize(tlm_ctx *ctx) {
+    TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_synchronize: null ctx");
+    TLM_HIP(hipStreamSynchronize(ctx->stream));
+    return TLM_OK;
+}
+
+extern "C" int tlm_ctx_set_walk_tuning(tlm_ctx *ctx, int waves_per_cu, uint32_t path_capacity) {
+    TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_set_walk_tuning: null ctx");
+    TLM_CHECK(waves_per_cu >= 0 && waves_per_cu <= 32, TLM_EINVAL, "waves_per_cu must be 0..32");
+    ctx->waves_per_cu = waves_per_cu;
+    ctx->path_capacity = path_capacity;
+    return TLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter_score
+
+extern "C" int tlm_filter_score(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *rec, uint8_t *keep_dev,
+                                float *si_dev, float *os_dev, float *es_dev, uint64_t *n_kept) {
+    TLM_CHECK(ctx && p && rec, TLM_EINVAL, "tlm_filter_score: null argument");
+    TLM_CHECK(rec->n == 0 || (rec->q_id && rec->t_id && rec->q_len && rec->q_start && rec->q_end && rec->t_len
+                              && rec->t_start && rec->t_end && rec->matches), TLM_EINVAL,
+              "tlm_filter_score: null column");
+    TLM_HIP(hipSetDevice(ctx->device));
+    CtxImpl *c = static_cast<CtxImpl *>(ctx);
+    unsigned long long *cnt = (unsigned long long *) (c->ws.cursor + 4);
+    TLM_HIP(hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    tlm_launch_filter_score(ctx->stream, *p, *rec, keep_dev, si_dev, os_dev, es_dev, cnt);
+    TLM_HIP(hipGetLastError());
+    unsigned long long h = 0;
+    TLM_HIP(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TLM_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_kept) *n_kept = h;
+    return TLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// graph adoption / download
+
+extern "C" void tlm_graph_destroy(tlm_graph *g) {
+    if (!g) return;
+    if (g->ctx) (void) hipSetDevice(g->ctx->device);
+    (void) hipFree(g->row_ptr); (void) hipFree(g->ent_es); (void) hipFree(g->ent_os);
+    (void) hipFree(g->q_start); (void) hipFree(g->t_start); (void) hipFree(g->q_end); (void) hipFree(g->t_end);
+    (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
+    (void) hipFree(g->node_flags); (void) hipFree(g->node_name_id); (void) hipFree(g->anchors); (void) hipFree(g->det_off);
+    delete g;
+}
+
+template <class T> static int upload(T **dst, const T *src, size_t n, hipStream_t s) {
+    TLM_HIP(hipMalloc((void **) dst, (n ? n : 1) * sizeof(T)));
+    if (n && src) TLM_HIP(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    else if (n) TLM_HIP(hipMemsetAsync(*dst, 0, n * sizeof(T), s));
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_from_csr(tlm_ctx *ctx, uint32_t n_nodes, uint64_t n_adj, const uint64_t *row_ptr,
+                                  const uint32_t *nbr, const uint32_t *q_start, const uint32_t *q_end,
+                                  const uint32_t *t_start, const uint32_t *t_end, const float *os, const float *si,
+                                  const float *es, const uint8_t *strand, const uint32_t *node_len,
+                                  const uint8_t *node_anchor, tlm_graph **out) {
+    TLM_CHECK(ctx && out && row_ptr && node_len && node_anchor, TLM_EINVAL, "tlm_graph_from_csr: null argument");
+    TLM_CHECK(n_adj == 0 || (nbr && q_start && t_start && os && es), TLM_EINVAL, "tlm_graph_from_csr: null column");
+    TLM_CHECK(n_nodes < (1u << 31) && n_adj < (1ull << 32) - 64, TLM_ELIMIT, "tlm_graph_from_csr: graph too large");
+    TLM_CHECK(row_ptr[0] == 0 && row_ptr[n_nodes] == n_adj, TLM_EINVAL, "tlm_graph_from_csr: row_ptr ends do not match");
+    for (uint32_t i = 0; i < n_nodes; i++)
+        TLM_CHECK(row_ptr[i] <= row_ptr[i + 1], TLM_EINVAL, "tlm_graph_from_csr: row_ptr not monotone at %u", i);
+    for (uint64_t k = 0; k < n_adj; k++)
+        TLM_CHECK(nbr[k] < n_nodes, TLM_EINVAL, "tlm_graph_from_csr: neighbour out of range at %llu", (unsigned long long) k);
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    tlm_graph *g = new tlm_graph();
+    g->ctx = ctx;
+    g->n_nodes = n_nodes;
+    g->n_adj = n_adj;
+    struct Guard { tlm_graph *g; ~Guard() { if (g) tlm_graph_destroy(g); } } guard{g};
+    std::vector<uint32_t> rp((size_t) n_nodes + 1);
+    for (uint32_t i = 0; i <= n_nodes; i++) rp[i] = (uint32_t) row_ptr[i];
+    std::vector<uint2> ees(n_adj), eos(n_adj);
+    for (uint64_t k = 0; k < n_adj; k++) {
+        const uint32_t w = nbr[k] | ((uint32_t) (node_anchor[nbr[k]] != 0) << 31);
+        uint32_t eb, ob;
+        std::memcpy(&eb, &es[k], 4);
+        std::memcpy(&ob, &os[k], 4);
+        ees[k] = make_uint2(w, eb);
+        eos[k] = make_uint2(w, ob);
+    }
+    std::vector<int32_t> name_id(n_nodes, -1);
+    if (int rc = upload(&g->row_ptr, rp.data(), rp.size(), s)) return rc;
+    if (int rc = upload(&g->ent_es, ees.data(), (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->ent_os, eos.data(), (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->q_start, q_start, (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->t_start, t_start, (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->q_end, q_end, (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->t_end, t_end, (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->si, si, (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->strand, strand, (size_t) n_adj, s)) return rc;
+    if (int rc = upload(&g->node_len, node_len, (size_t) n_nodes, s)) return rc;
+    if (int rc = upload(&g->node_anchor, node_anchor, (size_t) n_nodes, s)) return rc;
+    if (int rc = upload(&g->node_name_id, name_id.data(), (size_t) n_nodes, s)) return rc;
+    TLM_HIP(hipStreamSynchronize(s));
+    g->info.n_kept = n_adj / 2;
+    if (int rc = tlm_graph_finish(ctx, g)) return rc;
+    guard.g = nullptr;
+    *out = g;
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_get_info(const tlm_graph *g, tlm_graph_info *out) {
+    TLM_CHECK(g && out, TLM_EINVAL, "tlm_graph_get_info: null argument");
+    *out = g->info;
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_download(const tlm_graph *g, uint64_t *row_ptr, uint32_t *nbr, uint32_t *q_start,
+                                  uint32_t *q_end, uint32_t *t_start, uint32_t *t_end, float *os, float *si, float *es,
+                                  uint8_t *strand, uint32_t *node_len, uint8_t *node_anchor, int32_t *node_name_id) {
+    TLM_CHECK(g, TLM_EINVAL, "tlm_graph_download: null graph");
+    TLM_HIP(hipSetDevice(g->ctx->device));
+    hipStream_t s = g->ctx->stream;
+    const size_t N = g->n_nodes, A = (size_t) g->n_adj;
+#define DL(dst, src, n) do { if ((dst) && (n)) TLM_HIP(hipMemcpyAsync((dst), (src), (n) * sizeof(*(dst)), hipMemcpyDeviceToHost, s)); } while (0)
+    std::vector<uint32_t> rp;
+    if (row_ptr) {
+        rp.resize(N + 1);
+        TLM_HIP(hipMemcpyAsync(rp.data(), g->row_ptr, (N + 1) * 4, hipMemcpyDeviceToHost, s));
+    }
+    std::vector<uint2> ees, eos;
+    if ((nbr || es) && A) { ees.resize(A); TLM_HIP(hipMemcpyAsync(ees.data(), g->ent_es, A * 8, hipMemcpyDeviceToHost, s)); }
+    if (os && A) { eos.resize(A); TLM_HIP(hipMemcpyAsync(eos.data(), g->ent_os, A * 8, hipMemcpyDeviceToHost, s)); }
+    DL(q_start, g->q_start, A); DL(q_end, g->q_end, A); DL(t_start, g->t_start, A); DL(t_end, g->t_end, A);
+    DL(si, g->si, A); DL(strand, g->strand, A); DL(node_len, g->node_len, N); DL(node_anchor, g->node_anchor, N);
+    DL(node_name_id, g->node_name_id, N);
+#undef DL
+    TLM_HIP(hipStreamSynchronize(s));
+    if (row_ptr) for (size_t i = 0; i <= N; i++) row_ptr[i] = rp[i];
+    for (size_t k = 0; k < A; k++) {
+        if (nbr) nbr[k] = ees[k].x & 0x7FFFFFFFu;
+        if (es) std::memcpy(&es[k], &ees[k].y, 4);
+        if (os) std::memcpy(&os[k], &eos[k].y, 4);
+    }
+    return TLM_OK;
+}
+
+extern "C" uint64_t tlm_mc_units(const tlm_graph *g, const tlm_walk_params *p) {
+    if (!g || !p || p->rebuild_attempts <= 0) return 0;
+    return (uint64_t) g->h_anchors.size() * (uint64_t) p->rebuild_attempts;
+}
+
+extern "C" uint64_t tlm_det_units(const tlm_graph *g) { return g ? g->h_det_off.back() : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// result packing kernels
+
+// Exclusive scan over the units of (accepted ? 1 : 0) and (accepted ? n_nodes : 0); one workgroup.
+__global__ __launch_bounds__(1024) void scan_units_kernel(uint32_t n_units, const uint8_t *__restrict__ status,
+                                                          const uint32_t *__restrict__ nnodes,
+                                                          uint32_t *__restrict__ p_index, uint64_t *__restrict__ n_off,
+                                                          uint64_t *__restrict__ totals) {
+    __shared__ uint64_t s_cnt[1024];
+    __shared__ uint64_t s_sum[1024];
+    uint64_t carry_cnt = 0, carry_sum = 0;
+    const int t = threadIdx.x;
+    for (uint32_t base = 0; base < n_units; base += 1024) {
+        const uint32_t i = base + t;
+        const bool acc = i < n_units && status[i] == ST_ACCEPTED;
+        const uint64_t c = acc ? 1 : 0, v = acc ? nnodes[i] : 0;
+        s_cnt[t] = c;
+        s_sum[t] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint64_t a = 0, b = 0;
+            if (t >= d) { a = s_cnt[t - d]; b = s_sum[t - d]; }
+            __syncthreads();
+            s_cnt[t] += a;
+            s_sum[t] += b;
+            __syncthreads();
+        }
+        if (i < n_units) {
+            p_index[i] = (uint32_t) (carry_cnt + s_cnt[t] - c);
+            n_off[i] = carry_sum + s_sum[t] - v;
+        }
+        carry_cnt += s_cnt[1023];
+        carry_sum += s_sum[1023];
+        __syncthreads();
+    }
+    if (t == 0) { totals[0] = carry_cnt; totals[1] = carry_sum; }
+}
+
+__global__ __launch_bounds__(256) void pack_paths_kernel(uint32_t n_units, uint64_t unit_begin,
+                                                         const uint8_t *__restrict__ status,
+                                                         const uint32_t *__restrict__ nnodes,
+                                                         const int64_t *__restrict__ u_len,
+                                                         const uint64_t *__restrict__ u_off,
+                                                         const uint32_t *__restrict__ p_index,
+                                                         const uint64_t *__restrict__ n_off,
+                                                         const uint32_t *__restrict__ ar_nodes,
+                                                         const uint32_t *__restrict__ ar_slots,
+                                                         uint64_t *__restrict__ o_unit, int64_t *__restrict__ o_len,
+                                                         uint64_t *__restrict__ o_off, uint32_t *__restrict__ o_nodes,
+                                                         uint32_t *__restrict__ o_slots) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t ui = wave; ui < n_units; ui += n_waves) {
+        if (status[ui] != ST_ACCEPTED) continue;
+        const uint32_t pi = p_index[ui], n = nnodes[ui];
+        const uint64_t src = u_off[ui], dst = n_off[ui];
+        if (lane == 0) {
+            o_unit[pi] = unit_begin + ui;
+            o_len[pi] = u_len[ui];
+            o_off[pi] = dst;
+        }
+        for (uint32_t i = lane; i < n; i += 64) {
+            o_nodes[dst + i] = ar_nodes[src + i];
+            o_slots[dst + i] = ar_slots[src + i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// walk orchestration
+
+namespace {
+
+struct UnitBufs {
+    uint8_t *status = nullptr;
+    uint32_t *nnodes = nullptr, *steps = nullptr, *draws = nullptr;
+    int64_t *len = nullptr;
+    uint64_t *evals = nullptr, *off = nullptr;
+    uint32_t *p_index = nullptr;
+    uint64_t *n_off = nullptr, *totals = nullptr;
+    uint32_t *work_list = nullptr;
+    ~UnitBufs() {
+        (void) hipFree(status); (void) hipFree(nnodes); (void) hipFree(steps); (void) hipFree(draws); (void) hipFree(len);
+        (void) hipFree(evals); (void) hipFree(off); (void) hipFree(p_index); (void) hipFree(n_off); (void) hipFree(totals);
+        (void) hipFree(work_list);
+    }
+};
+
+template <class T> int dmalloc(T **p, size_t n) {
+    TLM_HIP(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
+    return TLM_OK;
+}
+
+int ensure_scratch(CtxImpl *c, uint32_t waves, uint32_t cap, uint32_t bm_words) {
+    Workspace &w = c->ws;
+    if (w.waves >= waves && w.cap == cap && w.bm_words == bm_words) return TLM_OK;
+    w.release_scratch();
+    if (int rc = dmalloc(&w.sc_nodes, (size_t) waves * cap)) return rc;
+    if (int rc = dmalloc(&w.sc_edges, (size_t) waves * cap)) return rc;
+    if (int rc = dmalloc(&w.sc_log, (size_t) waves * cap)) return rc;
+    if (int rc = dmalloc(&w.bitmaps, (size_t) waves * bm_words)) return rc;
+    TLM_HIP(hipMemsetAsync(w.bitmaps, 0, (size_t) waves * bm_words * 4, c->stream));
+    w.waves = waves;
+    w.cap = cap;
+    w.bm_words = bm_words;
+    return TLM_OK;
+}
+
+// Grow the arena to `need` entries, keeping the first `keep` entries.
+int ensure_arena(CtxImpl *c, uint64_t need, uint64_t keep) {
+    Workspace &w = c->ws;
+    if (w.ar_cap >= need) return TLM_OK;
+    uint32_t *nn = nullptr, *ns = nullptr;
+    if (int rc = dmalloc(&nn, (size_t) need)) return rc;
+    if (int rc = dmalloc(&ns, (size_t) need)) { (void) hipFree(nn); return rc; }
+    if (keep) {
+        TLM_HIP(hipMemcpyAsync(nn, w.ar_nodes, keep * 4, hipMemcpyDeviceToDevice, c->stream));
+        TLM_HIP(hipMemcpyAsync(ns, w.ar_slots, keep * 4, hipMemcpyDeviceToDevice, c->stream));
+        TLM_HIP(hipStreamSynchronize(c->stream));
+    }
+    w.release_arena();
+    w.ar_nodes = nn;
+    w.ar_slots = ns;
+    w.ar_cap = need;
+    return TLM_OK;
+}
+
+int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tlm_walk_params *p, uint64_t unit_begin,
+              uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr) {
+    TLM_CHECK(ctx && g && out, TLM_EINVAL, "walk: null argument");
+    TLM_CHECK(g->ctx == ctx, TLM_EINVAL, "walk: graph belongs to another context");
+    TLM_CHECK(metric >= 0 && metric <= 3, TLM_EINVAL, "walk: metric %d", metric);
+    TLM_CHECK(!is_mc || (p && p->rebuild_attempts >= 0 && p->backtrack_attempts >= 0), TLM_EINVAL, "walk: bad parameters");
+    CtxImpl *c = static_cast<CtxImpl *>(ctx);
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t total = is_mc ? tlm_mc_units(g, p) : tlm_det_units(g);
+    if (unit_end > total) unit_end = total;
+    if (unit_begin > unit_end) unit_begin = unit_end;
+    const uint64_t n_units64 = unit_end - unit_begin;
+    TLM_CHECK(n_units64 < (1ull << 31), TLM_ELIMIT, "walk: %llu units in one call (limit 2^31)", (unsigned long long) n_units64);
+    const uint32_t n_units = (uint32_t) n_units64;
+
+    tlm_pathset *ps = new tlm_pathset();
+    ps->ctx = ctx;
+    ps->n_units = n_units;
+    struct Guard { tlm_pathset *p; ~Guard() { if (p) tlm_pathset_destroy(p); } } guard{ps};
+    tlm_counters cnt;
+    std::memset(&cnt, 0, sizeof(cnt));
+
+    UnitBufs u;
+    if (int rc = dmalloc(&u.status, n_units)) return rc;
+    if (int rc = dmalloc(&u.nnodes, n_units)) return rc;
+    if (int rc = dmalloc(&u.steps, n_units)) return rc;
+    if (int rc = dmalloc(&u.draws, n_units)) return rc;
+    if (int rc = dmalloc(&u.len, n_units)) return rc;
+    if (int rc = dmalloc(&u.evals, n_units)) return rc;
+    if (int rc = dmalloc(&u.off, n_units)) return rc;
+    if (int rc = dmalloc(&u.p_index, n_units)) return rc;
+    if (int rc = dmalloc(&u.n_off, n_units)) return rc;
+    if (int rc = dmalloc(&u.totals, 2)) return rc;
+    if (int rc = dmalloc(&u.work_list, n_units)) return rc;
+    TLM_HIP(hipMemsetAsync(u.status, ST_NOT_RUN, n_units ? n_units : 1, s));
+
+    std::vector<uint8_t> h_status(n_units);
+    std::vector<uint64_t> h_off(n_units);
+    std::vector<uint32_t> h_nn(n_units);
+
+    if (n_units) {
+        const uint32_t N = g->n_nodes;
+        const uint32_t full_cap = N + 2;
+        uint32_t cap = ctx->path_capacity ? ctx->path_capacity : 16384u;
+        cap = std::max<uint32_t>(8u, std::min(cap, full_cap));
+        const uint32_t bm_words = (N + 31) / 32 + 1;
+        const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : 16;
+        uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) wpc;
+        waves = std::min<uint32_t>(waves, ((n_units + 3) / 4) * 4);
+        waves = std::max<uint32_t>(4u, (waves / 4) * 4);
+        cnt.waves = waves;
+        if (int rc = ensure_scratch(c, waves, cap, bm_words)) return rc;
+        if (int rc = ensure_arena(c, std::max<uint64_t>(1u << 20, (uint64_t) n_units * 256u), 0)) return rc;
+        unsigned long long *ar_cursor = (unsigned long long *) (c->ws.cursor + 2);
+        TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 16, s));
+
+        WalkArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.row_ptr = g->row_ptr;
+        a.ents = (metric == TLM_METRIC_ES || metric == TLM_METRIC_ES_SQRT) ? g->ent_es : g->ent_os;
+        a.q_start = g->q_start;
+        a.t_start = g->t_start;
+        a.node_len = g->node_len;
+        a.node_flags = g->node_flags;
+        a.n_nodes = N;
+        a.flag_bit = 1u << metric;
+        a.metric = metric;
+        a.anchors = g->anchors;
+        a.n_anchors = (uint32_t) g->h_anchors.size();
+        a.det_off = g->det_off;
+        a.unit_begin = unit_begin;
+        a.rebuild_attempts = is_mc ? p->rebuild_attempts : 1;
+        a.backtrack_attempts = is_mc ? p->backtrack_attempts : 0;
+        a.len_threshold = is_mc ? p->len_threshold : 0;
+        a.cursor = c->ws.cursor;
+        a.u_status = u.status; a.u_nnodes = u.nnodes; a.u_steps = u.steps; a.u_draws = u.draws;
+        a.u_len = u.len; a.u_evals = u.evals; a.u_off = u.off;
+        a.ar_cursor = ar_cursor;
+        const bool sq = metric >= 2;
+
+        std::vector<uint32_t> work;     // empty = identity
+        uint32_t n_work = n_units;
+        uint32_t cur_cap = cap, cur_waves = waves;
+        for (int round = 0; round < 64; round++) {
+            a.n_work = n_work;
+            a.work_list = work.empty() ? nullptr : u.work_list;
+            a.sc_nodes = c->ws.sc_nodes; a.sc_edges = c->ws.sc_edges; a.sc_log = c->ws.sc_log;
+            a.cap = c->ws.cap;
+            a.bitmaps = c->ws.bitmaps;
+            a.bm_words = c->ws.bm_words;
+            a.ar_nodes = c->ws.ar_nodes; a.ar_slots = c->ws.ar_slots; a.ar_cap = c->ws.ar_cap;
+            uint32_t launch_waves = std::min<uint32_t>(cur_waves, ((n_work + 3) / 4) * 4);
+            launch_waves = std::max<uint32_t>(4u, launch_waves);
+            TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 4, s));
+            TLM_HIP(hipEventRecord(ctx->ev0, s));
+            if (is_mc) tlm_launch_walk_mc(s, launch_waves / 4, sq, a);
+            else tlm_launch_walk_det(s, launch_waves / 4, sq, a);
+            TLM_HIP(hipGetLastError());
+            TLM_HIP(hipEventRecord(ctx->ev1, s));
+            TLM_HIP(hipMemcpyAsync(h_status.data(), u.status, n_units, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipEventSynchronize(ctx->ev1));
+            TLM_HIP(hipStreamSynchronize(s));
+            float ms = 0;
+            TLM_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            cnt.kernel_ms += ms;
+            cnt.kernel_launches++;
+            // overflow handling: re-run the affected units with a full-size path buffer / a larger arena
+            std::vector<uint32_t> sc_ovf, ar_ovf;
+            for (uint32_t i = 0; i < n_units; i++) {
+                if (h_status[i] == ST_SCRATCH_OVF) sc_ovf.push_back(i);
+                else if (h_status[i] == ST_ARENA_OVF) ar_ovf.push_back(i);
+                else TLM_CHECK(h_status[i] != ST_NOT_RUN, TLM_EINTERNAL, "walk: unit %u was not run", i);
+            }
+            if (sc_ovf.empty() && ar_ovf.empty()) break;
+            TLM_CHECK(round < 63, TLM_EINTERNAL, "walk: overflow re-runs did not converge");
+            if (!ar_ovf.empty()) {
+                TLM_HIP(hipMemcpyAsync(h_off.data(), u.off, (size_t) n_units * 8, hipMemcpyDeviceToHost, s));
+                TLM_HIP(hipMemcpyAsync(h_nn.data(), u.nnodes, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
+                TLM_HIP(hipStreamSynchronize(s));
+                uint64_t keep = ~0ull, extra = 0;
+                for (uint32_t i : ar_ovf) { keep = std::min(keep, h_off[i]); extra += h_nn[i]; }
+                // every reservation after the first failed one failed too, so [0, keep) is all valid paths
+                if (int rc = ensure_arena(c, (keep + extra) + (keep + extra) / 4 + (1u << 20), keep)) return rc;
+                unsigned long long k = keep;
+                TLM_HIP(hipMemcpyAsync(ar_cursor, &k, 8, hipMemcpyHostToDevice, s));
+                TLM_HIP(hipStreamSynchronize(s));
+            }
+            if (!sc_ovf.empty()) {
+                TLM_CHECK(cur_cap < full_cap, TLM_EINTERNAL, "walk: path buffer overflow at full capacity");
+                cur_cap = full_cap;
+                // bound the re-run's scratch to ~8 GiB
+                const uint64_t per_wave = (uint64_t) full_cap * 12u + (uint64_t) bm_words * 4u;
+                uint64_t w = (8ull << 30) / per_wave;
+                cur_waves = (uint32_t) std::max<uint64_t>(4, std::min<uint64_t>(cur_waves, (w / 4) * 4));
+                if (int rc = ensure_scratch(c, cur_waves, cur_cap, bm_words)) return rc;
+            }
+            work = sc_ovf;
+            work.insert(work.end(), ar_ovf.begin(), ar_ovf.end());
+            std::sort(work.begin(), work.end());
+            n_work = (uint32_t) work.size();
+            TLM_HIP(hipMemcpyAsync(u.work_list, work.data(), (size_t) n_work * 4, hipMemcpyHostToDevice, s));
+            TLM_HIP(hipStreamSynchronize(s));
+        }
+
+        // pack accepted paths in unit order
+        hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, s, n_units, u.status, u.nnodes, u.p_index, u.n_off,
+                           u.totals);
+        uint64_t h_tot[2] = {0, 0};
+        TLM_HIP(hipMemcpyAsync(h_tot, u.totals, 16, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        ps->n_paths = h_tot[0];
+        ps->n_nodes_total = h_tot[1];
+    }
+    if (int rc = dmalloc(&ps->unit, ps->n_paths)) return rc;
+    if (int rc = dmalloc(&ps->length, ps->n_paths)) return rc;
+    if (int rc = dmalloc(&ps->off, ps->n_paths + 1)) return rc;
+    if (int rc = dmalloc(&ps->nodes, ps->n_nodes_total)) return rc;
+    if (int rc = dmalloc(&ps->slots, ps->n_nodes_total)) return rc;
+    if (n_units) {
+        uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
+        hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, u.status,
+                           u.nnodes, u.len, u.off, u.p_index, u.n_off, c->ws.ar_nodes, c->ws.ar_slots, ps->unit, ps->length,
+                           ps->off, ps->nodes, ps->slots);
+        TLM_HIP(hipGetLastError());
+    }
+    TLM_HIP(hipMemcpyAsync(ps->off + ps->n_paths, &ps->n_nodes_total, 8, hipMemcpyHostToDevice, s));
+
+    // per-unit outcomes to the host
+    ps->stats.resize(n_units);
+    if (n_units) {
+        std::vector<uint32_t> h_steps(n_units), h_draws(n_units);
+        std::vector<int64_t> h_len(n_units);
+        std::vector<uint64_t> h_evals(n_units);
+        TLM_HIP(hipMemcpyAsync(h_status.data(), u.status, n_units, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_nn.data(), u.nnodes, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_steps.data(), u.steps, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_draws.data(), u.draws, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_len.data(), u.len, (size_t) n_units * 8, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_evals.data(), u.evals, (size_t) n_units * 8, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n_units; i++) {
+            tlm_unit_stat &st = ps->stats[i];
+            st.status = h_status[i];
+            st.n_nodes = h_nn[i];
+            st.steps = h_steps[i];
+            st.evals = h_evals[i];
+            st.draws = h_draws[i];
+            st.length = h_len[i];
+            cnt.steps += h_steps[i];
+            cnt.evals += h_evals[i];
+            cnt.draws += h_draws[i];
+        }
+    }
+    TLM_HIP(hipStreamSynchronize(s));
+    cnt.units = n_units;
+    cnt.accepted = ps->n_paths;
+    if (ctr) *ctr = cnt;
+    guard.p = nullptr;
+    *out = ps;
+    return TLM_OK;
+}
+
+}  // namespace
+
+extern "C" int tlm_walk_mc(tlm_ctx *ctx, const tlm_graph *g, int metric, const tlm_walk_params *p, uint64_t unit_begin,
+                           uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr) {
+    TLM_CHECK(p, TLM_EINVAL, "tlm_walk_mc: null parameters");
+    return run_walks(ctx, g, true, metric, p, unit_begin, unit_end, out, ctr);
+}
+
+extern "C" int tlm_walk_det(tlm_ctx *ctx, const tlm_graph *g, int metric, uint64_t unit_begin, uint64_t unit_end,
+                            tlm_pathset **out, tlm_counters *ctr) {
+    return run_walks(ctx, g, false, metric, nullptr, unit_begin, unit_end, out, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// path sets
+
+extern "C" int tlm_pathset_sizes(const tlm_pathset *ps, uint64_t *n_paths, uint64_t *n_nodes_total, uint64_t *n_units) {
+    TLM_CHECK(ps, TLM_EINVAL, "tlm_pathset_sizes: null path set");
+    if (n_paths) *n_paths = ps->n_paths;
+    if (n_nodes_total) *n_nodes_total = ps->n_nodes_total;
+    if (n_units) *n_units = ps->n_units;
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_export(const tlm_pathset *ps, int dst_is_device, uint64_t *unit, int64_t *length,
+                                  uint64_t *off, uint32_t *nodes, uint32_t *slots) {
+    TLM_CHECK(ps, TLM_EINVAL, "tlm_pathset_export: null path set");
+    TLM_HIP(hipSetDevice(ps->ctx->device));
+    hipStream_t s = ps->ctx->stream;
+    const hipMemcpyKind k = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (unit && ps->n_paths) TLM_HIP(hipMemcpyAsync(unit, ps->unit, ps->n_paths * 8, k, s));
+    if (length && ps->n_paths) TLM_HIP(hipMemcpyAsync(length, ps->length, ps->n_paths * 8, k, s));
+    if (off) TLM_HIP(hipMemcpyAsync(off, ps->off, (ps->n_paths + 1) * 8, k, s));
+    if (nodes && ps->n_nodes_total) TLM_HIP(hipMemcpyAsync(nodes, ps->nodes, ps->n_nodes_total * 4, k, s));
+    if (slots && ps->n_nodes_total) TLM_HIP(hipMemcpyAsync(slots, ps->slots, ps->n_nodes_total * 4, k, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_unit_stats(const tlm_pathset *ps, tlm_unit_stat *stats_host) {
+    TLM_CHECK(ps && stats_host, TLM_EINVAL, "tlm_pathset_unit_stats: null argument");
+    if (!ps->stats.empty()) std::memcpy(stats_host, ps->stats.data(), ps->stats.size() * sizeof(tlm_unit_stat));
+    return TLM_OK;
+}
+
+extern "C" void tlm_pathset_destroy(tlm_pathset *ps) {
+    if (!ps) return;
+    if (ps->ctx) (void) hipSetDevice(ps->ctx->device);
+    (void) hipFree(ps->unit); (void) hipFree(ps->length); (void) hipFree(ps->off); (void) hipFree(ps->nodes);
+    (void) hipFree(ps->slots);
+    delete ps;
+}

@@ -1,0 +1,479 @@
+// telomeri_amd/csrc/csr_build.hip -- OverlapGraph::load's graph construction on the device.
+//
+// Replaces the body of OverlapGraph::buildFrom / nodeIndex (reference src/OverlapGraph.cpp:204-258)
+// for all files of one graph:
+//   1. filter_score per file (filter_score.hip)                          -> keep, SI/OS/ES per record
+//   2. exclusive scan of keep                                            -> rank k of each kept record
+//   3. first-seen node numbering among kept records, query before target (:208-218): atomicMin of
+//      the position 2k+role per name id, then a radix sort of the (<= n_names) first positions
+//   4. two adjacency entries per kept record (:241-248): e=2k owned by the target (unswapped),
+//      e=2k+1 owned by the query (q/t index, start, end swapped; scores, strand as they are);
+//      a STABLE radix sort of (owner, e) gives CSR order = per-node record order
+//   5. gather of the record columns into the CSR arrays (hot: {nbr|anchor, ES}, {nbr|anchor, OS},
+//      q_start, t_start; cold: q_end, t_end, SI, strand)
+//   6. per-node order-safety flags for the roulette sums, anchor list, DET unit table
+// The sort and the scans are rocPRIM device primitives (native ROCm, no CUDA layer); everything
+// touching the reference's semantics is a kernel in this file.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "tlm_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+namespace {
+
+struct DevBuf {   // RAII for temporaries
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    template <class T> T *as() { return (T *) p; }
+};
+
+int dev_alloc(DevBuf &b, size_t bytes) {
+    TLM_HIP(hipMalloc(&b.p, bytes ? bytes : 16));
+    return TLM_OK;
+}
+
+template <class T> int dev_alloc_keep(T **out, size_t n) {
+    TLM_HIP(hipMalloc((void **) out, (n ? n : 1) * sizeof(T)));
+    return TLM_OK;
+}
+
+struct FileCols {
+    const int32_t *q_id, *t_id, *q_len, *q_start, *q_end, *t_len, *t_start, *t_end;
+    const uint8_t *strand;
+    uint64_t base;      // global record index of the file's record 0
+    uint64_t n;
+    int anchors;
+};
+constexpr int MAX_FILES = 4;
+struct FileTable {
+    FileCols f[MAX_FILES];
+    int n_files;
+};
+
+__device__ inline int file_of(const FileTable &ft, uint64_t g) {
+    int f = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_FILES; i++)
+        if (i < ft.n_files && g >= ft.f[i].base) f = i;
+    return f;
+}
+
+struct KeepToU32 {
+    __host__ __device__ uint32_t operator()(uint8_t k) const { return k; }
+};
+
+// step 3a: first position (2k + role) at which a kept record mentions each name; also kept_rec[k] = g
+__global__ __launch_bounds__(256) void first_seen_kernel(FileTable ft, int fi, const uint8_t *__restrict__ keep,
+                                                         const uint32_t *__restrict__ krank,
+                                                         uint32_t *__restrict__ first_pos,
+                                                         uint32_t *__restrict__ kept_rec) {
+    const FileCols &f = ft.f[fi];
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < f.n; i += stride) {
+        const uint64_t g = f.base + i;
+        if (!keep[g]) continue;
+        const uint32_t k = krank[g];
+        kept_rec[k] = (uint32_t) g;
+        atomicMin(&first_pos[f.q_id[i]], 2u * k);
+        atomicMin(&first_pos[f.t_id[i]], 2u * k + 1u);
+    }
+}
+
+__global__ void iota_kernel(uint32_t *p, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// step 3b: names sorted by first position -> node index; node attributes come from the creating
+// record (OverlapGraph.cpp:211,217): length = that sequence's length, anchor = (contig position
+// of the record == role of the name in it), ContigPosition per :130-138.
+__global__ __launch_bounds__(256) void make_nodes_kernel(FileTable ft, uint32_t n_nodes,
+                                                         const uint32_t *__restrict__ sorted_pos,
+                                                         const uint32_t *__restrict__ sorted_name,
+                                                         const uint32_t *__restrict__ kept_rec,
+                                                         const uint8_t *__restrict__ name_is_ctg,
+                                                         uint32_t *__restrict__ node_of_name,
+                                                         uint32_t *__restrict__ node_len,
+                                                         uint8_t *__restrict__ node_anchor,
+                                                         int32_t *__restrict__ node_name_id) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t pos = sorted_pos[i], name = sorted_name[i];
+    const uint32_t role = pos & 1u;              // 0 = query, 1 = target
+    const uint64_t g = kept_rec[pos >> 1];
+    const int fi = file_of(ft, g);
+    const FileCols &f = ft.f[fi];
+    const uint64_t r = g - f.base;
+    bool anchor = false;
+    if (f.anchors) {
+        const bool pos_query = name_is_ctg[f.q_id[r]] != 0;   // ContigPosition::QUERY else TARGET
+        anchor = pos_query ? (role == 0) : (role == 1);
+    }
+    node_of_name[name] = i;
+    node_len[i] = (uint32_t) (role == 0 ? f.q_len[r] : f.t_len[r]);
+    node_anchor[i] = anchor ? 1 : 0;
+    node_name_id[i] = (int32_t) name;
+}
+
+// step 4: (owner, e) pairs
+__global__ __launch_bounds__(256) void make_entries_kernel(FileTable ft, uint64_t n_kept,
+                                                           const uint32_t *__restrict__ kept_rec,
+                                                           const uint32_t *__restrict__ node_of_name,
+                                                           uint32_t *__restrict__ owner, uint32_t *__restrict__ eidx) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < n_kept; k += stride) {
+        const uint64_t g = kept_rec[k];
+        const FileCols &f = ft.f[file_of(ft, g)];
+        const uint64_t r = g - f.base;
+        const uint32_t qn = node_of_name[f.q_id[r]], tn = node_of_name[f.t_id[r]];
+        owner[2 * k] = tn;        // nodes_[tn_index].edges.push_back(e)          :243
+        owner[2 * k + 1] = qn;    // swap; nodes_[qn_index].edges.push_back(e)    :245-248
+        eidx[2 * k] = (uint32_t) (2 * k);
+        eidx[2 * k + 1] = (uint32_t) (2 * k + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void row_ptr_kernel(uint64_t n_adj, uint32_t n_nodes,
+                                                      const uint32_t *__restrict__ sorted_owner,
+                                                      uint32_t *__restrict__ row_ptr) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t d = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; d < n_adj; d += stride) {
+        // every node owns at least one entry (nodes exist only through kept records)
+        if (d == 0 || sorted_owner[d] != sorted_owner[d - 1]) row_ptr[sorted_owner[d]] = (uint32_t) d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) row_ptr[n_nodes] = (uint32_t) n_adj;
+}
+
+// step 5
+__global__ __launch_bounds__(256) void gather_kernel(FileTable ft, uint64_t n_adj, const uint32_t *__restrict__ sorted_e,
+                                                     const uint32_t *__restrict__ kept_rec,
+                                                     const uint32_t *__restrict__ node_of_name,
+                                                     const uint8_t *__restrict__ node_anchor,
+                                                     const float *__restrict__ r_si, const float *__restrict__ r_os,
+                                                     const float *__restrict__ r_es, uint2 *__restrict__ ent_es,
+                                                     uint2 *__restrict__ ent_os, uint32_t *__restrict__ q_start,
+                                                     uint32_t *__restrict__ q_end, uint32_t *__restrict__ t_start,
+                                                     uint32_t *__restrict__ t_end, float *__restrict__ si,
+                                                     uint8_t *__restrict__ strand) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t d = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; d < n_adj; d += stride) {
+        const uint32_t e = sorted_e[d];
+        const uint64_t g = kept_rec[e >> 1];
+        const bool swapped = (e & 1u) != 0;
+        const FileCols &f = ft.f[file_of(ft, g)];
+        const uint64_t r = g - f.base;
+        const uint32_t qn = node_of_name[f.q_id[r]], tn = node_of_name[f.t_id[r]];
+        const uint32_t nbr = swapped ? tn : qn;       // Edge::q_index of the entry
+        const uint32_t word = nbr | ((uint32_t) node_anchor[nbr] << 31);
+        ent_es[d] = make_uint2(word, __float_as_uint(r_es[g]));
+        ent_os[d] = make_uint2(word, __float_as_uint(r_os[g]));
+        const uint32_t qs = (uint32_t) f.q_start[r], qe = (uint32_t) f.q_end[r];
+        const uint32_t ts = (uint32_t) f.t_start[r], te = (uint32_t) f.t_end[r];
+        q_start[d] = swapped ? ts : qs;
+        q_end[d] = swapped ? te : qe;
+        t_start[d] = swapped ? qs : ts;
+        t_end[d] = swapped ? qe : te;
+        si[d] = r_si[g];
+        strand[d] = f.strand ? (f.strand[r] != 0) : 0;
+    }
+}
+
+// step 6a: is every roulette sum over a subset of this node's list independent of the order of
+// the additions?  All |m| are multiples of 2^kmin; if sum|m| < 2^(kmin+52) every partial sum of
+// every subset in every order is exactly representable in a double.  One wave
+// per node; the criterion is evaluated for the four metrics of Utils::getMetric.
+__device__ inline void safety_of(float m, int &kmin, double &tot, bool &bad) {
+    const uint32_t u = __float_as_uint(m);
+    const uint32_t ex = (u >> 23) & 0xFFu, man = u & 0x7FFFFFu;
+    if (ex == 0xFFu) { bad = true; return; }          // inf / NaN
+    if (ex == 0 && man == 0) return;                  // +-0 contributes nothing
+    const uint32_t full = ex ? (man | 0x800000u) : man;
+    const int e = (ex ? (int) ex : 1) - 127 - 23;      // value = full * 2^e
+    const int k = e + (__ffs((int) full) - 1);
+    kmin = min(kmin, k);
+    tot += fabs((double) m);
+}
+
+__global__ __launch_bounds__(256) void node_flags_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                                         const uint2 *__restrict__ ent_es,
+                                                         const uint2 *__restrict__ ent_os,
+                                                         uint8_t *__restrict__ node_flags,
+                                                         uint32_t *__restrict__ unsafe_cnt,
+                                                         uint32_t *__restrict__ max_deg) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t local_max = 0;
+    for (uint32_t node = wave; node < n_nodes; node += n_waves) {
+        const uint32_t r0 = row_ptr[node], r1 = row_ptr[node + 1];
+        local_max = max(local_max, r1 - r0);
+        int kmin[4] = {1 << 20, 1 << 20, 1 << 20, 1 << 20};
+        double tot[4] = {0, 0, 0, 0};
+        bool bad[4] = {false, false, false, false};
+        for (uint32_t i = r0 + lane; i < r1; i += 64) {
+            const float es = __uint_as_float(ent_es[i].y), os = __uint_as_float(ent_os[i].y);
+            safety_of(es, kmin[TLM_METRIC_ES], tot[TLM_METRIC_ES], bad[TLM_METRIC_ES]);
+            safety_of(os, kmin[TLM_METRIC_OS], tot[TLM_METRIC_OS], bad[TLM_METRIC_OS]);
+            safety_of(sqrtf(es), kmin[TLM_METRIC_ES_SQRT], tot[TLM_METRIC_ES_SQRT], bad[TLM_METRIC_ES_SQRT]);
+            safety_of(sqrtf(os), kmin[TLM_METRIC_OS_SQRT], tot[TLM_METRIC_OS_SQRT], bad[TLM_METRIC_OS_SQRT]);
+        }
+        uint8_t flags = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            int k = kmin[m];
+            double t = tot[m];
+            int b = bad[m];
+            for (int d = 32; d > 0; d >>= 1) {
+                k = min(k, __shfl_xor(k, d));
+                t += __shfl_xor(t, d);
+                b |= __shfl_xor(b, d);
+            }
+            // t is itself rounded; 2^(k+52) leaves a factor 2 of slack for that
+            const bool safe = !b && (k == (1 << 20) || t < ldexp(1.0, k + 52));
+            if (safe) flags |= (uint8_t) (1u << m);
+            else if (lane == 0) atomicAdd(&unsafe_cnt[m], 1u);
+        }
+        if (lane == 0) node_flags[node] = flags;
+    }
+    for (int d = 32; d > 0; d >>= 1) local_max = max(local_max, (uint32_t) __shfl_xor((int) local_max, d));
+    if (lane == 0) atomicMax(max_deg, local_max);
+}
+
+// step 6b: DET units of an anchor = first edges up to and including the first one that leads to an
+// anchor (PathManager.cpp:204,224-229)
+__global__ void det_count_kernel(uint32_t n_anchors, const uint32_t *__restrict__ anchors,
+                                 const uint32_t *__restrict__ row_ptr, const uint2 *__restrict__ ent,
+                                 uint64_t *__restrict__ cnt) {
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_anchors) return;
+    const uint32_t node = anchors[a];
+    uint64_t c = 0;
+    for (uint32_t i = row_ptr[node]; i < row_ptr[node + 1]; i++) {
+        c++;
+        if (ent[i].x >> 31) break;
+    }
+    cnt[a] = c;
+}
+
+unsigned grid_for(uint64_t n) {
+    uint64_t b = (n + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned) (b ? b : 1);
+}
+
+}  // namespace
+
+int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
+    hipStream_t s = ctx->stream;
+    const uint32_t N = g->n_nodes;
+    TLM_HIP(hipMalloc((void **) &g->node_flags, N ? N : 1));
+    DevBuf cnts;
+    if (int rc = dev_alloc(cnts, 8 * sizeof(uint32_t))) return rc;
+    TLM_HIP(hipMemsetAsync(cnts.p, 0, 8 * sizeof(uint32_t), s));
+    if (N) {
+        hipLaunchKernelGGL(node_flags_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
+                           g->ent_es, g->ent_os, g->node_flags, cnts.as<uint32_t>(), cnts.as<uint32_t>() + 4);
+    }
+    uint32_t h_cnts[8];
+    TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, sizeof(h_cnts), hipMemcpyDeviceToHost, s));
+    std::vector<uint8_t> h_anchor(N);
+    if (N) TLM_HIP(hipMemcpyAsync(h_anchor.data(), g->node_anchor, N, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    for (int m = 0; m < 4; m++) g->info.unsafe_nodes[m] = h_cnts[m];
+    g->info.max_degree = h_cnts[4];
+    g->h_anchors.clear();
+    for (uint32_t i = 0; i < N; i++)
+        if (h_anchor[i]) g->h_anchors.push_back(i);
+    const uint32_t na = (uint32_t) g->h_anchors.size();
+    g->info.n_anchors = na;
+    g->info.n_nodes = N;
+    g->info.n_adj = g->n_adj;
+    TLM_HIP(hipMalloc((void **) &g->anchors, (na ? na : 1) * sizeof(uint32_t)));
+    TLM_HIP(hipMalloc((void **) &g->det_off, ((size_t) na + 1) * sizeof(uint64_t)));
+    g->h_det_off.assign((size_t) na + 1, 0);
+    if (na) {
+        TLM_HIP(hipMemcpyAsync(g->anchors, g->h_anchors.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        DevBuf cnt;
+        if (int rc = dev_alloc(cnt, na * sizeof(uint64_t))) return rc;
+        hipLaunchKernelGGL(det_count_kernel, dim3((na + 63) / 64), dim3(64), 0, s, na, g->anchors, g->row_ptr, g->ent_es,
+                           cnt.as<uint64_t>());
+        std::vector<uint64_t> h_cnt(na);
+        TLM_HIP(hipMemcpyAsync(h_cnt.data(), cnt.p, na * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        for (uint32_t a = 0; a < na; a++) g->h_det_off[a + 1] = g->h_det_off[a] + h_cnt[a];
+    }
+    TLM_HIP(hipMemcpyAsync(g->det_off, g->h_det_off.data(), ((size_t) na + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *files, int n_files,
+                               uint32_t n_names, const uint8_t *name_is_ctg_dev, tlm_graph **out) {
+    TLM_CHECK(ctx && p && files && out, TLM_EINVAL, "tlm_graph_build: null argument");
+    TLM_CHECK(n_files >= 1 && n_files <= MAX_FILES, TLM_EINVAL, "tlm_graph_build: n_files must be 1..%d", MAX_FILES);
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    FileTable ft;
+    std::memset(&ft, 0, sizeof(ft));
+    ft.n_files = n_files;
+    uint64_t R = 0;
+    for (int i = 0; i < n_files; i++) {
+        const tlm_records &r = files[i];
+        TLM_CHECK(r.n == 0 || (r.q_id && r.t_id && r.q_len && r.q_start && r.q_end && r.t_len && r.t_start && r.t_end
+                               && r.matches), TLM_EINVAL, "tlm_graph_build: file %d has a null column", i);
+        ft.f[i] = FileCols{r.q_id, r.t_id, r.q_len, r.q_start, r.q_end, r.t_len, r.t_start, r.t_end, r.strand, R, r.n,
+                           r.anchors};
+        R += r.n;
+    }
+    TLM_CHECK(R < (1ull << 31), TLM_ELIMIT, "tlm_graph_build: %llu records exceed the 2^31 layout limit",
+              (unsigned long long) R);
+    TLM_CHECK(n_names < (1u << 31), TLM_ELIMIT, "tlm_graph_build: too many names");
+
+    tlm_graph *g = new tlm_graph();
+    g->ctx = ctx;
+    struct Guard {   // destroy the half-built graph on any early return
+        tlm_graph *g;
+        ~Guard() { if (g) tlm_graph_destroy(g); }
+    } guard{g};
+
+    TLM_HIP(hipEventRecord(ctx->ev0, s));
+    // 1. filter + score
+    DevBuf keep, r_si, r_os, r_es, krank, nk;
+    if (int rc = dev_alloc(keep, R)) return rc;
+    if (int rc = dev_alloc(r_si, R * 4)) return rc;
+    if (int rc = dev_alloc(r_os, R * 4)) return rc;
+    if (int rc = dev_alloc(r_es, R * 4)) return rc;
+    if (int rc = dev_alloc(krank, (R + 1) * 4)) return rc;
+    if (int rc = dev_alloc(nk, MAX_FILES * sizeof(unsigned long long))) return rc;
+    TLM_HIP(hipMemsetAsync(nk.p, 0, MAX_FILES * sizeof(unsigned long long), s));
+    hipEvent_t f0, f1;
+    TLM_HIP(hipEventCreate(&f0));
+    TLM_HIP(hipEventCreate(&f1));
+    TLM_HIP(hipEventRecord(f0, s));
+    for (int i = 0; i < n_files; i++) {
+        const uint64_t b = ft.f[i].base;
+        tlm_launch_filter_score(s, *p, files[i], keep.as<uint8_t>() + b, r_si.as<float>() + b, r_os.as<float>() + b,
+                                r_es.as<float>() + b, nk.as<unsigned long long>() + i);
+    }
+    TLM_HIP(hipEventRecord(f1, s));
+    unsigned long long h_nk[MAX_FILES] = {0, 0, 0, 0};
+    TLM_HIP(hipMemcpyAsync(h_nk, nk.p, sizeof(h_nk), hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    float fms = 0;
+    TLM_HIP(hipEventElapsedTime(&fms, f0, f1));
+    (void) hipEventDestroy(f0);
+    (void) hipEventDestroy(f1);
+    uint64_t K = 0;
+    for (int i = 0; i < n_files; i++) { g->info.n_kept_per_file[i] = h_nk[i]; K += h_nk[i]; }
+    g->info.n_records = R;
+    g->info.n_kept = K;
+    g->info.filter_ms = fms;
+    const uint64_t A = 2 * K;
+    TLM_CHECK(A < (1ull << 32) - 64, TLM_ELIMIT, "tlm_graph_build: %llu adjacency entries exceed the u32 CSR layout",
+              (unsigned long long) A);
+    g->n_adj = A;
+
+    // 2. rank of each kept record
+    {
+        auto in = rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
+        size_t tb = 0;
+        TLM_HIP(rocprim::exclusive_scan(nullptr, tb, in, krank.as<uint32_t>(), 0u, (size_t) R, rocprim::plus<uint32_t>(), s));
+        DevBuf tmp;
+        if (int rc = dev_alloc(tmp, tb)) return rc;
+        TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, in, krank.as<uint32_t>(), 0u, (size_t) R, rocprim::plus<uint32_t>(), s));
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+
+    // 3. first-seen numbering
+    DevBuf first_pos, kept_rec, name_iota, sorted_pos, sorted_name, node_of_name;
+    if (int rc = dev_alloc(first_pos, (size_t) n_names * 4)) return rc;
+    if (int rc = dev_alloc(kept_rec, K * 4)) return rc;
+    if (int rc = dev_alloc(name_iota, (size_t) n_names * 4)) return rc;
+    if (int rc = dev_alloc(sorted_pos, (size_t) n_names * 4)) return rc;
+    if (int rc = dev_alloc(sorted_name, (size_t) n_names * 4)) return rc;
+    if (int rc = dev_alloc(node_of_name, (size_t) n_names * 4)) return rc;
+    TLM_HIP(hipMemsetAsync(first_pos.p, 0xFF, (size_t) n_names * 4, s));
+    for (int i = 0; i < n_files; i++) {
+        if (!ft.f[i].n) continue;
+        hipLaunchKernelGGL(first_seen_kernel, dim3(grid_for(ft.f[i].n)), dim3(256), 0, s, ft, i, keep.as<uint8_t>(),
+                           krank.as<uint32_t>(), first_pos.as<uint32_t>(), kept_rec.as<uint32_t>());
+    }
+    uint32_t N = 0;
+    if (n_names) {
+        hipLaunchKernelGGL(iota_kernel, dim3((n_names + 255) / 256), dim3(256), 0, s, name_iota.as<uint32_t>(), n_names);
+        size_t tb = 0;
+        TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, first_pos.as<uint32_t>(), sorted_pos.as<uint32_t>(),
+                                          name_iota.as<uint32_t>(), sorted_name.as<uint32_t>(), (size_t) n_names, 0, 32, s));
+        DevBuf tmp;
+        if (int rc = dev_alloc(tmp, tb)) return rc;
+        TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, first_pos.as<uint32_t>(), sorted_pos.as<uint32_t>(),
+                                          name_iota.as<uint32_t>(), sorted_name.as<uint32_t>(), (size_t) n_names, 0, 32, s));
+        // N = number of names that occur in a kept record = first index with pos == 0xFFFFFFFF
+        std::vector<uint32_t> h_pos(n_names);
+        TLM_HIP(hipMemcpyAsync(h_pos.data(), sorted_pos.p, (size_t) n_names * 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        N = (uint32_t) (std::lower_bound(h_pos.begin(), h_pos.end(), 0xFFFFFFFFu) - h_pos.begin());
+    }
+    g->n_nodes = N;
+    if (int rc = dev_alloc_keep(&g->node_len, N)) return rc;
+    if (int rc = dev_alloc_keep(&g->node_anchor, N)) return rc;
+    if (int rc = dev_alloc_keep(&g->node_name_id, N)) return rc;
+    if (N) {
+        hipLaunchKernelGGL(make_nodes_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ft, N, sorted_pos.as<uint32_t>(),
+                           sorted_name.as<uint32_t>(), kept_rec.as<uint32_t>(), name_is_ctg_dev,
+                           node_of_name.as<uint32_t>(), g->node_len, g->node_anchor, g->node_name_id);
+    }
+
+    // 4. adjacency entries, stable sort by owner
+    if (int rc = dev_alloc_keep(&g->row_ptr, (size_t) N + 1)) return rc;
+    if (int rc = dev_alloc_keep(&g->ent_es, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->ent_os, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->q_start, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->q_end, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->t_start, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->t_end, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->si, A)) return rc;
+    if (int rc = dev_alloc_keep(&g->strand, A)) return rc;
+    TLM_HIP(hipMemsetAsync(g->row_ptr, 0, ((size_t) N + 1) * 4, s));
+    if (A) {
+        DevBuf owner, eidx, sorted_owner, sorted_e;
+        if (int rc = dev_alloc(owner, A * 4)) return rc;
+        if (int rc = dev_alloc(eidx, A * 4)) return rc;
+        if (int rc = dev_alloc(sorted_owner, A * 4)) return rc;
+        if (int rc = dev_alloc(sorted_e, A * 4)) return rc;
+        hipLaunchKernelGGL(make_entries_kernel, dim3(grid_for(K)), dim3(256), 0, s, ft, K, kept_rec.as<uint32_t>(),
+                           node_of_name.as<uint32_t>(), owner.as<uint32_t>(), eidx.as<uint32_t>());
+        unsigned end_bit = 1;
+        while ((1ull << end_bit) < (uint64_t) N && end_bit < 32) end_bit++;
+        size_t tb = 0;
+        TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, owner.as<uint32_t>(), sorted_owner.as<uint32_t>(), eidx.as<uint32_t>(),
+                                          sorted_e.as<uint32_t>(), (size_t) A, 0, end_bit, s));
+        DevBuf tmp;
+        if (int rc = dev_alloc(tmp, tb)) return rc;
+        TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, owner.as<uint32_t>(), sorted_owner.as<uint32_t>(), eidx.as<uint32_t>(),
+                                          sorted_e.as<uint32_t>(), (size_t) A, 0, end_bit, s));
+        hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, N, sorted_owner.as<uint32_t>(), g->row_ptr);
+        // 5. gather
+        hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, ft, A, sorted_e.as<uint32_t>(),
+                           kept_rec.as<uint32_t>(), node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(),
+                           r_os.as<float>(), r_es.as<float>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start,
+                           g->t_end, g->si, g->strand);
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+    // 6.
+    if (int rc = tlm_graph_finish(ctx, g)) return rc;
+    TLM_HIP(hipEventRecord(ctx->ev1, s));
+    TLM_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    TLM_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    g->info.build_ms = ms;
+    TLM_HIP(hipGetLastError());
+    guard.g = nullptr;
+    *out = g;
+    return TLM_OK;
+}

@@ -1,0 +1,89 @@
+// telomeri_amd/csrc/tlm_common.h -- internal declarations shared by the HIP translation units.
+#ifndef TLM_COMMON_H
+#define TLM_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/telomeri_hip.h"
+
+void tlm_set_error(const char *fmt, ...);
+
+#define TLM_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            tlm_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return TLM_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define TLM_CHECK(cond, code, ...)                                                             \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            tlm_set_error(__VA_ARGS__);                                                        \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while (0)
+
+struct tlm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 0;
+    int waves_per_cu = 0;          // 0 = default
+    uint32_t path_capacity = 0;    // 0 = default
+};
+
+// Device-resident graph.  HBM layout:
+//   row_ptr[N+1]            u32   CSR offsets (A < 2^32)
+//   ent_es[A], ent_os[A]    u32x2 {neighbour | anchor(neighbour) << 31, fp32 bits of ES resp. OS}
+//                                 -- the 8 B a walk reads per edge-extension eval
+//   q_start[A], t_start[A]  u32   length increments (Path::updateLength), read once per step
+//   q_end, t_end, si, strand      cold columns for the Scaffolder / downloads
+//   node_len[N] u32, node_anchor[N] u8, node_flags[N] u8 (bit m: metric m's sums are order-safe)
+struct tlm_graph {
+    tlm_ctx *ctx = nullptr;
+    uint32_t n_nodes = 0;
+    uint64_t n_adj = 0;
+    uint32_t *row_ptr = nullptr;
+    uint2 *ent_es = nullptr, *ent_os = nullptr;
+    uint32_t *q_start = nullptr, *t_start = nullptr, *q_end = nullptr, *t_end = nullptr;
+    float *si = nullptr;
+    uint8_t *strand = nullptr;
+    uint32_t *node_len = nullptr;
+    uint8_t *node_anchor = nullptr;
+    uint8_t *node_flags = nullptr;
+    int32_t *node_name_id = nullptr;
+    uint32_t *anchors = nullptr;       // [n_anchors] node index, ascending
+    uint64_t *det_off = nullptr;       // [n_anchors+1] prefix of DET units per anchor
+    std::vector<uint32_t> h_anchors;
+    std::vector<uint64_t> h_det_off;
+    tlm_graph_info info{};
+};
+
+// internal per-unit status codes beyond the public TLM_UNIT_* ones
+enum : uint8_t { ST_ABANDONED = 0, ST_ACCEPTED = 1, ST_NEGATIVE = 2, ST_SCRATCH_OVF = 3, ST_ARENA_OVF = 4, ST_NOT_RUN = 255 };
+
+struct tlm_pathset {
+    tlm_ctx *ctx = nullptr;
+    uint64_t n_units = 0, n_paths = 0, n_nodes_total = 0;
+    // packed result (device)
+    uint64_t *unit = nullptr;
+    int64_t *length = nullptr;
+    uint64_t *off = nullptr;
+    uint32_t *nodes = nullptr, *slots = nullptr;
+    std::vector<tlm_unit_stat> stats;   // host copy
+};
+
+// graph build (csr_build.hip)
+int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g);   // node_flags, anchors, det_off, info
+
+// kernels launched from the API layer
+void tlm_launch_filter_score(hipStream_t s, const tlm_filter_params &p, const tlm_records &r, uint8_t *keep, float *si,
+                             float *os, float *es, unsigned long long *n_kept_dev);
+
+#endif

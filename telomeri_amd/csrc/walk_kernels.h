@@ -1,0 +1,62 @@
+// telomeri_amd/csrc/walk_kernels.h -- device side of the contig-to-contig walks (gfx950).
+//
+// One 64-lane wavefront per live walk (north_star): the neighbour list of the current node is
+// read as coalesced 8-byte {neighbour|anchor, metric} entries, lane i holding entry base+i; the
+// forced-anchor test, the visited test, the roulette prefix sums (MC) and the rank arg-max (DET)
+// are wave ballots / scans / reductions.  Waves are persistent and pull walk units from one atomic
+// cursor, so divergent walk lengths do not idle the chip; every wave leaves when the cursor passes
+// the end of the work list.  No MFMA: integer / fp32 / fp64 scalar work bound by HBM/L2 gathers.
+//
+//   MC  : PathManager::buildMonteCarlo     reference src/PathManager.cpp:12-177
+//   DET : PathManager::buildDeterministic  reference src/PathManager.cpp:179-386
+//   length bookkeeping : Path::updateLength  reference src/Path.cpp:6-16
+//   RNG : std::mt19937 + generate_canonical<double,53>  (libstdc++ 11, bits/random.tcc:3348-3380)
+#ifndef TLM_WALK_KERNELS_H
+#define TLM_WALK_KERNELS_H
+
+#include "tlm_common.h"
+
+struct WalkArgs {
+    // graph (tlm_graph)
+    const uint32_t *row_ptr;
+    const uint2 *ents;              // ent_es or ent_os
+    const uint32_t *q_start, *t_start;
+    const uint32_t *node_len;
+    const uint8_t *node_flags;
+    uint32_t n_nodes;
+    uint32_t flag_bit;              // 1 << metric
+    int32_t metric;
+    // units
+    const uint32_t *anchors;
+    uint32_t n_anchors;
+    const uint64_t *det_off;
+    uint64_t unit_begin;
+    uint32_t n_work;
+    const uint32_t *work_list;      // unit - unit_begin per work item, or null = identity
+    int32_t rebuild_attempts, backtrack_attempts;
+    int64_t len_threshold;
+    // per-wave scratch
+    uint32_t *sc_nodes, *sc_edges, *sc_log;
+    uint32_t cap;                   // entries per wave in each scratch array
+    uint32_t *bitmaps;
+    uint32_t bm_words;              // words per wave
+    // work queue
+    uint32_t *cursor;
+    // per-unit outputs
+    uint8_t *u_status;
+    uint32_t *u_nnodes, *u_steps, *u_draws;
+    int64_t *u_len;
+    uint64_t *u_evals, *u_off;
+    // arena of accepted paths
+    uint32_t *ar_nodes, *ar_slots;
+    uint64_t ar_cap;
+    unsigned long long *ar_cursor;
+};
+
+constexpr int WALK_BLOCK = 256;                 // 4 independent waves per workgroup
+constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
+
+void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a);
+void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a);
+
+#endif

@@ -209,6 +209,9 @@ CONFIGS: Dict[str, dict] = {
     # low coverage: dead ends, backtracking, abandoned walks
     "sparse": dict(seed=3, genome_len=300_000, n_contigs=3, contig_len=40_000, n_reads=210,
                    read_len_lo=4_000, read_len_hi=12_000),
+    # ~50x coverage: neighbour lists of several 64-entry chunks
+    "dense": dict(seed=4, genome_len=120_000, n_contigs=2, contig_len=30_000, n_reads=700,
+                  read_len_lo=5_000, read_len_hi=12_000),
     # C2 E. coli-like: 4.6 Mb, 3 contigs, 40 k reads mean 8 kb
     "ecoli": dict(seed=12, genome_len=4_600_000, n_contigs=3, contig_len=1_400_000, n_reads=40_000,
                   read_len_lo=3_000, read_len_hi=13_000),

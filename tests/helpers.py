@@ -1,0 +1,101 @@
+"""Shared test plumbing: one dataset -> the oracle's graph (CPU) and the device graph (HIP)."""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+import torch
+
+from oracle import pyoracle as po
+from telomeri_amd import synth
+
+REC_COLS = ("q_len", "q_start", "q_end", "t_len", "t_start", "t_end", "matches", "strand")
+
+
+def oracle_graph(ds: synth.Dataset, fp: po.FilterParams, files=None) -> po.Graph:
+    """files: list of (Records, anchors) in load order; default rr then cr (reference Main.cpp:223)."""
+    g = po.Graph()
+    ctg = ds.name_is_ctg().numpy().astype(np.uint8)
+    for rec, anchors in files or [(ds.rr, False), (ds.cr, True)]:
+        cols = [getattr(rec, c).cpu().numpy() for c in REC_COLS]
+        g.add_records(anchors, fp, ctg, rec.q_id.cpu().numpy(), rec.t_id.cpu().numpy(), *cols)
+    return g
+
+
+def to_oracle_fp(fp) -> po.FilterParams:
+    return po.FilterParams(fp.mode, fp.min_overlap_length, fp.min_overlap_percentage, fp.max_overhang_length,
+                           fp.max_overhang_percentage)
+
+
+def to_oracle_wp(wp) -> po.WalkParams:
+    return po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
+
+
+def device_graph(ctx, ds: synth.Dataset, fp, files=None):
+    files = files or [(ds.rr, False), (ds.cr, True)]
+    recs = [r.to("cuda") for r, _ in files]
+    return ctx.build_graph(fp, recs, [a for _, a in files], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+
+
+def assert_csr_equal(dev_csr, ora_csr) -> None:
+    assert dev_csr.n_nodes == ora_csr.n_nodes
+    assert dev_csr.n_adj == ora_csr.n_adj
+    np.testing.assert_array_equal(dev_csr.row_ptr, ora_csr.row_ptr)
+    np.testing.assert_array_equal(dev_csr.node_len, ora_csr.node_len)
+    np.testing.assert_array_equal(dev_csr.node_anchor, ora_csr.node_anchor)
+    for name in ("nbr", "q_start", "q_end", "t_start", "t_end", "strand"):
+        np.testing.assert_array_equal(getattr(dev_csr, name), getattr(ora_csr, name), err_msg=name)
+    for name in ("os", "si", "es"):   # bit patterns, not values
+        np.testing.assert_array_equal(getattr(dev_csr, name).view(np.uint32), getattr(ora_csr, name).view(np.uint32),
+                                      err_msg=name)
+
+
+def assert_paths_equal(dev_paths, ora_paths) -> None:
+    """Both are packed Path sets (unit, length, off, nodes, slots)."""
+    np.testing.assert_array_equal(dev_paths.unit, ora_paths.unit)
+    np.testing.assert_array_equal(dev_paths.length, ora_paths.length)
+    np.testing.assert_array_equal(dev_paths.off, ora_paths.off)
+    np.testing.assert_array_equal(dev_paths.nodes, ora_paths.nodes)
+    np.testing.assert_array_equal(dev_paths.slots, ora_paths.slots)
+
+
+def assert_stats_equal(dev_stats: np.ndarray, ora_stats: np.ndarray) -> None:
+    for f in ("status", "n_nodes", "steps", "evals", "draws", "length"):
+        bad = np.nonzero(dev_stats[f] != ora_stats[f])[0]
+        assert bad.size == 0, "per-unit %s differs at units %s: device %s oracle %s" % (
+            f, bad[:8], dev_stats[f][bad[:8]], ora_stats[f][bad[:8]])
+
+
+def quirks_dataset(seed: int = 5) -> synth.Dataset:
+    """A small dataset plus the record shapes the reference treats specially:
+    multi-edges, self overlaps, a contig<->contig record, a `ctg` name as QUERY of a cr record,
+    a read first seen in the cr file, records that fail the filter, shuffled record order."""
+    ds = synth.make_dataset("quirks", seed=seed, genome_len=150_000, n_contigs=3, contig_len=25_000, n_reads=160,
+                            read_len_lo=4_000, read_len_hi=11_000)
+    g = torch.Generator().manual_seed(seed)
+    rr, cr = ds.rr, ds.cr
+    # 15 % multi-edges: repeat some rr records with shifted coordinates
+    n = len(rr)
+    dup = torch.nonzero(torch.rand(n, generator=g) < 0.15).flatten()
+    extra = rr.take(dup)
+    extra.q_start = extra.q_start + 7
+    extra.q_end = torch.maximum(extra.q_end - 5, extra.q_start + 1)
+    extra.matches = torch.clamp(extra.matches - 11, min=0)
+    # self overlaps (same name): must be rejected by OverlapGraph.cpp:157
+    selfo = rr.take(torch.arange(0, min(n, 40), 4))
+    selfo.t_id = selfo.q_id.clone()
+    rr = rr.cat(extra).cat(selfo)
+    perm = torch.randperm(len(rr), generator=g)
+    rr = rr.take(perm)
+    # cr: a contig<->contig record (forced-anchor rule, DET break), a ctg-as-query record, shuffled
+    nreads = ds.n_reads
+    def rec(q, t, ql, qs, qe, tl, ts, te, m, s):
+        i32 = lambda v: torch.tensor([v], dtype=torch.int32)
+        return synth.Records(i32(q), i32(t), i32(ql), i32(qs), i32(qe), i32(tl), i32(ts), i32(te), i32(m), i32(s))
+    c2c = rec(nreads + 1, nreads + 0, 25_000, 20_000, 24_990, 25_000, 10, 5_000, 4_500, 0)     # ctg2 (query) -> ctg1
+    r = int(cr.q_id[0])
+    cq = rec(nreads + 2, r, 25_000, 100, 6_000, int(ds.read_len[r]), 50, 5_950, 5_000, 1)     # ctg3 as QUERY vs a read
+    cr = cr.cat(c2c).cat(cq)
+    perm = torch.randperm(len(cr), generator=g)
+    cr = cr.take(perm)
+    return dataclasses.replace(ds, rr=rr, cr=cr)

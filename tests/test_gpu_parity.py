@@ -1,0 +1,272 @@
+"""GPU parity proper: the HIP path, called through the C ABI, against the oracle (CPU restatement of
+the reference, pinned by tests/test_oracle_*.py).  Bar: bit-exact -- node numbering, adjacency order,
+fp32 bit patterns of SI/OS/ES, every accepted path (nodes, edge slots, length, order) and the
+per-unit counters (steps, evals, draws) under the deterministic builder and per-walk-seeded MC.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import pyoracle as po
+from telomeri_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return capi.Context(0)
+
+
+def _walk_both(ctx, dg, og, metric, wp, *, mc, unit_begin=0, unit_end=None):
+    if mc:
+        ps = dg.walk_mc(metric, wp, unit_begin, unit_end)
+        ops, octr, ostats = og.walk_mc(metric, H.to_oracle_wp(wp), po.SEED_PER_WALK, unit_begin, unit_end)
+    else:
+        ps = dg.walk_det(metric, unit_begin, unit_end)
+        ops, octr, ostats = og.walk_det(metric, unit_begin, unit_end)
+    H.assert_stats_equal(ps.unit_stats(), ostats)
+    H.assert_paths_equal(ps.to_host(), ops)
+    c = ps.counters
+    assert (c.units, c.steps, c.evals, c.draws, c.accepted) == (octr.units, octr.steps, octr.evals, octr.draws,
+                                                                octr.accepted)
+    return ps, ops
+
+
+# ---------------------------------------------------------------------------------------------
+# a2 + a3
+
+@pytest.mark.parametrize("mode,extra", [("avg", {}), ("min", {}), ("max", {}), ("sum", {}),
+                                        ("avg", dict(min_oll=5000, min_olp=0.05, max_ohl=3000, max_ohp=0.1))])
+def test_filter_score_bits(ctx, mode, extra):
+    ds = synth.make_config("toy")
+    rec = ds.rr.cat(ds.cr)
+    fp = capi.FilterParams.default(mode, **extra)
+    keep, si, os_, es, nk = ctx.filter_score(fp, rec.to("cuda"))
+    cols = [getattr(rec, c).numpy() for c in H.REC_COLS[:7]]
+    same = (rec.q_id == rec.t_id).numpy().astype(np.uint8)
+    okeep, osi, oos, oes = po.filter_score(H.to_oracle_fp(fp), *cols, same)
+    np.testing.assert_array_equal(keep.cpu().numpy(), okeep)
+    assert nk == int(okeep.sum())
+    for dev, ora in ((si, osi), (os_, oos), (es, oes)):
+        np.testing.assert_array_equal(dev.cpu().numpy().view(np.uint32), ora.view(np.uint32))
+
+
+def test_filter_score_edge_values(ctx):
+    """zero-length sequences, negative overlaps, zero overlap (0/0), INT extremes: same bits as x86."""
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32)
+    rec = synth.Records(q_id=i32([0, 1, 2, 3, 4, 5]), t_id=i32([1, 2, 3, 4, 5, 5]),
+                        q_len=i32([0, 1000, 1000, 2_000_000_000, 5, 10]), q_start=i32([0, 500, 10, 0, 0, 0]),
+                        q_end=i32([0, 400, 10, 1_000_000_000, 5, 10]), t_len=i32([0, 1000, 1000, 2_000_000_000, 7, 10]),
+                        t_start=i32([0, 0, 20, 5, 1, 0]), t_end=i32([0, 900, 20, 1_000_000_005, 6, 10]),
+                        matches=i32([0, 100, 0, 900_000_000, 5, 10]), strand=i32([0, 1, 0, 1, 0, 0]))
+    for mode in ("avg", "min", "max", "sum"):
+        fp = capi.FilterParams.default(mode)
+        keep, si, os_, es, nk = ctx.filter_score(fp, rec.to("cuda"))
+        cols = [getattr(rec, c).numpy() for c in H.REC_COLS[:7]]
+        okeep, osi, oos, oes = po.filter_score(H.to_oracle_fp(fp), *cols, (rec.q_id == rec.t_id).numpy().astype(np.uint8))
+        np.testing.assert_array_equal(keep.cpu().numpy(), okeep, err_msg=mode)
+        for dev, ora in ((si, osi), (os_, oos), (es, oes)):
+            np.testing.assert_array_equal(dev.cpu().numpy().view(np.uint32), ora.view(np.uint32), err_msg=mode)
+
+
+def test_filter_score_empty(ctx):
+    ds = synth.make_config("tiny")
+    rec = ds.rr.take(torch.zeros(0, dtype=torch.long))
+    keep, si, os_, es, nk = ctx.filter_score(capi.FilterParams.default(), rec.to("cuda"))
+    assert nk == 0 and keep.numel() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# a4
+
+@pytest.mark.parametrize("name,mode", [("tiny", "avg"), ("toy", "avg"), ("toy", "min"), ("sparse", "avg"),
+                                       ("dense", "avg")])
+def test_graph_build_matches_oracle(ctx, name, mode):
+    ds = synth.make_config(name)
+    fp = capi.FilterParams.default(mode)
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    H.assert_csr_equal(dg.download(), og.csr())
+    gi = dg.info()
+    assert gi.n_records == len(ds.rr) + len(ds.cr)
+    assert gi.n_kept * 2 == gi.n_adj
+    ids = dg.download().node_name_id
+    assert [og.node_ext_id(i) for i in range(len(ids))] == ids.tolist()
+
+
+def test_graph_build_quirks(ctx):
+    ds = H.quirks_dataset()
+    for mode in ("avg", "min"):
+        fp = capi.FilterParams.default(mode)
+        dg = H.device_graph(ctx, ds, fp)
+        og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+        H.assert_csr_equal(dg.download(), og.csr())
+        assert dg.det_units() == og.det_units()
+
+
+def test_graph_build_single_file_and_empty(ctx):
+    ds = synth.make_config("tiny")
+    fp = capi.FilterParams.default()
+    dg = H.device_graph(ctx, ds, fp, files=[(ds.cr, True)])
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp), files=[(ds.cr, True)])
+    H.assert_csr_equal(dg.download(), og.csr())
+    # a filter that keeps nothing: an empty graph, no walk units, empty path sets
+    fp0 = capi.FilterParams.default("avg", min_oll=10 ** 9)
+    dg0 = H.device_graph(ctx, ds, fp0)
+    assert dg0.info().n_nodes == 0 and dg0.info().n_adj == 0
+    wp = capi.WalkParams.default(rb_att=5)
+    assert dg0.mc_units(wp) == 0 and dg0.det_units() == 0
+    ps = dg0.walk_mc(capi.METRIC_ES, wp)
+    assert ps.n_paths == 0 and ps.n_units == 0
+    assert len(ps.to_host()) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# a7 / a8
+
+@pytest.mark.parametrize("name,rb,bt", [("tiny", 60, 60), ("toy", 40, 60), ("sparse", 80, 3), ("sparse", 40, 0),
+                                        ("dense", 30, 60)])
+@pytest.mark.parametrize("metric", [capi.METRIC_ES, capi.METRIC_OS])
+def test_walk_mc_per_walk_seed(ctx, name, rb, bt, metric):
+    ds = synth.make_config(name)
+    fp = capi.FilterParams.default()
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    wp = capi.WalkParams.default(rb_att=rb, bt_att=bt)
+    assert dg.mc_units(wp) == og.mc_units(H.to_oracle_wp(wp))
+    ps, ops = _walk_both(ctx, dg, og, metric, wp, mc=True)
+    if name != "sparse":
+        assert ps.n_paths > 0          # the comparison is not vacuous
+
+
+@pytest.mark.parametrize("name", ["tiny", "toy", "sparse", "dense"])
+@pytest.mark.parametrize("metric", [capi.METRIC_ES, capi.METRIC_OS])
+def test_walk_det(ctx, name, metric):
+    ds = synth.make_config(name)
+    fp = capi.FilterParams.default()
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    assert dg.det_units() == og.det_units()
+    _walk_both(ctx, dg, og, metric, None, mc=False)
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_ES_SQRT, capi.METRIC_OS_SQRT])
+def test_walks_quirks_all_metrics(ctx, metric):
+    """multi-edges (DET re-find of the first entry with the same neighbour), contig<->contig edges
+    (forced anchor rule, DET first-edge break), filter-min graph with high-degree contigs."""
+    ds = H.quirks_dataset()
+    fp = capi.FilterParams.default("min")
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    wp = capi.WalkParams.default(rb_att=50, bt_att=5)
+    ps, _ = _walk_both(ctx, dg, og, metric, wp, mc=True)
+    pd, _ = _walk_both(ctx, dg, og, metric, None, mc=False)
+    assert ps.n_paths + pd.n_paths > 0
+
+
+def test_walk_unit_ranges_concatenate(ctx):
+    """Sharding contract: any partition of the units yields the same paths."""
+    ds = synth.make_config("tiny")
+    fp = capi.FilterParams.default()
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    wp = capi.WalkParams.default(rb_att=30)
+    total = dg.mc_units(wp)
+    cut = total // 3 + 1
+    whole = dg.walk_mc(capi.METRIC_ES, wp).to_host()
+    a, _ = _walk_both(ctx, dg, og, capi.METRIC_ES, wp, mc=True, unit_begin=0, unit_end=cut)
+    b, _ = _walk_both(ctx, dg, og, capi.METRIC_ES, wp, mc=True, unit_begin=cut, unit_end=total)
+    ha, hb = a.to_host(), b.to_host()
+    np.testing.assert_array_equal(np.concatenate([ha.unit, hb.unit]), whole.unit)
+    np.testing.assert_array_equal(np.concatenate([ha.nodes, hb.nodes]), whole.nodes)
+    np.testing.assert_array_equal(np.concatenate([ha.slots, hb.slots]), whole.slots)
+    dtot = dg.det_units()
+    d1, _ = _walk_both(ctx, dg, og, capi.METRIC_OS, None, mc=False, unit_begin=0, unit_end=dtot // 2)
+    d2, _ = _walk_both(ctx, dg, og, capi.METRIC_OS, None, mc=False, unit_begin=dtot // 2, unit_end=dtot)
+    dw = dg.walk_det(capi.METRIC_OS).to_host()
+    np.testing.assert_array_equal(np.concatenate([d1.to_host().nodes, d2.to_host().nodes]), dw.nodes)
+
+
+def test_walk_overflow_reruns(ctx):
+    """A tiny path buffer forces the scratch-overflow re-run; results must not change."""
+    ds = synth.make_config("tiny")
+    fp = capi.FilterParams.default()
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    c2 = capi.Context(0)
+    c2.set_walk_tuning(waves_per_cu=2, path_capacity=8)
+    dg = H.device_graph(c2, ds, fp)
+    wp = capi.WalkParams.default(rb_att=25)
+    ps, _ = _walk_both(c2, dg, og, capi.METRIC_ES, wp, mc=True)
+    assert ps.counters.kernel_launches >= 2
+    pd, _ = _walk_both(c2, dg, og, capi.METRIC_ES, None, mc=False)
+
+
+def _synthetic_csr(n_reads=400, deg=90, seed=0, wild=False):
+    """A random graph handed over as CSR (tlm_graph_from_csr): degrees above one 64-lane chunk,
+    optionally metrics whose double sums are NOT exact (forces the in-order serial summation)."""
+    rng = np.random.default_rng(seed)
+    n = n_reads + 3
+    anchors = np.zeros(n, np.uint8)
+    anchors[[5, n // 2, n - 2]] = 1
+    rows = []
+    for i in range(n):
+        d = int(rng.integers(2, deg))
+        nb = rng.integers(0, n, size=d)
+        nb = nb[nb != i]
+        rows.append(nb)
+    row_ptr = np.zeros(n + 1, np.uint64)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    nbr = np.concatenate(rows).astype(np.uint32)
+    a = nbr.shape[0]
+    if wild:
+        ex = rng.integers(-40, 60, size=a)
+        es = (rng.random(a).astype(np.float32) + np.float32(0.5)) * np.exp2(ex).astype(np.float32)
+        os_ = (rng.random(a).astype(np.float32) + np.float32(0.5)) * np.exp2(-ex).astype(np.float32)
+    else:
+        es = (rng.random(a) * 20000).astype(np.float32)
+        os_ = (rng.random(a) * 9000).astype(np.float32)
+    q_start = rng.integers(0, 9000, size=a).astype(np.uint32)
+    t_start = rng.integers(0, 6000, size=a).astype(np.uint32)
+    node_len = rng.integers(20000, 90000, size=n).astype(np.uint32)
+    return row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors
+
+
+@pytest.mark.parametrize("wild", [False, True])
+def test_walks_on_adopted_csr(ctx, wild):
+    row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors = _synthetic_csr(wild=wild)
+    dg = ctx.graph_from_csr(row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    og = po.Graph.from_csr(row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    gi = dg.info()
+    if wild:
+        assert gi.unsafe_nodes[0] > 0 and gi.unsafe_nodes[1] > 0      # the serial path is exercised
+    else:
+        assert gi.unsafe_nodes[0] == 0 and gi.unsafe_nodes[1] == 0
+    wp = capi.WalkParams.default(rb_att=40, bt_att=4, len_thr=400_000)
+    for metric in (capi.METRIC_ES, capi.METRIC_OS):
+        _walk_both(ctx, dg, og, metric, wp, mc=True)
+        _walk_both(ctx, dg, og, metric, None, mc=False)
+
+
+def test_rng_stream_through_long_walks(ctx):
+    """More than 312 draws in one walk crosses an mt19937 twist on the device."""
+    row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors = _synthetic_csr(n_reads=3000, deg=40, seed=3)
+    anchors[:] = 0
+    anchors[7] = 1                       # a single anchor: walks only end by length or dead end
+    q_start[:] = 10                      # +5 bp per step: the length cap is never reached
+    t_start[:] = 5
+    dg = ctx.graph_from_csr(row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    og = po.Graph.from_csr(row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    wp = capi.WalkParams.default(rb_att=6, bt_att=2)
+    ps, _ = _walk_both(ctx, dg, og, capi.METRIC_ES, wp, mc=True)
+    assert ps.unit_stats()["draws"].max() > 700
+
+
+def test_no_cpu_fallback_symbols():
+    """The product library must not link or load the oracle."""
+    import subprocess
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    nm = subprocess.run(["nm", "-D", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "tlo_" not in nm
