@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- edge-extension evals/sec of the path build (BASELINE.json metric) on MI355X.
+
+A "step" is one pass of the hot path over this rank's batch: the four builders of reference
+Main.cpp:237-243 (MC/ES, MC/OS, DET/ES, DET/OS) over the rank's anchor bundle on the resident CSR, then
+(N > 1) the single all-gather of the Path sets.  Inputs are resident in HBM before the timed region:
+the synthetic A. thaliana-shaped overlaps are generated on the GPU (telomeri_amd.synth), filtered,
+scored and turned into the CSR by the library; graph-build timings are reported beside the metric.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Weak scaling: every rank walks `--anchors-per-gpu` anchors (25 = 200 anchors / 8 GPUs, the A. thaliana
+config) with the reference's default 2000 Monte-Carlo trials per anchor.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="athaliana", help="telomeri_amd.synth.CONFIGS entry")
+    ap.add_argument("--anchors-per-gpu", type=int, default=25)
+    ap.add_argument("--rb-att", type=int, default=2000)
+    ap.add_argument("--bt-att", type=int, default=60)
+    ap.add_argument("--len-thr", type=int, default=4_700_000)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--no-det", action="store_true", help="skip the deterministic builders (diagnostics only)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (reported as cores)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from telomeri_amd import capi, pathgather, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    t0 = time.time()
+    ctx = capi.Context(local_rank)
+    if args.waves_per_cu:
+        ctx.set_walk_tuning(args.waves_per_cu, 0)
+    ds = synth.make_config(args.config, device=str(dev))
+    torch.cuda.synchronize(dev)
+    t_gen = time.time() - t0
+    fp = capi.FilterParams.default()
+    t0 = time.time()
+    g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+    t_build = time.time() - t0
+    gi = g.info()
+    n_records = int(gi.n_records)
+    del ds
+    torch.cuda.empty_cache()
+    if rank == 0:
+        log("dataset %s: %d records generated in %.1fs; graph %d nodes / %d adjacency entries / %d anchors built in "
+            "%.2fs (device %.1f ms, filter_score %.2f ms); max degree %d; unsafe nodes %s" % (
+                args.config, n_records, t_gen, gi.n_nodes, gi.n_adj, gi.n_anchors, t_build, gi.build_ms, gi.filter_ms,
+                gi.max_degree, list(gi.unsafe_nodes)))
+
+    wp = capi.WalkParams.default(args.rb_att, args.bt_att, args.len_thr)
+    n_anchors = int(gi.n_anchors)
+    apg = min(args.anchors_per_gpu, max(1, n_anchors // world))
+    a0, a1 = rank * apg, rank * apg + apg
+    mc_range = (a0 * args.rb_att, a1 * args.rb_att)
+    _, det_off = g.anchor_table()
+    d0, d1 = int(det_off[a0]), int(det_off[a1])
+
+    def one_step():
+        sets, ctrs = [], []
+        for metric in (capi.METRIC_ES, capi.METRIC_OS):
+            ps = g.walk_mc(metric, wp, *mc_range)
+            sets.append(ps); ctrs.append(("mc", ps.counters))
+        if not args.no_det:
+            for metric in (capi.METRIC_ES, capi.METRIC_OS):
+                ps = g.walk_det(metric, d0, d1)
+                sets.append(ps); ctrs.append(("det", ps.counters))
+        if world > 1:
+            packed = [pathgather.PackedPaths(*ps.to_device_tensors(dev)) for ps in sets]
+            gathered = pathgather.allgather_paths(packed)
+            n_total = sum(p.n_paths for p in gathered)
+        else:
+            n_total = sum(ps.n_paths for ps in sets)
+        return ctrs, n_total
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.time()
+    evals = 0
+    mc_ms = mc_evals = mc_launches = 0.0
+    det_ms = det_evals = det_launches = 0.0
+    paths_total = 0
+    for _ in range(args.steps):
+        ctrs, paths_total = one_step()
+        for kind, c in ctrs:
+            evals += int(c.evals)
+            if kind == "mc":
+                mc_ms += c.kernel_ms; mc_evals += int(c.evals); mc_launches += c.kernel_launches
+            else:
+                det_ms += c.kernel_ms; det_evals += int(c.evals); det_launches += c.kernel_launches
+    sync()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(evals)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        evals_all = float(tsum[1])
+    else:
+        evals_all = float(evals)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = evals_all / elapsed
+    # roofline of the dominant kernel (walk_mc_kernel): 8 algorithmic bytes per eval
+    ach = 8.0 * mc_evals / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.config, {}).get("walk_mc_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "edge-extension evals/sec in path build",
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s-shaped synthetic overlaps (telomeri_amd.synth.CONFIGS['%s']): %d PAF records -> "
+                               "%d nodes, %d adjacency entries; per GPU %d anchors x (%d MC trials x {ES,OS} + DET "
+                               "first edges x {ES,OS})" % (args.config, args.config, n_records, gi.n_nodes, gi.n_adj,
+                                                           apg, args.rb_att),
+                   "anchors_per_gpu": apg, "rebuild_attempts": args.rb_att, "backtrack_attempts": args.bt_att,
+                   "len_threshold": args.len_thr, "seed_policy": "per-walk mt19937",
+                   "partition": "anchor bundles per rank, CSR replicated, one all-gather of Paths"},
+        "roofline": {"bound": "hbm", "kernel": "walk_mc_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                     "frac": ach / 8000.0, "traffic": traffic,
+                     "launches": int(mc_launches), "avg_launch_ms": mc_ms / max(mc_launches, 1),
+                     "algorithmic_bytes_per_eval": 8, "evals_per_launch": mc_evals / max(mc_launches, 1)},
+        "kernels": {"walk_mc_ms_per_step": mc_ms / max(args.steps, 1), "walk_det_ms_per_step": det_ms / max(args.steps, 1),
+                    "walk_mc_evals_per_s": mc_evals / (mc_ms * 1e-3) if mc_ms else None,
+                    "walk_det_evals_per_s": det_evals / (det_ms * 1e-3) if det_ms else None,
+                    "graph_build_device_ms": gi.build_ms, "filter_score_ms": gi.filter_ms,
+                    "filter_score_records_per_s": n_records / (gi.filter_ms * 1e-3) if gi.filter_ms else None,
+                    "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
+        "paths_per_step": paths_total,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, g, wp, g.download(cold=False), mc_range, capi)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, g, wp, h, mc_range, capi):
+    """The oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on a
+    bounded sample of the SAME workload: the first units of this rank's MC/ES bundle.  Also checks that
+    the device reports identical per-unit evals for that sample."""
+    import numpy as np
+    from oracle import pyoracle as po
+    og = po.Graph.from_csr(h.row_ptr, h.nbr, h.q_start, h.t_start, h.os, h.es, h.node_len, h.node_anchor)
+    owp = po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = max(1, min(cores, args.cpu_threads))   # a 1-GPU box's CPU share is 16 cores
+    # calibrate on a few units, single thread
+    u0 = mc_range[0]
+    t0 = time.time()
+    _, c1, _ = og.walk_mc(po.METRIC_ES, owp, po.SEED_PER_WALK, u0, u0 + 4, 1)
+    dt = max(time.time() - t0, 1e-4)
+    per_unit = dt / 4
+    n1 = int(max(4, min(mc_range[1] - u0, args.cpu_seconds * 0.4 / per_unit)))
+    t0 = time.time()
+    _, c1, s1 = og.walk_mc(po.METRIC_ES, owp, po.SEED_PER_WALK, u0, u0 + n1, 1)
+    dt1 = time.time() - t0
+    nall = int(max(cores * 4, min(mc_range[1] - u0, args.cpu_seconds * 0.6 * cores / per_unit)))
+    t0 = time.time()
+    _, call, sall = og.walk_mc(po.METRIC_ES, owp, po.SEED_PER_WALK, u0, u0 + nall, cores)
+    dtall = time.time() - t0
+    # parity of the sample against the device
+    ps = g.walk_mc(capi.METRIC_ES, wp, u0, u0 + nall)
+    dstat = ps.unit_stats()
+    same = bool(np.array_equal(dstat["evals"], sall["evals"]) and np.array_equal(dstat["status"], sall["status"])
+                and np.array_equal(dstat["length"], sall["length"]))
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": call.evals / dtall, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "MC/ES units [%d,%d) of the same graph on %d threads (%.1fs); 1 thread: %d units, %.3g evals/s" % (
+                u0, u0 + nall, cores, dtall, n1, c1.evals / dt1),
+            "value_1thread": c1.evals / dt1, "cpu_model": model, "sample_matches_device": same}
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,10 @@ int tlm_graph_download(const tlm_graph *g, uint64_t *row_ptr, uint32_t *nbr, uin
  * visits (it stops after the first edge that leads straight to an anchor, PathManager.cpp:224-229). */
 uint64_t tlm_mc_units(const tlm_graph *g, const tlm_walk_params *p);
 uint64_t tlm_det_units(const tlm_graph *g);
+/* The unit tables, HOST buffers: anchor_nodes[n_anchors] = node index of each anchor in node order,
+ * det_off[n_anchors+1] = prefix of DET units per anchor (anchor k owns DET units
+ * [det_off[k], det_off[k+1]) and MC units [k*rebuild_attempts, (k+1)*rebuild_attempts)).  Either may be NULL. */
+int tlm_graph_anchor_table(const tlm_graph *g, uint32_t *anchor_nodes, uint64_t *det_off);
 /* Seed of the std::mt19937 owned by MC walk (anchor node, trial r) under `metric`. */
 uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r);
 

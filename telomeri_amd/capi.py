@@ -102,6 +102,7 @@ def lib() -> C.CDLL:
     L.tlm_mc_units.restype = C.c_uint64
     L.tlm_det_units.argtypes = [V]
     L.tlm_det_units.restype = C.c_uint64
+    L.tlm_graph_anchor_table.argtypes = [V, V, V]
     L.tlm_walk_seed.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
     L.tlm_walk_seed.restype = C.c_uint32
     L.tlm_walk_mc.argtypes = [V, V, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, P(V), P(Counters)]
@@ -125,7 +126,7 @@ def _np_ptr(a: Optional[np.ndarray]):
 
 @dataclasses.dataclass
 class HostPaths:
-    """Packed Path set on the host (same layout as oracle.pyoracle.PathSet)."""
+    """Packed Path set on the host: path i = nodes[off[i]:off[i+1]], slots likewise (last slot 0xFFFFFFFF)."""
     unit: np.ndarray
     length: np.ndarray
     off: np.ndarray
@@ -141,8 +142,9 @@ class HostPaths:
 
 
 class PathSet:
-    def __init__(self, handle, counters: Counters) -> None:
+    def __init__(self, handle, counters: Counters, ctx: "Context" = None) -> None:
         self._h = handle
+        self._ctx = ctx              # the context must outlive the path set
         self.counters = counters
         n_paths, n_nodes, n_units = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().tlm_pathset_sizes(self._h, C.byref(n_paths), C.byref(n_nodes), C.byref(n_units)), "tlm_pathset_sizes")
@@ -249,6 +251,14 @@ class Graph:
     def det_units(self) -> int:
         return int(lib().tlm_det_units(self._h))
 
+    def anchor_table(self):
+        """-> (anchor node indices uint32 [n_anchors], DET unit prefix uint64 [n_anchors+1])"""
+        na = int(self.info().n_anchors)
+        anchors = np.zeros(na, np.uint32)
+        det_off = np.zeros(na + 1, np.uint64)
+        _check(lib().tlm_graph_anchor_table(self._h, _np_ptr(anchors), _np_ptr(det_off)), "tlm_graph_anchor_table")
+        return anchors, det_off
+
     def walk_mc(self, metric: int, wp: WalkParams, unit_begin: int = 0, unit_end: Optional[int] = None) -> PathSet:
         if unit_end is None:
             unit_end = self.mc_units(wp)
@@ -256,7 +266,7 @@ class Graph:
         ctr = Counters()
         _check(lib().tlm_walk_mc(self.ctx._h, self._h, metric, C.byref(wp), unit_begin, unit_end, C.byref(h),
                                  C.byref(ctr)), "tlm_walk_mc")
-        return PathSet(h, ctr)
+        return PathSet(h, ctr, self.ctx)
 
     def walk_det(self, metric: int, unit_begin: int = 0, unit_end: Optional[int] = None) -> PathSet:
         if unit_end is None:
@@ -265,7 +275,7 @@ class Graph:
         ctr = Counters()
         _check(lib().tlm_walk_det(self.ctx._h, self._h, metric, unit_begin, unit_end, C.byref(h), C.byref(ctr)),
                "tlm_walk_det")
-        return PathSet(h, ctr)
+        return PathSet(h, ctr, self.ctx)
 
 
 def _records_struct(rec, anchors: bool) -> _Records:

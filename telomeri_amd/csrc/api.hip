@@ -131,7 +131,7 @@ extern "C" int tlm_filter_score(tlm_ctx *ctx, const tlm_filter_params *p, const 
 
 extern "C" void tlm_graph_destroy(tlm_graph *g) {
     if (!g) return;
-    if (g->ctx) (void) hipSetDevice(g->ctx->device);
+    (void) hipSetDevice(g->device);
     (void) hipFree(g->row_ptr); (void) hipFree(g->ent_es); (void) hipFree(g->ent_os);
     (void) hipFree(g->q_start); (void) hipFree(g->t_start); (void) hipFree(g->q_end); (void) hipFree(g->t_end);
     (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
@@ -163,6 +163,7 @@ extern "C" int tlm_graph_from_csr(tlm_ctx *ctx, uint32_t n_nodes, uint64_t n_adj
     hipStream_t s = ctx->stream;
     tlm_graph *g = new tlm_graph();
     g->ctx = ctx;
+    g->device = ctx->device;
     g->n_nodes = n_nodes;
     g->n_adj = n_adj;
     struct Guard { tlm_graph *g; ~Guard() { if (g) tlm_graph_destroy(g); } } guard{g};
@@ -240,6 +241,13 @@ extern "C" uint64_t tlm_mc_units(const tlm_graph *g, const tlm_walk_params *p) {
 }
 
 extern "C" uint64_t tlm_det_units(const tlm_graph *g) { return g ? g->h_det_off.back() : 0; }
+
+extern "C" int tlm_graph_anchor_table(const tlm_graph *g, uint32_t *anchor_nodes, uint64_t *det_off) {
+    TLM_CHECK(g, TLM_EINVAL, "tlm_graph_anchor_table: null graph");
+    if (anchor_nodes && !g->h_anchors.empty()) std::memcpy(anchor_nodes, g->h_anchors.data(), g->h_anchors.size() * 4);
+    if (det_off) std::memcpy(det_off, g->h_det_off.data(), g->h_det_off.size() * 8);
+    return TLM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // result packing kernels
@@ -377,6 +385,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
     TLM_CHECK(!is_mc || (p && p->rebuild_attempts >= 0 && p->backtrack_attempts >= 0), TLM_EINVAL, "walk: bad parameters");
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     TLM_HIP(hipSetDevice(ctx->device));
+    (void) hipGetLastError();     // a stale error of an unrelated earlier call must not be blamed on this one
     hipStream_t s = ctx->stream;
     const uint64_t total = is_mc ? tlm_mc_units(g, p) : tlm_det_units(g);
     if (unit_end > total) unit_end = total;
@@ -387,6 +396,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
 
     tlm_pathset *ps = new tlm_pathset();
     ps->ctx = ctx;
+    ps->device = ctx->device;
     ps->n_units = n_units;
     struct Guard { tlm_pathset *p; ~Guard() { if (p) tlm_pathset_destroy(p); } } guard{ps};
     tlm_counters cnt;
@@ -599,7 +609,7 @@ extern "C" int tlm_pathset_sizes(const tlm_pathset *ps, uint64_t *n_paths, uint6
 extern "C" int tlm_pathset_export(const tlm_pathset *ps, int dst_is_device, uint64_t *unit, int64_t *length,
                                   uint64_t *off, uint32_t *nodes, uint32_t *slots) {
     TLM_CHECK(ps, TLM_EINVAL, "tlm_pathset_export: null path set");
-    TLM_HIP(hipSetDevice(ps->ctx->device));
+    TLM_HIP(hipSetDevice(ps->device));
     hipStream_t s = ps->ctx->stream;
     const hipMemcpyKind k = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (unit && ps->n_paths) TLM_HIP(hipMemcpyAsync(unit, ps->unit, ps->n_paths * 8, k, s));
@@ -619,7 +629,7 @@ extern "C" int tlm_pathset_unit_stats(const tlm_pathset *ps, tlm_unit_stat *stat
 
 extern "C" void tlm_pathset_destroy(tlm_pathset *ps) {
     if (!ps) return;
-    if (ps->ctx) (void) hipSetDevice(ps->ctx->device);
+    (void) hipSetDevice(ps->device);
     (void) hipFree(ps->unit); (void) hipFree(ps->length); (void) hipFree(ps->off); (void) hipFree(ps->nodes);
     (void) hipFree(ps->slots);
     delete ps;

@@ -336,6 +336,8 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
 
     tlm_graph *g = new tlm_graph();
     g->ctx = ctx;
+    g->device = ctx->device;
+    (void) hipGetLastError();
     struct Guard {   // destroy the half-built graph on any early return
         tlm_graph *g;
         ~Guard() { if (g) tlm_graph_destroy(g); }

@@ -47,6 +47,7 @@ struct tlm_ctx {
 //   node_len[N] u32, node_anchor[N] u8, node_flags[N] u8 (bit m: metric m's sums are order-safe)
 struct tlm_graph {
     tlm_ctx *ctx = nullptr;
+    int device = 0;                    // copy of ctx->device: destroy must not touch a dead context
     uint32_t n_nodes = 0;
     uint64_t n_adj = 0;
     uint32_t *row_ptr = nullptr;
@@ -70,6 +71,7 @@ enum : uint8_t { ST_ABANDONED = 0, ST_ACCEPTED = 1, ST_NEGATIVE = 2, ST_SCRATCH_
 
 struct tlm_pathset {
     tlm_ctx *ctx = nullptr;
+    int device = 0;
     uint64_t n_units = 0, n_paths = 0, n_nodes_total = 0;
     // packed result (device)
     uint64_t *unit = nullptr;

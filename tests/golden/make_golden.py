@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the UNMODIFIED reference (oracle/_ref, built by `make -C oracle ref`
+from the sources under /root/reference).  Run in the build container only; the fixtures it writes
+are data (inputs + the reference's outputs), committed so that they travel to the GPU box where the
+reference does not exist.
+
+    python tests/golden/make_golden.py
+
+Fixtures
+  ecoli_cr.paf.gz            the reference's own bundled data file test/res/EColi_CR_overlaps.paf
+  ecoli_cr_known.json        what the reference loads from it under 5 filter settings
+  <set>_rr.paf.gz, <set>_cr.paf.gz, <set>.dump.gz, <set>.json
+                             synthetic inputs (telomeri_amd.synth / tests.helpers), the reference's
+                             graph + the four builders' path lists (ref_dump format), and the
+                             arguments used
+  mt19937.json               std::mt19937(5489) raw outputs and uniform_real_distribution<double>
+                             values from libstdc++ (a 10-line C++ program compiled here)
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from oracle import pyoracle as po  # noqa: E402
+from telomeri_amd import synth  # noqa: E402
+import helpers as H  # noqa: E402
+
+REF_FIXTURE = "/root/reference/test/res/EColi_CR_overlaps.paf"
+
+
+def gz_write(src: str, dst: str) -> None:
+    with open(src, "rb") as fi, gzip.GzipFile(dst, "wb", mtime=0) as fo:
+        shutil.copyfileobj(fi, fo)
+
+
+def graph_digest(d: po.RefDump) -> str:
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(d.node_anchor).tobytes())
+    h.update(np.ascontiguousarray(d.node_len).tobytes())
+    h.update("\n".join(d.node_name).encode())
+    h.update(np.ascontiguousarray(d.adj).tobytes())
+    return h.hexdigest()
+
+
+def main() -> None:
+    assert po.have_ref(), "build the reference first: make -C oracle ref"
+    tmp = tempfile.mkdtemp(prefix="tlm_golden_")
+    empty = os.path.join(tmp, "empty.paf")
+    open(empty, "w").close()
+
+    # --- 1. the bundled fixture and its known-answer table
+    gz_write(REF_FIXTURE, os.path.join(HERE, "ecoli_cr.paf.gz"))
+    known = {}
+    settings = {
+        "avg": ["--filter-avg"], "sum": ["--filter-sum"], "min": ["--filter-min"], "max": ["--filter-max"],
+        "strict": ["--min-oll", "5000", "--max-ohp", "0.1", "--min-olp", "0.05", "--max-ohl", "3000"],
+    }
+    for key, args in settings.items():
+        d = po.run_ref_dump(empty, REF_FIXTURE, os.path.join(tmp, "fx.dump"), args + ["--rb-att", "20"])
+        os_bits = d.adj[:, 7].astype(np.uint32).view(np.float32)
+        es_bits = d.adj[:, 9].astype(np.uint32).view(np.float32)
+        known[key] = {
+            "args": args, "kept": int(d.adj.shape[0] // 2), "nodes": len(d.node_name),
+            "anchors": int(d.node_anchor.sum()), "max_con": int(d.node_deg.max()),
+            "min_os": float(os_bits.min()), "max_os": float(os_bits.max()),
+            "min_es": float(es_bits.min()), "max_es": float(es_bits.max()),
+            "graph_sha256": graph_digest(d),
+            "paths": {str(b): len(p) for b, p in d.builders.items()},
+        }
+    json.dump(known, open(os.path.join(HERE, "ecoli_cr_known.json"), "w"), indent=1, sort_keys=True)
+
+    # --- 2. synthetic sets with full dumps
+    sets = {
+        "tiny": (synth.make_config("tiny"), ["--rb-att", "60"]),
+        "sparse": (synth.make_config("sparse"), ["--rb-att", "80", "--bt-att", "3"]),
+        "quirks": (H.quirks_dataset(), ["--filter-min", "--rb-att", "50", "--bt-att", "5", "--sqrt"]),
+    }
+    for name, (ds, args) in sets.items():
+        rr, cr = os.path.join(tmp, name + "_rr.paf"), os.path.join(tmp, name + "_cr.paf")
+        synth.write_paf(ds, ds.rr, rr)
+        synth.write_paf(ds, ds.cr, cr)
+        dump = os.path.join(tmp, name + ".dump")
+        d = po.run_ref_dump(rr, cr, dump, args)
+        gz_write(rr, os.path.join(HERE, name + "_rr.paf.gz"))
+        gz_write(cr, os.path.join(HERE, name + "_cr.paf.gz"))
+        gz_write(dump, os.path.join(HERE, name + ".dump.gz"))
+        json.dump({"args": args, "paths": {str(b): len(p) for b, p in d.builders.items()},
+                   "nodes": len(d.node_name), "adj": int(d.adj.shape[0])},
+                  open(os.path.join(HERE, name + ".json"), "w"), indent=1, sort_keys=True)
+        print(name, len(d.node_name), d.adj.shape[0], {b: len(p) for b, p in d.builders.items()})
+
+    # --- 3. libstdc++ RNG vectors
+    src = os.path.join(tmp, "rng.cpp")
+    open(src, "w").write(r'''
+#include <random>
+#include <cstdio>
+#include <cstring>
+int main() {
+    std::mt19937 g;                       // default seed 5489 (PathManager.cpp:13)
+    std::printf("{\"raw\": [");
+    for (int i = 0; i < 16; i++) std::printf("%s%u", i ? ", " : "", (unsigned) g());
+    std::mt19937 g2;
+    g2.discard(9999);
+    std::printf("], \"raw_10000th\": %u, \"canonical_bits\": [", (unsigned) g2());
+    std::mt19937 g3;
+    std::uniform_real_distribution<> dis(0., 1.);   // PathManager.cpp:14
+    for (int i = 0; i < 700; i++) {        // crosses a twist (624 words = 312 doubles)
+        double d = dis(g3); unsigned long long u; std::memcpy(&u, &d, 8);
+        std::printf("%s%llu", i ? ", " : "", u);
+    }
+    std::mt19937 g4(123456789u);
+    std::printf("], \"seed\": 123456789, \"seed_canonical_bits\": [");
+    for (int i = 0; i < 8; i++) {
+        double d = dis(g4); unsigned long long u; std::memcpy(&u, &d, 8);
+        std::printf("%s%llu", i ? ", " : "", u);
+    }
+    std::printf("]}\n");
+}
+''')
+    exe = os.path.join(tmp, "rng")
+    subprocess.run(["g++", "-O1", "-o", exe, src], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    json.dump(json.loads(out), open(os.path.join(HERE, "mt19937.json"), "w"))
+    shutil.rmtree(tmp)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
