@@ -136,6 +136,8 @@ extern "C" void tlm_graph_destroy(tlm_graph *g) {
     (void) hipFree(g->q_start); (void) hipFree(g->t_start); (void) hipFree(g->q_end); (void) hipFree(g->t_end);
     (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
     (void) hipFree(g->node_flags); (void) hipFree(g->node_name_id); (void) hipFree(g->anchors); (void) hipFree(g->det_off);
+    (void) hipFree(g->w_row); (void) hipFree(g->w_ent_es); (void) hipFree(g->w_ent_os); (void) hipFree(g->w_qs);
+    (void) hipFree(g->w_ts);
     delete g;
 }
 
@@ -426,24 +428,33 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         uint32_t cap = ctx->path_capacity ? ctx->path_capacity : 16384u;
         cap = std::max<uint32_t>(8u, std::min(cap, full_cap));
         const uint32_t bm_words = (N + 31) / 32 + 1;
-        const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : 16;
-        uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) wpc;
+        // persistent grid = what is resident at once: blocks/CU from the occupancy query (a block is 4
+        // waves), optionally capped by the tuning knob; never more than 8 blocks (32 waves) per CU
+        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, metric >= 2), 8);
+        if (ctx->waves_per_cu) bpc = std::max(1, std::min(bpc, ctx->waves_per_cu / WALK_WAVES_PER_BLOCK));
+        uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) bpc * WALK_WAVES_PER_BLOCK;
         waves = std::min<uint32_t>(waves, ((n_units + 3) / 4) * 4);
         waves = std::max<uint32_t>(4u, (waves / 4) * 4);
         cnt.waves = waves;
         if (int rc = ensure_scratch(c, waves, cap, bm_words)) return rc;
-        if (int rc = ensure_arena(c, std::max<uint64_t>(1u << 20, (uint64_t) n_units * 256u), 0)) return rc;
+        // arena for the accepted paths: the worst case (every unit accepted at full buffer length) when
+        // that fits 8 GiB, else a guess that the overflow re-run below corrects
+        {
+            const uint64_t worst = (uint64_t) n_units * cap;
+            const uint64_t budget = (8ull << 30) / 8;
+            const uint64_t want = worst <= budget ? worst : std::max<uint64_t>(budget, (uint64_t) n_units * 256u);
+            if (int rc = ensure_arena(c, std::max<uint64_t>(1u << 20, want), 0)) return rc;
+        }
         unsigned long long *ar_cursor = (unsigned long long *) (c->ws.cursor + 2);
         TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 16, s));
 
         WalkArgs a;
         std::memset(&a, 0, sizeof(a));
-        a.row_ptr = g->row_ptr;
-        a.ents = (metric == TLM_METRIC_ES || metric == TLM_METRIC_ES_SQRT) ? g->ent_es : g->ent_os;
-        a.q_start = g->q_start;
-        a.t_start = g->t_start;
+        a.rows = g->w_row;
+        a.ents = (metric == TLM_METRIC_ES || metric == TLM_METRIC_ES_SQRT) ? g->w_ent_es : g->w_ent_os;
+        a.q_start = g->w_qs;
+        a.t_start = g->w_ts;
         a.node_len = g->node_len;
-        a.node_flags = g->node_flags;
         a.n_nodes = N;
         a.flag_bit = 1u << metric;
         a.metric = metric;

@@ -184,14 +184,16 @@ __global__ __launch_bounds__(256) void gather_kernel(FileTable ft, uint64_t n_ad
 }
 
 // step 6a: is every roulette sum over a subset of this node's list independent of the order of
-// the additions?  All |m| are multiples of 2^kmin; if sum|m| < 2^(kmin+52) every partial sum of
-// every subset in every order is exactly representable in a double.  One wave
+// the additions, and non-decreasing along the list?  All m are >= 0 and multiples of 2^kmin; if
+// sum m < 2^(kmin+52) every partial sum of every subset in every order is exactly representable
+// in a double.  One wave
 // per node; the criterion is evaluated for the four metrics of Utils::getMetric.
 __device__ inline void safety_of(float m, int &kmin, double &tot, bool &bad) {
     const uint32_t u = __float_as_uint(m);
     const uint32_t ex = (u >> 23) & 0xFFu, man = u & 0x7FFFFFu;
     if (ex == 0xFFu) { bad = true; return; }          // inf / NaN
     if (ex == 0 && man == 0) return;                  // +-0 contributes nothing
+    if (u >> 31) { bad = true; return; }              // negative: prefix sums would not be monotone
     const uint32_t full = ex ? (man | 0x800000u) : man;
     const int e = (ex ? (int) ex : 1) - 127 - 23;      // value = full * 2^e
     const int k = e + (__ffs((int) full) - 1);
@@ -260,6 +262,38 @@ __global__ void det_count_kernel(uint32_t n_anchors, const uint32_t *__restrict_
     cnt[a] = c;
 }
 
+// walk layout: padded degrees, then (after an exclusive scan) the per-node record and the row copies
+__global__ void padded_degree_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ pd) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) pd[i] = (row_ptr[i + 1] - row_ptr[i] + 3u) & ~3u;
+}
+
+__global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                                          const uint32_t *__restrict__ w_start,
+                                                          const uint8_t *__restrict__ node_flags,
+                                                          const uint2 *__restrict__ ent_es,
+                                                          const uint2 *__restrict__ ent_os,
+                                                          const uint32_t *__restrict__ q_start,
+                                                          const uint32_t *__restrict__ t_start, uint2 *__restrict__ w_row,
+                                                          uint2 *__restrict__ w_ent_es, uint2 *__restrict__ w_ent_os,
+                                                          uint32_t *__restrict__ w_qs, uint32_t *__restrict__ w_ts) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t node = wave; node < n_nodes; node += n_waves) {
+        const uint32_t r0 = row_ptr[node], deg = row_ptr[node + 1] - r0, w0 = w_start[node];
+        const uint32_t pdeg = (deg + 3u) & ~3u;
+        if (lane == 0) w_row[node] = make_uint2(w0, deg | ((uint32_t) node_flags[node] << 24));
+        for (uint32_t j = lane; j < pdeg; j += 64) {
+            const bool real = j < deg;
+            w_ent_es[w0 + j] = real ? ent_es[r0 + j] : make_uint2(0u, 0u);
+            w_ent_os[w0 + j] = real ? ent_os[r0 + j] : make_uint2(0u, 0u);
+            w_qs[w0 + j] = real ? q_start[r0 + j] : 0u;
+            w_ts[w0 + j] = real ? t_start[r0 + j] : 0u;
+        }
+    }
+}
+
 unsigned grid_for(uint64_t n) {
     uint64_t b = (n + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -281,11 +315,51 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     }
     uint32_t h_cnts[8];
     TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, sizeof(h_cnts), hipMemcpyDeviceToHost, s));
+    // walk layout
+    {
+        DevBuf pd, ws;
+        if (int rc = dev_alloc(pd, ((size_t) N + 1) * 4)) return rc;
+        if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
+        uint64_t apad = 0;
+        if (N) {
+            hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, pd.as<uint32_t>());
+            size_t tb = 0;
+            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+                                            rocprim::plus<uint32_t>(), s));
+            DevBuf tmp;
+            if (int rc = dev_alloc(tmp, tb)) return rc;
+            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+                                            rocprim::plus<uint32_t>(), s));
+            uint32_t last_start = 0, last_pd = 0;
+            TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(&last_pd, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipStreamSynchronize(s));
+            apad = (uint64_t) last_start + last_pd;
+            // 3 padding entries per node at most; the u32 scan must not have wrapped
+            TLM_CHECK(g->n_adj + 3ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
+        }
+        g->n_adj_pad = apad;
+        TLM_HIP(hipMalloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2)));
+        TLM_HIP(hipMalloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2)));
+        TLM_HIP(hipMalloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2)));
+        TLM_HIP(hipMalloc((void **) &g->w_qs, (apad + 256) * 4));
+        TLM_HIP(hipMalloc((void **) &g->w_ts, (apad + 256) * 4));
+        // 256 zero entries of slack after the last row: a lane's 4-entry read never leaves the buffer
+        TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
+        TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
+        if (N) {
+            hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
+                               ws.as<uint32_t>(), g->node_flags, g->ent_es, g->ent_os, g->q_start, g->t_start, g->w_row,
+                               g->w_ent_es, g->w_ent_os, g->w_qs, g->w_ts);
+        }
+        TLM_HIP(hipStreamSynchronize(s));
+    }
     std::vector<uint8_t> h_anchor(N);
     if (N) TLM_HIP(hipMemcpyAsync(h_anchor.data(), g->node_anchor, N, hipMemcpyDeviceToHost, s));
     TLM_HIP(hipStreamSynchronize(s));
     for (int m = 0; m < 4; m++) g->info.unsafe_nodes[m] = h_cnts[m];
     g->info.max_degree = h_cnts[4];
+    TLM_CHECK(h_cnts[4] < (1u << 24), TLM_ELIMIT, "a node of degree %u exceeds the 2^24 layout limit", h_cnts[4]);
     g->h_anchors.clear();
     for (uint32_t i = 0; i < N; i++)
         if (h_anchor[i]) g->h_anchors.push_back(i);

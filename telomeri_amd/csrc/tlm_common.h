@@ -58,6 +58,12 @@ struct tlm_graph {
     uint32_t *node_len = nullptr;
     uint8_t *node_anchor = nullptr;
     uint8_t *node_flags = nullptr;
+    // walk layout: every row padded to a multiple of 4 entries (32 B), so that a lane
+    // reads its 4 consecutive entries with two aligned 16-byte loads; one 8-byte record per node
+    uint64_t n_adj_pad = 0;
+    uint2 *w_row = nullptr;            // [N] {padded row start, degree | order-safety flags << 24}
+    uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
+    uint32_t *w_qs = nullptr, *w_ts = nullptr;         // [n_adj_pad]
     int32_t *node_name_id = nullptr;
     uint32_t *anchors = nullptr;       // [n_anchors] node index, ascending
     uint64_t *det_off = nullptr;       // [n_anchors+1] prefix of DET units per anchor

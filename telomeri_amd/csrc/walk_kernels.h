@@ -17,12 +17,11 @@
 #include "tlm_common.h"
 
 struct WalkArgs {
-    // graph (tlm_graph)
-    const uint32_t *row_ptr;
-    const uint2 *ents;              // ent_es or ent_os
+    // graph (tlm_graph, walk layout: rows padded to 4 entries)
+    const uint2 *rows;              // per node {row start, degree | order-safety flags << 24}
+    const uint2 *ents;              // w_ent_es or w_ent_os
     const uint32_t *q_start, *t_start;
     const uint32_t *node_len;
-    const uint8_t *node_flags;
     uint32_t n_nodes;
     uint32_t flag_bit;              // 1 << metric
     int32_t metric;
@@ -56,6 +55,8 @@ struct WalkArgs {
 constexpr int WALK_BLOCK = 256;                 // 4 independent waves per workgroup
 constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
 
+// resident workgroups per CU of the kernel (occupancy query): the persistent grid is sized from it
+int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric);
 void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a);
 void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a);
 

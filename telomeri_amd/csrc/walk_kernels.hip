@@ -84,34 +84,35 @@ __device__ __forceinline__ int64_t edge_delta(const WalkArgs &a, uint32_t e) {
     return (int64_t) a.q_start[e] - (int64_t) a.t_start[e];    // Path.cpp:14
 }
 
-// Inclusive prefix, in list order, of the candidates' metrics of one 64-entry chunk, continuing
-// `carry`.  safe: every partial sum is exact in a double, so the log-step scan equals the
-// reference's sequential `sum += metric` bit for bit; otherwise the additions are done one
-// candidate after the other in list order, exactly as PathManager.cpp:64,109 does them.
-__device__ inline double chunk_scan(double mv, uint64_t cm, double &carry, bool safe, int lane) {
-    double incl;
-    if (safe) {
-        incl = mv;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        incl += carry;
-        carry = __shfl(incl, 63);
-    } else {
-        double run = carry;
-        incl = 0.0;
-        uint64_t mm = cm;
-        while (mm) {
-            const int j = __ffsll((unsigned long long) mm) - 1;
-            mm &= mm - 1;
-            run += __shfl(mv, j);
-            if (lane == j) incl = run;
-        }
-        carry = run;
-    }
-    return incl;
+// ---------------------------------------------------------------------------------------------
+// Wave-level primitives on DPP (data-parallel primitives: lane permutes inside the VALU, no LDS
+// round trip).  gfx9 controls: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, l);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {   // lanes without a source read 0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// inclusive prefix sum over the 64 lanes: 4 shifts inside each row of 16, then the row totals
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+    v += dpp_f64<0x111, 0xf>(v);
+    v += dpp_f64<0x112, 0xf>(v);
+    v += dpp_f64<0x114, 0xf>(v);
+    v += dpp_f64<0x118, 0xf>(v);
+    v += dpp_f64<0x142, 0xa>(v);     // lane 15 of rows 0 / 2 -> rows 1 / 3
+    v += dpp_f64<0x143, 0xc>(v);     // lane 31 -> rows 2 and 3
+    return v;
 }
 
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
@@ -155,7 +156,7 @@ __device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int
             for (uint32_t i = lane; i < n_out; i += 64) {
                 const uint32_t node = ws.pn[i];
                 a.ar_nodes[off + i] = node;
-                a.ar_slots[off + i] = (i < m) ? (ws.pe[i] - a.row_ptr[node]) : 0xFFFFFFFFu;
+                a.ar_slots[off + i] = (i < m) ? (ws.pe[i] - a.rows[node].x) : 0xFFFFFFFFu;
             }
         }
     }
@@ -174,6 +175,234 @@ __device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int
 
 // ---------------------------------------------------------------------------------------------
 // One Monte-Carlo trial: PathManager.cpp:30-160.
+//
+// The selection scan of one step (:53-115) on a wave, BLOCKED layout: a chunk is 256 consecutive
+// entries and lane l owns entries 4l..4l+3 of it (two aligned 16-byte loads: rows are padded to 4
+// entries).  List order is lane-major, so the prefix of entry (l, k) is
+//     [sum of earlier chunks] + [exclusive wave scan of the lane totals](l) + [running sum inside lane l],
+// i.e. ONE 64-lane scan per 256 entries, the rest is lane-local.  On a safe node (all metrics >= 0,
+// every partial sum exact in a double -- node flag from the graph build) any association of the
+// additions gives the reference's bits, and the non-decreasing prefix lets the second pass
+// (:107-114) look only at the one lane whose range contains `random`.  Unsafe nodes take
+// select_serial, which adds one candidate after the other in list order.
+
+struct Selection {
+    int pick;            // position in the list, -1 = none
+    uint32_t nbr;        // neighbour at `pick`
+    bool anchor;         // its anchor flag
+    bool forced;         // taken by the forced-anchor rule (:57-60)
+    uint32_t ncand;      // unvisited neighbours seen (0 with pick < 0 = dead end)
+    uint32_t evals;      // adjacency entries examined
+};
+
+template <bool SQRT>
+__device__ __forceinline__ double metric_f64(uint32_t bits) {
+    float mf = __uint_as_float(bits);
+    if (SQRT) mf = sqrtf(mf);                           // Utils::getMetric, Utils.hpp:47-60
+    return (double) mf;
+}
+
+struct Chunk {           // one lane's 4 entries of a 256-entry chunk
+    uint32_t nb[4];      // neighbour | anchor << 31
+    uint32_t mb[4];      // fp32 bits of the metric
+};
+
+__device__ __forceinline__ Chunk load_chunk(const uint2 *ents, uint32_t row, uint32_t base, int lane) {
+    // row is a multiple of 4 entries and so is base + 4*lane: 32-byte aligned, two dwordx4 loads.  Entries past
+    // the degree are padding or belong to the next row; they are masked by position, never used.
+    const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + base + 4u * (uint32_t) lane);
+    const uint4 lo = p[0], hi = p[1];
+    Chunk c;
+    c.nb[0] = lo.x; c.mb[0] = lo.y; c.nb[1] = lo.z; c.mb[1] = lo.w;
+    c.nb[2] = hi.x; c.mb[2] = hi.y; c.nb[3] = hi.z; c.mb[3] = hi.w;
+    return c;
+}
+
+// forced anchor edge inside one chunk: the first entry, in list order, whose neighbour is an anchor other than
+// `start` (:57-60).  Returns its position inside the chunk (lane*4+k) or -1.
+__device__ __forceinline__ int forced_in_chunk(const Chunk &c, uint32_t base, uint32_t deg, uint32_t start, int lane,
+                                               uint32_t &nbr_out) {
+    int best = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
+        const uint64_t fm = __ballot(i < deg && (c.nb[k] >> 31) && (c.nb[k] & 0x7FFFFFFFu) != start);
+        if (fm) {
+            const int fl = __ffsll((unsigned long long) fm) - 1;
+            const int pos = fl * 4 + k;
+            if (best < 0 || pos < best) {
+                best = pos;
+                nbr_out = readlane_u32(c.nb[k], fl) & 0x7FFFFFFFu;
+            }
+        }
+    }
+    return best;
+}
+
+// One lane's view of a chunk after the visited test: metric of each candidate, -1 for "not a candidate"
+// (safe nodes have no negative metrics), and the lane's sum.
+template <bool SQRT>
+__device__ __forceinline__ bool lane_candidates(const Chunk &c, const uint32_t *bm, uint32_t base, uint32_t deg, int lane,
+                                                double (&mv)[4], double &lane_sum) {
+    bool has = false;
+    lane_sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
+        const bool in = i < deg;
+        const bool cand = in && !bm_test(bm, in ? (c.nb[k] & 0x7FFFFFFFu) : 0u);     // :63
+        mv[k] = cand ? metric_f64<SQRT>(c.mb[k]) : -1.0;
+        if (cand) {
+            lane_sum += mv[k];                                                       // :64
+            has = true;
+        }
+    }
+    return has;
+}
+
+// The hit lies in lane `hl` (its inclusive prefix reached `random`, the one before did not): find the first
+// candidate k of that lane whose prefix reaches `random` (:108-113) and report it.
+__device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4], double excl,
+                                                double random, uint32_t base, int hl) {
+    int myk = -1;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {           // backwards, so that the FIRST k satisfying the test wins
+        double p = excl;
+#pragma unroll
+        for (int j = 0; j <= k; j++)
+            if (mv[j] >= 0.0) p += mv[j];
+        if (mv[k] >= 0.0 && p >= random) myk = k;                                    // :110
+    }
+    const int k = __builtin_amdgcn_readlane(myk, hl);
+    const uint32_t e0 = readlane_u32(c.nb[0], hl), e1 = readlane_u32(c.nb[1], hl);
+    const uint32_t e2 = readlane_u32(c.nb[2], hl), e3 = readlane_u32(c.nb[3], hl);
+    const uint32_t e = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
+    s.pick = (int) base + hl * 4 + k;
+    s.nbr = e & 0x7FFFFFFFu;
+    s.anchor = (e >> 31) != 0;
+}
+
+template <bool SQRT>
+__device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uint32_t *bm, volatile uint32_t *mt, int &mti,
+                                                    int lane, uint32_t row, uint32_t deg, uint32_t start,
+                                                    uint32_t &draws) {
+    Selection s{-1, 0u, false, false, 0u, deg};
+    if (deg <= 256u) {
+        // the whole list in one chunk: one load, one visited probe, ONE scan (it yields the total and every
+        // lane's prefix), no second pass over memory
+        const Chunk c = load_chunk(a.ents, row, 0u, lane);
+        uint32_t fn = 0;
+        const int fpos = forced_in_chunk(c, 0u, deg, start, lane, fn);
+        if (fpos >= 0) {
+            s.pick = fpos;
+            s.nbr = fn;
+            s.anchor = s.forced = true;
+            s.evals = (uint32_t) fpos + 1u;
+            return s;
+        }
+        double mv[4], lane_sum;
+        const bool has = lane_candidates<SQRT>(c, bm, 0u, deg, lane, mv, lane_sum);
+        if (!__ballot(has)) return s;                                               // :72 dead end
+        s.ncand = 1;
+        const double incl = wave_incl_scan_f64(lane_sum);
+        const double random = mt_canonical(mt, mti, lane) * readlane_f64(incl, 63);  // :104
+        draws++;
+        const uint64_t hm = __ballot(has && incl >= random);
+        if (hm) resolve_in_lane(s, c, mv, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
+        return s;
+    }
+    // ---- longer lists, pass 1 (:53-67): total over the unvisited neighbours, chunk after chunk
+    double total = 0.0;
+    for (uint32_t base = 0; base < deg; base += 256) {
+        const Chunk c = load_chunk(a.ents, row, base, lane);
+        uint32_t fn = 0;
+        const int fpos = forced_in_chunk(c, base, deg, start, lane, fn);
+        if (fpos >= 0) {
+            s.pick = (int) base + fpos;
+            s.nbr = fn;
+            s.anchor = s.forced = true;
+            s.evals = (uint32_t) s.pick + 1u;
+            return s;
+        }
+        double mv[4], lane_sum;
+        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum);
+        if (__ballot(has)) {
+            total += readlane_f64(wave_incl_scan_f64(lane_sum), 63);
+            s.ncand = 1;
+        }
+    }
+    if (s.ncand == 0) return s;
+    const double random = mt_canonical(mt, mti, lane) * total;                      // :104
+    draws++;
+    // ---- pass 2 (:107-114): the first candidate whose inclusive prefix reaches `random`
+    double carry = 0.0;
+    for (uint32_t base = 0; base < deg; base += 256) {
+        const Chunk c = load_chunk(a.ents, row, base, lane);
+        double mv[4], lane_sum;
+        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum);
+        if (!__ballot(has)) continue;
+        const double incl = wave_incl_scan_f64(lane_sum) + carry;
+        carry = readlane_f64(incl, 63);
+        const uint64_t hm = __ballot(has && incl >= random);
+        if (hm) {
+            resolve_in_lane(s, c, mv, incl - lane_sum, random, base, __ffsll((unsigned long long) hm) - 1);
+            return s;
+        }
+    }
+    return s;
+}
+
+// Unsafe node (a metric is negative / not finite, or the sums are not exact in a double): the additions are made
+// one candidate after the other in list order, as PathManager.cpp:64,109 makes them.  Rare; never on real overlaps.
+template <bool SQRT>
+__device__ Selection select_serial(const WalkArgs &a, const uint32_t *bm, volatile uint32_t *mt, int &mti,
+                                                int lane, uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws) {
+    Selection s{-1, 0u, false, false, 0u, deg};
+    double total = 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+        double run = 0.0;
+        double random = 0.0;
+        if (pass == 1) {
+            if (s.ncand == 0) return s;
+            random = mt_canonical(mt, mti, lane) * total;                            // :104
+            draws++;
+        }
+        for (uint32_t base = 0; base < deg; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < deg;
+            const uint2 ent = valid ? a.ents[row + i] : make_uint2(0u, 0u);
+            const uint32_t nbr = ent.x & 0x7FFFFFFFu;
+            if (pass == 0) {
+                const uint64_t fm = __ballot(valid && (ent.x >> 31) && nbr != start);     // :57
+                if (fm) {
+                    const int fl = __ffsll((unsigned long long) fm) - 1;
+                    s.pick = (int) base + fl;
+                    s.nbr = readlane_u32(nbr, fl);
+                    s.anchor = s.forced = true;
+                    s.evals = (uint32_t) s.pick + 1u;
+                    return s;
+                }
+            }
+            const bool cand = valid && !bm_test(bm, nbr);                          // :63
+            uint64_t cm = __ballot(cand);
+            if (pass == 0) s.ncand += (uint32_t) __popcll((unsigned long long) cm);
+            const double mv = cand ? metric_f64<SQRT>(ent.y) : 0.0;
+            while (cm) {
+                const int j = __ffsll((unsigned long long) cm) - 1;
+                cm &= cm - 1;
+                run += readlane_f64(mv, j);                                           // :64 / :109
+                if (pass == 1 && run >= random) {                                     // :110
+                    s.pick = (int) base + j;
+                    s.nbr = readlane_u32(nbr, j);
+                    s.anchor = (readlane_u32(ent.x, j) >> 31) != 0;
+                    return s;
+                }
+            }
+        }
+        total = run;
+    }
+    return s;
+}
 
 template <bool SQRT>
 __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint32_t *mt, int lane, uint32_t ui,
@@ -197,52 +426,28 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
     }
     wave_sync();
     for (;;) {                                          // :48
-        const uint32_t row = rfl(a.row_ptr[n]);
-        const uint32_t deg = rfl(a.row_ptr[n + 1]) - row;
-        const bool safe = (rfl(a.node_flags[n]) & a.flag_bit) != 0;
-        // ---- selection scan (:53-67): forced anchor edge, else sum over unvisited neighbours
-        int forced = -1;
-        uint32_t pick_nbr = 0;
-        bool pick_anchor = false;
-        double total = 0.0;
-        uint32_t ncand = 0;
-        for (uint32_t base = 0; base < deg; base += 64) {
-            const uint32_t i = base + lane;
-            const bool valid = i < deg;
-            const uint2 ent = valid ? a.ents[row + i] : make_uint2(0u, 0u);
-            const uint32_t nbr = ent.x & 0x7FFFFFFFu;
-            const uint64_t fm = __ballot(valid && (ent.x >> 31) && nbr != start);     // :57
-            if (fm) {
-                const int fl = __ffsll((unsigned long long) fm) - 1;
-                forced = (int) base + fl;
-                pick_nbr = __shfl(nbr, fl);
-                pick_anchor = true;
-                break;
-            }
-            const bool cand = valid && !bm_test(ws.bm, nbr);                         // :63
-            const uint64_t cm = __ballot(cand);
-            if (cm) {
-                float mf = __uint_as_float(ent.y);
-                if (SQRT) mf = sqrtf(mf);
-                const double mv = cand ? (double) mf : 0.0;
-                (void) chunk_scan(mv, cm, total, safe, lane);                         // :64
-                ncand += (uint32_t) __popcll((unsigned long long) cm);
-            }
-        }
-        evals += forced >= 0 ? (uint64_t) (forced + 1) : (uint64_t) deg;
+        const uint2 rec = a.rows[n];
+        const uint32_t row = rfl(rec.x);
+        const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
+        const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
+        // ---- selection scan (:53-115)
+        const Selection s = safe ? select_blocked<SQRT>(a, ws.bm, mt, mti, lane, row, deg, start, draws)
+                                 : select_serial<SQRT>(a, ws.bm, mt, mti, lane, row, deg, start, draws);
+        evals += s.evals;
         steps++;
-        int pick = -1;
-        if (forced >= 0) {
-            pick = forced;                              // :70-71
-        } else if (ncand == 0) {                        // :72 dead end
+        if (s.pick < 0) {
+            if (s.ncand != 0) break;    // no prefix reached `random` (NaN / negative metrics): the reference
+                                        // dereferences a null Edge* there; oracle and kernel abandon the walk
+            // :72 dead end
             if (backtracks < a.backtrack_attempts && m > 1) {    // :76
                 bool t = false;
                 do {                                    // :78-88
                     m--;
                     acc -= edge_delta(a, rfl(ws.pe[m]));
                     const uint32_t back = rfl(ws.pn[m]);
-                    const uint32_t brow = rfl(a.row_ptr[back]);
-                    const uint32_t bdeg = rfl(a.row_ptr[back + 1]) - brow;
+                    const uint2 brec = a.rows[back];
+                    const uint32_t brow = rfl(brec.x);
+                    const uint32_t bdeg = rfl(brec.y) & 0xFFFFFFu;
                     for (uint32_t base = 0; base < bdeg && !t; base += 64) {
                         const uint32_t i = base + lane;
                         const bool valid = i < bdeg;
@@ -256,55 +461,27 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
                 continue;
             }
             break;                                      // :101
-        } else {
-            const double random = mt_canonical(mt, mti, lane) * total;               // :104
-            draws++;
-            double carry = 0.0;                         // :107
-            for (uint32_t base = 0; base < deg; base += 64) {
-                const uint32_t i = base + lane;
-                const bool valid = i < deg;
-                const uint2 ent = valid ? a.ents[row + i] : make_uint2(0u, 0u);
-                const uint32_t nbr = ent.x & 0x7FFFFFFFu;
-                const bool cand = valid && !bm_test(ws.bm, nbr);
-                const uint64_t cm = __ballot(cand);
-                if (!cm) continue;
-                float mf = __uint_as_float(ent.y);
-                if (SQRT) mf = sqrtf(mf);
-                const double mv = cand ? (double) mf : 0.0;
-                const double incl = chunk_scan(mv, cm, carry, safe, lane);            // :109
-                const uint64_t hm = __ballot(cand && incl >= random);                // :110
-                if (hm) {
-                    const int hl = __ffsll((unsigned long long) hm) - 1;
-                    pick = (int) base + hl;
-                    pick_nbr = __shfl(nbr, hl);
-                    pick_anchor = (__shfl(ent.x, hl) >> 31) != 0;
-                    break;
-                }
-            }
-            // no prefix reached `random` (NaN / negative metrics): the reference dereferences a null
-            // Edge* there; the oracle and this kernel abandon the walk instead.
-            if (pick < 0) break;
         }
         // ---- advance (:118-123)
         if (m + 2 > a.cap || nlog + 1 > a.cap) {
             status = ST_SCRATCH_OVF;
             break;
         }
-        const uint32_t eidx = row + (uint32_t) pick;
+        const uint32_t eidx = row + (uint32_t) s.pick;
         if (lane == 0) {
             ws.pe[m] = eidx;
-            ws.pn[m + 1] = pick_nbr;
-            ws.bm[pick_nbr >> 5] |= 1u << (pick_nbr & 31);
-            ws.lg[nlog] = pick_nbr;
+            ws.pn[m + 1] = s.nbr;
+            ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
+            ws.lg[nlog] = s.nbr;
         }
         nlog++;
         const int64_t len = len0 + acc;                 // :125 -- the new last edge is excluded (Path.cpp:12-15)
         acc += edge_delta(a, eidx);
         m++;
-        n = pick_nbr;
+        n = s.nbr;
         wave_sync();
         if (len <= 0) break;                            // :126-128
-        if (pick_anchor) {                              // :131-134
+        if (s.anchor) {                                 // :131-134
             acceptable = true;
             break;
         }
@@ -333,7 +510,7 @@ __device__ __forceinline__ uint64_t det_key(uint32_t bits, uint32_t i) {
 template <bool SQRT>
 __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uint32_t ui, uint32_t start,
                          uint32_t first_slot) {
-    const uint32_t first = rfl(a.row_ptr[start]) + first_slot;
+    const uint32_t first = rfl(a.rows[start].x) + first_slot;
     const uint2 ent0 = a.ents[first];
     const uint32_t second = rfl(ent0.x & 0x7FFFFFFFu);
     const bool second_anchor = rfl(ent0.x >> 31) != 0;
@@ -365,8 +542,9 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
         bool went_back = false;
         uint32_t node = second;
         for (;;) {                                          // :243
-            const uint32_t row = rfl(a.row_ptr[node]);
-            const uint32_t deg = rfl(a.row_ptr[node + 1]) - row;
+            const uint2 rec = a.rows[node];
+            const uint32_t row = rfl(rec.x);
+            const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
             bool go_back = false;
             uint32_t chosen = 0;
             if (deg == 0 || skip_n_best >= deg - 1) {       // :245, :267
@@ -488,7 +666,7 @@ template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_mc_kernel(WalkArgs a) {
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
+    const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
     uint32_t ui;
     while (next_work(a, lane, ui)) {
@@ -502,7 +680,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_mc_kernel(WalkArgs a) {
 template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
+    const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
     uint32_t ui;
     while (next_work(a, lane, ui)) {
@@ -518,6 +696,17 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
 }
 
 }  // namespace
+
+int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric) {
+    int n = 0;
+    hipError_t e;
+    if (is_mc) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<true>, WALK_BLOCK, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<false>, WALK_BLOCK, 0);
+    else e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<true>, WALK_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<false>, WALK_BLOCK, 0);
+    if (e != hipSuccess || n < 1) n = 1;
+    return n;
+}
 
 void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a) {
     if (sqrt_metric) hipLaunchKernelGGL(walk_mc_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
