@@ -129,6 +129,14 @@ int tlm_filter_score(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records
  * record order.  `name_is_ctg[n_names]` (dev, uint8): name starts with "ctg", case-insensitive. */
 int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *files, int n_files,
                     uint32_t n_names, const uint8_t *name_is_ctg_dev, tlm_graph **out);
+/* The same with every column of `files` (and name_is_ctg) in HOST memory: the library uploads them.  This is
+ * what a host program that has just tokenised its PAF files calls (telomeri_amd/host/). */
+int tlm_graph_build_host(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *files_host, int n_files,
+                         uint32_t n_names, const uint8_t *name_is_ctg_host, tlm_graph **out);
+/* Records kept by the filter, in order: rec[k] = index of the k-th kept record, counted over all files of the
+ * build in load order (HOST buffer of tlm_graph_info.n_kept entries).  This is edges_ order (OverlapGraph.cpp:241).
+ * Only for graphs made by tlm_graph_build*. */
+int tlm_graph_kept_records(const tlm_graph *g, uint32_t *rec_host);
 /* Adopt a finished CSR given in HOST memory (tests; hosts that build adjacency themselves).
  * Entry k of node i: nbr[row_ptr[i]+k]; q_end/t_end/si/strand may be NULL. */
 int tlm_graph_from_csr(tlm_ctx *ctx, uint32_t n_nodes, uint64_t n_adj, const uint64_t *row_ptr,

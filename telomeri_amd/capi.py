@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
     L.tlm_ctx_set_walk_tuning.argtypes = [V, C.c_int, C.c_uint32]
     L.tlm_filter_score.argtypes = [V, P(FilterParams), P(_Records), V, V, V, V, P(C.c_uint64)]
     L.tlm_graph_build.argtypes = [V, P(FilterParams), P(_Records), C.c_int, C.c_uint32, V, P(V)]
+    L.tlm_graph_build_host.argtypes = [V, P(FilterParams), P(_Records), C.c_int, C.c_uint32, V, P(V)]
+    L.tlm_graph_kept_records.argtypes = [V, V]
     L.tlm_graph_from_csr.argtypes = [V, C.c_uint32, C.c_uint64] + [V] * 12 + [P(V)]
     L.tlm_graph_destroy.argtypes = [V]
     L.tlm_graph_get_info.argtypes = [V, P(GraphInfo)]
@@ -245,6 +247,11 @@ class Graph:
                                         _np_ptr(node_len), _np_ptr(node_anchor), _np_ptr(name_id)), "tlm_graph_download")
         return HostCsr(n, a, row_ptr, nbr, qs, qe, ts, te, os_, si, es, strand, node_len, node_anchor, name_id)
 
+    def kept_records(self) -> np.ndarray:
+        out = np.zeros(int(self.info().n_kept), np.uint32)
+        _check(lib().tlm_graph_kept_records(self._h, _np_ptr(out)), "tlm_graph_kept_records")
+        return out
+
     def mc_units(self, wp: WalkParams) -> int:
         return int(lib().tlm_mc_units(self._h, C.byref(wp)))
 
@@ -338,6 +345,26 @@ class Context:
         h = C.c_void_p()
         _check(lib().tlm_graph_build(self._h, C.byref(fp), arr, len(files), n_names, ctg.data_ptr(), C.byref(h)),
                "tlm_graph_build")
+        return Graph(self, h)
+
+    def build_graph_host(self, fp: FilterParams, files: Sequence[dict], anchors: Sequence[bool], n_names: int,
+                         name_is_ctg) -> Graph:
+        """files: dicts of HOST int32 numpy columns (q_id, t_id, q_len, ..., matches) + uint8 strand."""
+        keep = []
+        recs = []
+        for f, a in zip(files, anchors):
+            cols = {k: np.ascontiguousarray(f[k], np.int32) for k in ("q_id", "t_id", "q_len", "q_start", "q_end", "t_len",
+                                                                       "t_start", "t_end", "matches")}
+            strand = np.ascontiguousarray(f["strand"], np.uint8)
+            keep.append((cols, strand))
+            recs.append(_Records(cols["q_id"].shape[0], *[cols[k].ctypes.data for k in (
+                "q_id", "t_id", "q_len", "q_start", "q_end", "t_len", "t_start", "t_end", "matches")], strand.ctypes.data,
+                int(a)))
+        arr = (_Records * len(recs))(*recs)
+        ctg = np.ascontiguousarray(name_is_ctg, np.uint8)
+        h = C.c_void_p()
+        _check(lib().tlm_graph_build_host(self._h, C.byref(fp), arr, len(recs), n_names, _np_ptr(ctg), C.byref(h)),
+               "tlm_graph_build_host")
         return Graph(self, h)
 
     def graph_from_csr(self, row_ptr, nbr, q_start, t_start, os_, es, node_len, node_anchor, q_end=None, t_end=None,

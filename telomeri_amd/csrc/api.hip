@@ -137,7 +137,7 @@ extern "C" void tlm_graph_destroy(tlm_graph *g) {
     (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
     (void) hipFree(g->node_flags); (void) hipFree(g->node_name_id); (void) hipFree(g->anchors); (void) hipFree(g->det_off);
     (void) hipFree(g->w_row); (void) hipFree(g->w_ent_es); (void) hipFree(g->w_ent_os); (void) hipFree(g->w_qs);
-    (void) hipFree(g->w_ts);
+    (void) hipFree(g->w_ts); (void) hipFree(g->kept_rec);
     delete g;
 }
 

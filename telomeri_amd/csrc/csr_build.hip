@@ -386,6 +386,52 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     return TLM_OK;
 }
 
+extern "C" int tlm_graph_kept_records(const tlm_graph *g, uint32_t *rec_host) {
+    TLM_CHECK(g && rec_host, TLM_EINVAL, "tlm_graph_kept_records: null argument");
+    TLM_CHECK(g->kept_rec || g->info.n_kept == 0, TLM_EINVAL, "tlm_graph_kept_records: graph was not made by tlm_graph_build");
+    TLM_HIP(hipSetDevice(g->device));
+    if (g->info.n_kept) TLM_HIP(hipMemcpy(rec_host, g->kept_rec, g->info.n_kept * 4, hipMemcpyDeviceToHost));
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_build_host(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *files_host, int n_files,
+                                    uint32_t n_names, const uint8_t *name_is_ctg_host, tlm_graph **out) {
+    TLM_CHECK(ctx && p && files_host && out, TLM_EINVAL, "tlm_graph_build_host: null argument");
+    TLM_CHECK(n_files >= 1 && n_files <= MAX_FILES, TLM_EINVAL, "tlm_graph_build_host: n_files must be 1..%d", MAX_FILES);
+    TLM_HIP(hipSetDevice(ctx->device));
+    std::vector<DevBuf> bufs((size_t) n_files * 10 + 1);
+    tlm_records dev[MAX_FILES];
+    size_t b = 0;
+    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+        *dst = nullptr;
+        if (!src) return TLM_OK;
+        if (int rc = dev_alloc(bufs[b], bytes)) return rc;
+        if (bytes) TLM_HIP(hipMemcpyAsync(bufs[b].p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        *dst = bufs[b].p;
+        b++;
+        return TLM_OK;
+    };
+    for (int i = 0; i < n_files; i++) {
+        const tlm_records &h = files_host[i];
+        dev[i] = h;
+        const size_t n4 = (size_t) h.n * 4;
+        if (int rc = up(h.q_id, n4, (const void **) &dev[i].q_id)) return rc;
+        if (int rc = up(h.t_id, n4, (const void **) &dev[i].t_id)) return rc;
+        if (int rc = up(h.q_len, n4, (const void **) &dev[i].q_len)) return rc;
+        if (int rc = up(h.q_start, n4, (const void **) &dev[i].q_start)) return rc;
+        if (int rc = up(h.q_end, n4, (const void **) &dev[i].q_end)) return rc;
+        if (int rc = up(h.t_len, n4, (const void **) &dev[i].t_len)) return rc;
+        if (int rc = up(h.t_start, n4, (const void **) &dev[i].t_start)) return rc;
+        if (int rc = up(h.t_end, n4, (const void **) &dev[i].t_end)) return rc;
+        if (int rc = up(h.matches, n4, (const void **) &dev[i].matches)) return rc;
+        if (int rc = up(h.strand, (size_t) h.n, (const void **) &dev[i].strand)) return rc;
+    }
+    const uint8_t *ctg_dev = nullptr;
+    if (int rc = up(name_is_ctg_host, n_names, (const void **) &ctg_dev)) return rc;
+    TLM_HIP(hipStreamSynchronize(ctx->stream));
+    return tlm_graph_build(ctx, p, dev, n_files, n_names, ctg_dev, out);
+}
+
 extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const tlm_records *files, int n_files,
                                uint32_t n_names, const uint8_t *name_is_ctg_dev, tlm_graph **out) {
     TLM_CHECK(ctx && p && files && out, TLM_EINVAL, "tlm_graph_build: null argument");
@@ -466,9 +512,9 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     }
 
     // 3. first-seen numbering
-    DevBuf first_pos, kept_rec, name_iota, sorted_pos, sorted_name, node_of_name;
+    DevBuf first_pos, name_iota, sorted_pos, sorted_name, node_of_name;
     if (int rc = dev_alloc(first_pos, (size_t) n_names * 4)) return rc;
-    if (int rc = dev_alloc(kept_rec, K * 4)) return rc;
+    if (int rc = dev_alloc_keep(&g->kept_rec, (size_t) K)) return rc;
     if (int rc = dev_alloc(name_iota, (size_t) n_names * 4)) return rc;
     if (int rc = dev_alloc(sorted_pos, (size_t) n_names * 4)) return rc;
     if (int rc = dev_alloc(sorted_name, (size_t) n_names * 4)) return rc;
@@ -477,7 +523,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     for (int i = 0; i < n_files; i++) {
         if (!ft.f[i].n) continue;
         hipLaunchKernelGGL(first_seen_kernel, dim3(grid_for(ft.f[i].n)), dim3(256), 0, s, ft, i, keep.as<uint8_t>(),
-                           krank.as<uint32_t>(), first_pos.as<uint32_t>(), kept_rec.as<uint32_t>());
+                           krank.as<uint32_t>(), first_pos.as<uint32_t>(), g->kept_rec);
     }
     uint32_t N = 0;
     if (n_names) {
@@ -501,7 +547,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     if (int rc = dev_alloc_keep(&g->node_name_id, N)) return rc;
     if (N) {
         hipLaunchKernelGGL(make_nodes_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ft, N, sorted_pos.as<uint32_t>(),
-                           sorted_name.as<uint32_t>(), kept_rec.as<uint32_t>(), name_is_ctg_dev,
+                           sorted_name.as<uint32_t>(), g->kept_rec, name_is_ctg_dev,
                            node_of_name.as<uint32_t>(), g->node_len, g->node_anchor, g->node_name_id);
     }
 
@@ -522,7 +568,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         if (int rc = dev_alloc(eidx, A * 4)) return rc;
         if (int rc = dev_alloc(sorted_owner, A * 4)) return rc;
         if (int rc = dev_alloc(sorted_e, A * 4)) return rc;
-        hipLaunchKernelGGL(make_entries_kernel, dim3(grid_for(K)), dim3(256), 0, s, ft, K, kept_rec.as<uint32_t>(),
+        hipLaunchKernelGGL(make_entries_kernel, dim3(grid_for(K)), dim3(256), 0, s, ft, K, g->kept_rec,
                            node_of_name.as<uint32_t>(), owner.as<uint32_t>(), eidx.as<uint32_t>());
         unsigned end_bit = 1;
         while ((1ull << end_bit) < (uint64_t) N && end_bit < 32) end_bit++;
@@ -536,7 +582,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, N, sorted_owner.as<uint32_t>(), g->row_ptr);
         // 5. gather
         hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, ft, A, sorted_e.as<uint32_t>(),
-                           kept_rec.as<uint32_t>(), node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(),
+                           g->kept_rec, node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(),
                            r_os.as<float>(), r_es.as<float>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start,
                            g->t_end, g->si, g->strand);
         TLM_HIP(hipStreamSynchronize(s));

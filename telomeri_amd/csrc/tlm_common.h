@@ -65,6 +65,7 @@ struct tlm_graph {
     uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
     uint32_t *w_qs = nullptr, *w_ts = nullptr;         // [n_adj_pad]
     int32_t *node_name_id = nullptr;
+    uint32_t *kept_rec = nullptr;      // [n_kept] global record index of each kept record (tlm_graph_build only)
     uint32_t *anchors = nullptr;       // [n_anchors] node index, ascending
     uint64_t *det_off = nullptr;       // [n_anchors+1] prefix of DET units per anchor
     std::vector<uint32_t> h_anchors;

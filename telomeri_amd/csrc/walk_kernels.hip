@@ -193,6 +193,8 @@ struct Selection {
     bool forced;         // taken by the forced-anchor rule (:57-60)
     uint32_t ncand;      // unvisited neighbours seen (0 with pick < 0 = dead end)
     uint32_t evals;      // adjacency entries examined
+    uint32_t word;       // visited-bitmap word of `nbr` as probed (valid iff has_word): marking needs no re-read
+    bool has_word;
 };
 
 template <bool SQRT>
@@ -207,14 +209,20 @@ struct Chunk {           // one lane's 4 entries of a 256-entry chunk
     uint32_t mb[4];      // fp32 bits of the metric
 };
 
-__device__ __forceinline__ Chunk load_chunk(const uint2 *ents, uint32_t row, uint32_t base, int lane) {
-    // row is a multiple of 4 entries and so is base + 4*lane: 32-byte aligned, two dwordx4 loads.  Entries past
-    // the degree are padding or belong to the next row; they are masked by position, never used.
-    const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + base + 4u * (uint32_t) lane);
-    const uint4 lo = p[0], hi = p[1];
+__device__ __forceinline__ Chunk load_chunk(const uint2 *ents, uint32_t row, uint32_t base, uint32_t deg, int lane) {
+    // row is a multiple of 4 entries and so is base + 4*lane: 32-byte aligned, two dwordx4 loads.  Lanes whose four
+    // entries all lie past the degree load nothing; inside a lane, entries past the degree are row padding, masked
+    // by position and never used.
     Chunk c;
-    c.nb[0] = lo.x; c.mb[0] = lo.y; c.nb[1] = lo.z; c.mb[1] = lo.w;
-    c.nb[2] = hi.x; c.mb[2] = hi.y; c.nb[3] = hi.z; c.mb[3] = hi.w;
+    if (base + 4u * (uint32_t) lane < deg) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + base + 4u * (uint32_t) lane);
+        const uint4 lo = p[0], hi = p[1];
+        c.nb[0] = lo.x; c.mb[0] = lo.y; c.nb[1] = lo.z; c.mb[1] = lo.w;
+        c.nb[2] = hi.x; c.mb[2] = hi.y; c.nb[3] = hi.z; c.mb[3] = hi.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) c.nb[k] = c.mb[k] = 0u;
+    }
     return c;
 }
 
@@ -243,14 +251,18 @@ __device__ __forceinline__ int forced_in_chunk(const Chunk &c, uint32_t base, ui
 // (safe nodes have no negative metrics), and the lane's sum.
 template <bool SQRT>
 __device__ __forceinline__ bool lane_candidates(const Chunk &c, const uint32_t *bm, uint32_t base, uint32_t deg, int lane,
-                                                double (&mv)[4], double &lane_sum) {
+                                                double (&mv)[4], double &lane_sum, uint32_t (&w)[4]) {
     bool has = false;
     lane_sum = 0.0;
 #pragma unroll
+    for (int k = 0; k < 4; k++) {       // the four probes are independent: all in flight together
+        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
+        w[k] = (i < deg) ? bm[(c.nb[k] & 0x7FFFFFFFu) >> 5] : 0xFFFFFFFFu;
+    }
+#pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
-        const bool in = i < deg;
-        const bool cand = in && !bm_test(bm, in ? (c.nb[k] & 0x7FFFFFFFu) : 0u);     // :63
+        const bool cand = i < deg && !((w[k] >> (c.nb[k] & 31u)) & 1u);              // :63
         mv[k] = cand ? metric_f64<SQRT>(c.mb[k]) : -1.0;
         if (cand) {
             lane_sum += mv[k];                                                       // :64
@@ -262,8 +274,9 @@ __device__ __forceinline__ bool lane_candidates(const Chunk &c, const uint32_t *
 
 // The hit lies in lane `hl` (its inclusive prefix reached `random`, the one before did not): find the first
 // candidate k of that lane whose prefix reaches `random` (:108-113) and report it.
-__device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4], double excl,
-                                                double random, uint32_t base, int hl) {
+__device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4],
+                                                const uint32_t (&w)[4], double excl, double random, uint32_t base,
+                                                int hl) {
     int myk = -1;
 #pragma unroll
     for (int k = 3; k >= 0; k--) {           // backwards, so that the FIRST k satisfying the test wins
@@ -277,6 +290,10 @@ __device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, co
     const uint32_t e0 = readlane_u32(c.nb[0], hl), e1 = readlane_u32(c.nb[1], hl);
     const uint32_t e2 = readlane_u32(c.nb[2], hl), e3 = readlane_u32(c.nb[3], hl);
     const uint32_t e = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
+    const uint32_t w0 = readlane_u32(w[0], hl), w1 = readlane_u32(w[1], hl);
+    const uint32_t w2 = readlane_u32(w[2], hl), w3 = readlane_u32(w[3], hl);
+    s.word = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
+    s.has_word = true;
     s.pick = (int) base + hl * 4 + k;
     s.nbr = e & 0x7FFFFFFFu;
     s.anchor = (e >> 31) != 0;
@@ -286,11 +303,11 @@ template <bool SQRT>
 __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uint32_t *bm, volatile uint32_t *mt, int &mti,
                                                     int lane, uint32_t row, uint32_t deg, uint32_t start,
                                                     uint32_t &draws) {
-    Selection s{-1, 0u, false, false, 0u, deg};
+    Selection s{-1, 0u, false, false, 0u, deg, 0u, false};
     if (deg <= 256u) {
         // the whole list in one chunk: one load, one visited probe, ONE scan (it yields the total and every
         // lane's prefix), no second pass over memory
-        const Chunk c = load_chunk(a.ents, row, 0u, lane);
+        const Chunk c = load_chunk(a.ents, row, 0u, deg, lane);
         uint32_t fn = 0;
         const int fpos = forced_in_chunk(c, 0u, deg, start, lane, fn);
         if (fpos >= 0) {
@@ -301,20 +318,21 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
             return s;
         }
         double mv[4], lane_sum;
-        const bool has = lane_candidates<SQRT>(c, bm, 0u, deg, lane, mv, lane_sum);
+        uint32_t w[4];
+        const bool has = lane_candidates<SQRT>(c, bm, 0u, deg, lane, mv, lane_sum, w);
         if (!__ballot(has)) return s;                                               // :72 dead end
         s.ncand = 1;
         const double incl = wave_incl_scan_f64(lane_sum);
         const double random = mt_canonical(mt, mti, lane) * readlane_f64(incl, 63);  // :104
         draws++;
         const uint64_t hm = __ballot(has && incl >= random);
-        if (hm) resolve_in_lane(s, c, mv, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
+        if (hm) resolve_in_lane(s, c, mv, w, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
         return s;
     }
     // ---- longer lists, pass 1 (:53-67): total over the unvisited neighbours, chunk after chunk
     double total = 0.0;
     for (uint32_t base = 0; base < deg; base += 256) {
-        const Chunk c = load_chunk(a.ents, row, base, lane);
+        const Chunk c = load_chunk(a.ents, row, base, deg, lane);
         uint32_t fn = 0;
         const int fpos = forced_in_chunk(c, base, deg, start, lane, fn);
         if (fpos >= 0) {
@@ -325,7 +343,8 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
             return s;
         }
         double mv[4], lane_sum;
-        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum);
+        uint32_t w[4];
+        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum, w);
         if (__ballot(has)) {
             total += readlane_f64(wave_incl_scan_f64(lane_sum), 63);
             s.ncand = 1;
@@ -337,15 +356,16 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
     // ---- pass 2 (:107-114): the first candidate whose inclusive prefix reaches `random`
     double carry = 0.0;
     for (uint32_t base = 0; base < deg; base += 256) {
-        const Chunk c = load_chunk(a.ents, row, base, lane);
+        const Chunk c = load_chunk(a.ents, row, base, deg, lane);
         double mv[4], lane_sum;
-        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum);
+        uint32_t w[4];
+        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum, w);
         if (!__ballot(has)) continue;
         const double incl = wave_incl_scan_f64(lane_sum) + carry;
         carry = readlane_f64(incl, 63);
         const uint64_t hm = __ballot(has && incl >= random);
         if (hm) {
-            resolve_in_lane(s, c, mv, incl - lane_sum, random, base, __ffsll((unsigned long long) hm) - 1);
+            resolve_in_lane(s, c, mv, w, incl - lane_sum, random, base, __ffsll((unsigned long long) hm) - 1);
             return s;
         }
     }
@@ -357,7 +377,7 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
 template <bool SQRT>
 __device__ Selection select_serial(const WalkArgs &a, const uint32_t *bm, volatile uint32_t *mt, int &mti,
                                                 int lane, uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws) {
-    Selection s{-1, 0u, false, false, 0u, deg};
+    Selection s{-1, 0u, false, false, 0u, deg, 0u, false};
     double total = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         double run = 0.0;
@@ -412,7 +432,9 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
     uint32_t n = start;
     uint32_t m = 0;          // p.edges_.size()
     uint32_t nlog = 1;
-    int64_t acc = 0;         // sum of the increments of ALL m edges
+    int64_t acc = 0;         // sum of the increments of edges 0..m-2 (all but the last pushed one)
+    uint32_t pend_qs = 0, pend_ts = 0;   // q_start / t_start of the last pushed edge, in flight
+    bool have_pend = false;
     const int64_t len0 = (int64_t) a.node_len[start];
     int backtracks = 0;
     uint32_t steps = 0, draws = 0;
@@ -442,8 +464,10 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
             if (backtracks < a.backtrack_attempts && m > 1) {    // :76
                 bool t = false;
                 do {                                    // :78-88
+                    // pop edge m-1: it was the pending one (never added); the new last edge m-2 leaves the sum
                     m--;
-                    acc -= edge_delta(a, rfl(ws.pe[m]));
+                    have_pend = false;
+                    if (m >= 1) acc -= edge_delta(a, rfl(ws.pe[m - 1]));
                     const uint32_t back = rfl(ws.pn[m]);
                     const uint2 brec = a.rows[back];
                     const uint32_t brow = rfl(brec.x);
@@ -458,6 +482,12 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
                 if (m == 0) break;                      // :90-95
                 ++backtracks;
                 n = rfl(ws.pn[m]);                      // :98
+                {   // the new last edge's increment becomes the pending one again
+                    const uint32_t le = rfl(ws.pe[m - 1]);
+                    pend_qs = a.q_start[le];
+                    pend_ts = a.t_start[le];
+                    have_pend = true;
+                }
                 continue;
             }
             break;                                      // :101
@@ -471,12 +501,21 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
         if (lane == 0) {
             ws.pe[m] = eidx;
             ws.pn[m + 1] = s.nbr;
-            ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
+            // visited mark without a read-modify-write round trip: the probe already fetched the word.  A forced
+            // pick is an anchor, the walk ends with it and nothing is probed afterwards.
+            if (s.has_word) ws.bm[s.nbr >> 5] = s.word | (1u << (s.nbr & 31));
+            else if (!s.forced) ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
             ws.lg[nlog] = s.nbr;
         }
         nlog++;
-        const int64_t len = len0 + acc;                 // :125 -- the new last edge is excluded (Path.cpp:12-15)
-        acc += edge_delta(a, eidx);
+        // :125 -- Path::length() after this push excludes the new last edge (Path.cpp:12-15): it is len0 plus the
+        // increments of all EARLIER edges.  The increment of the edge pushed in the previous step was requested
+        // then (pend_*) and is only consumed here, a whole step later, so its latency is never waited for.
+        if (have_pend) acc += (int64_t) pend_qs - (int64_t) pend_ts;
+        const int64_t len = len0 + acc;
+        pend_qs = a.q_start[eidx];
+        pend_ts = a.t_start[eidx];
+        have_pend = true;
         m++;
         n = s.nbr;
         wave_sync();
@@ -487,7 +526,8 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
         }
         if (len >= a.len_threshold) break;              // :137-142
     }
-    const int64_t len_final = len0 + acc - (m ? edge_delta(a, rfl(ws.pe[m - 1])) : 0);
+    // acc holds the increments of edges 0..m-2 (the last pushed edge is still pending): exactly Path::length()
+    const int64_t len_final = len0 + acc;
     if (acceptable && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :146-155
     finish_unit(a, ws, lane, ui, status, m, nlog, len_final, steps, evals, draws);
 }

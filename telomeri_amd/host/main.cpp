@@ -1,0 +1,145 @@
+// telomeri_amd/host/main.cpp -- `telomeri_hip`: the reference's command line for the hot path.
+//
+//   telomeri_hip [options] <rr.paf> <cr.paf> <reads.fasta> <contigs.fasta> <out.fasta>
+//
+// Options and defaults as reference src/Main.cpp:56-69,100-192 (the parser there, not its help text).
+// Stages up to the end of the hot path run as in Main.cpp:212-252: load rr + cr, the four builders,
+// filterUnique, stats.  What follows in the reference (grouping, consensus, Scaffolder: SURVEY.md §8f) is
+// not part of this round; instead `--dump <file>` writes graph and paths in oracle/ref_dump's text format
+// so the result can be compared with the reference's.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+#include "telomeri_host.hpp"
+
+static bool parse_ulong(const char *s, ulong &v) {
+    char *end = nullptr;
+    if (!s || !*s || *s == '-') return false;
+    v = std::strtoul(s, &end, 10);
+    return end && *end == 0;
+}
+
+static bool parse_perc(const char *s, float &v) {
+    char *end = nullptr;
+    if (!s || !*s) return false;
+    v = std::strtof(s, &end);
+    return end && *end == 0 && v >= 0.0f && v <= 1.0f;
+}
+
+static unsigned bits_of(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+int main(int argc, char **argv) {
+    OverlapGraph graph;
+    PathManager pm;
+    const char *mode_string = "AVG";
+    std::string dump;
+    std::vector<char *> pos;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](const char *what) -> char * {
+            if (i + 1 >= argc) { std::cerr << "Missing value for " << what << std::endl; std::exit(1); }
+            return argv[++i];
+        };
+        ulong u;
+        float f;
+        if (a == "--filter-avg") { graph.filter_params_.mode = OverlapGraph::AVG; mode_string = "AVG"; }
+        else if (a == "--filter-min") { graph.filter_params_.mode = OverlapGraph::MIN; mode_string = "MIN"; }
+        else if (a == "--filter-max") { graph.filter_params_.mode = OverlapGraph::MAX; mode_string = "MAX"; }
+        else if (a == "--filter-sum") { graph.filter_params_.mode = OverlapGraph::SUM; mode_string = "SUM"; }
+        else if (a == "--min-oll") { if (!parse_ulong(need("--min-oll"), u)) return 1; graph.filter_params_.min_overlap_length = u; }
+        else if (a == "--min-olp") { if (!parse_perc(need("--min-olp"), f)) return 1; graph.filter_params_.min_overlap_percentage = f; }
+        else if (a == "--max-ohl") { if (!parse_ulong(need("--max-ohl"), u)) return 1; graph.filter_params_.max_overhang_length = u; }
+        else if (a == "--max-ohp") { if (!parse_perc(need("--max-ohp"), f)) return 1; graph.filter_params_.max_overhang_percentage = f; }
+        else if (a == "--rb-att") { if (!parse_ulong(need("--rb-att"), u)) return 1; pm.params_.rebuild_attempts = (int) u; }
+        else if (a == "--bt-att") { if (!parse_ulong(need("--bt-att"), u)) return 1; pm.params_.backtrack_attempts = (int) u; }
+        else if (a == "--len-thr") { if (!parse_ulong(need("--len-thr"), u)) return 1; pm.params_.len_threshold = (long) u; }
+        else if (a == "--w-size") { if (!parse_ulong(need("--w-size"), u)) return 1; pm.params_.window_size = u; }
+        else if (a == "--r-thr") { if (!parse_perc(need("--r-thr"), f)) return 1; pm.params_.ratio_threshold = f; }
+        else if (a == "--dump") dump = need("--dump");
+        else pos.push_back(argv[i]);
+    }
+    if (pos.size() != 5) {
+        std::cerr << "Please provide a path to read-read and contig-read files!\n"
+                  << "Usage: telomeri_hip [option...] <read-read_overlap_file>.paf <contig-read_overlap_file>.paf "
+                  << "<reads_file>.fasta <contigs_file>.fasta <output_file>.fasta [--dump <paths.txt>]" << std::endl;
+        return 1;
+    }
+    std::cout << "Filter:\n    Mode: " << mode_string << "\n    Min overlap length: " << graph.filter_params_.min_overlap_length
+              << "\n    Min overlap percentage: " << graph.filter_params_.min_overlap_percentage
+              << "\n    Max overhang length: " << graph.filter_params_.max_overhang_length
+              << "\n    Max overhang percentage: " << graph.filter_params_.max_overhang_percentage << std::endl;
+    std::cout << "Path construction:\n    Rebuild attempts: " << pm.params_.rebuild_attempts
+              << "\n    Backtrack attempts: " << pm.params_.backtrack_attempts
+              << "\n    Length threshold: " << pm.params_.len_threshold << "\n" << std::endl;
+
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&]() {
+        auto t1 = std::chrono::steady_clock::now();
+        double s = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return s;
+    };
+    std::cout << "\nLoading overlaps..." << std::endl;
+    if (!graph.load(pos[0], false) || !graph.load(pos[1], true)) return 1;          // Main.cpp:223
+    std::cout << "Done (" << lap() << "s)" << std::endl << graph.stats() << std::endl;
+
+    std::cout << "Calculating paths..." << std::endl;
+    FILE *out = nullptr;
+    if (!dump.empty()) {
+        out = std::fopen(dump.c_str(), "w");
+        if (!out) { std::perror(dump.c_str()); return 1; }
+        std::fprintf(out, "TLMDUMP 1\nN %zu\n", graph.nodes_.size());
+        size_t adj = 0;
+        for (const auto &n : graph.nodes_) {
+            std::fprintf(out, "n %u %d %u %zu %s\n", n.index, n.anchor ? 1 : 0, n.length, n.edges.size(), n.name.c_str());
+            adj += n.edges.size();
+        }
+        std::fprintf(out, "A %zu\n", adj);
+        for (const auto &n : graph.nodes_)
+            for (size_t s = 0; s < n.edges.size(); s++) {
+                const auto &e = n.edges[s];
+                std::fprintf(out, "a %u %zu %u %u %u %u %u %u %u %u %d\n", e.t_index, s, e.q_index, e.q_start, e.q_end,
+                             e.t_start, e.t_end, bits_of(e.overlap_score), bits_of(e.sequence_identity),
+                             bits_of(e.extension_score), e.relative_strand ? 1 : 0);
+            }
+    }
+    struct B { int id; bool mc; Utils::Metrics m; };
+    const B builders[4] = {{0, true, Utils::Metrics::EXTENSION_SCORE}, {1, true, Utils::Metrics::OVERLAP_SCORE},
+                           {2, false, Utils::Metrics::EXTENSION_SCORE}, {3, false, Utils::Metrics::OVERLAP_SCORE}};
+    uint64_t evals = 0;
+    double kernel_ms = 0;
+    for (const B &b : builders) {                                                     // Main.cpp:237-243
+        const size_t before = pm.paths().size();
+        if (b.mc) pm.buildMonteCarlo(graph, b.m);
+        else pm.buildDeterministic(graph, b.m);
+        evals += pm.last_counters.evals;
+        kernel_ms += pm.last_counters.kernel_ms;
+        if (out) {
+            std::fprintf(out, "B %d %zu\n", b.id, pm.paths().size() - before);
+            for (size_t i = before; i < pm.paths().size(); i++) {
+                const Path &p = pm.paths()[i];
+                std::fprintf(out, "p %ld %zu", p.length(), p.nodes_.size());
+                for (const auto *n : p.nodes_) std::fprintf(out, " %u", n->index);
+                for (const auto *e : p.edges_) std::fprintf(out, " %ld", (long) (e - graph.nodes_[e->t_index].edges.data()));
+                std::fprintf(out, "\n");
+            }
+        }
+    }
+    if (out) std::fclose(out);
+    pm.filterUnique();                                                                // Main.cpp:247
+    std::cout << "Done (" << lap() << "s)" << std::endl << pm.stats() << std::endl;
+    std::cout << "edge-extension evals: " << evals << " in " << kernel_ms << " ms of walk kernels ("
+              << (kernel_ms > 0 ? evals / (kernel_ms * 1e-3) : 0.0) << " evals/s)" << std::endl;
+    auto pba = pm.getPathsBetweenAnchors();                                           // Main.cpp:251-252
+    std::cout << "Anchor pairs with paths: " << pba.size() << std::endl;
+    std::cout << "Grouping, consensus and scaffold output are not part of this build (DESIGN.md §8); "
+              << pos[4] << " not written." << std::endl;
+    return 0;
+}
