@@ -77,9 +77,9 @@ def main() -> None:
     torch.cuda.empty_cache()
     if rank == 0:
         log("dataset %s: %d records generated in %.1fs; graph %d nodes / %d adjacency entries / %d anchors built in "
-            "%.2fs (device %.1f ms, filter_score %.2f ms); max degree %d; unsafe nodes %s" % (
+            "%.2fs (device %.1f ms, filter_score %.2f ms); max degree %d; unsafe nodes %s; BFS levels %d" % (
                 args.config, n_records, t_gen, gi.n_nodes, gi.n_adj, gi.n_anchors, t_build, gi.build_ms, gi.filter_ms,
-                gi.max_degree, list(gi.unsafe_nodes)))
+                gi.max_degree, list(gi.unsafe_nodes), gi.bfs_levels))
 
     wp = capi.WalkParams.default(args.rb_att, args.bt_att, args.len_thr)
     n_anchors = int(gi.n_anchors)

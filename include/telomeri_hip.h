@@ -155,6 +155,7 @@ typedef struct {
     uint64_t n_kept_per_file[4];
     uint32_t max_degree;
     uint32_t unsafe_nodes[4];      /* per metric: nodes whose roulette sums are not order-independent */
+    uint32_t bfs_levels;           /* levels of the multi-source BFS behind the walk layout's node order (0 = none) */
     double build_ms;               /* device time of tlm_graph_build */
     double filter_ms;              /* of which: the filter_score kernel */
 } tlm_graph_info;

@@ -15,7 +15,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtelomeri_hip.so")
+# TLM_LIB selects another build of the same library (timing-only ablation builds under profiles/, never tests)
+LIB_PATH = os.environ.get("TLM_LIB") or os.path.join(HERE, "lib", "libtelomeri_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 MODE = {"min": 0, "max": 1, "avg": 2, "sum": 3}
@@ -60,7 +61,7 @@ class _Records(C.Structure):
 class GraphInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_anchors", C.c_uint32), ("n_adj", C.c_uint64), ("n_records", C.c_uint64),
                 ("n_kept", C.c_uint64), ("n_kept_per_file", C.c_uint64 * 4), ("max_degree", C.c_uint32),
-                ("unsafe_nodes", C.c_uint32 * 4), ("build_ms", C.c_double), ("filter_ms", C.c_double)]
+                ("unsafe_nodes", C.c_uint32 * 4), ("bfs_levels", C.c_uint32), ("build_ms", C.c_double), ("filter_ms", C.c_double)]
 
 
 UNIT_STAT_DTYPE = np.dtype([("status", np.uint8), ("n_nodes", np.uint32), ("steps", np.uint32), ("evals", np.uint64),

@@ -137,7 +137,7 @@ extern "C" void tlm_graph_destroy(tlm_graph *g) {
     (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
     (void) hipFree(g->node_flags); (void) hipFree(g->node_name_id); (void) hipFree(g->anchors); (void) hipFree(g->det_off);
     (void) hipFree(g->w_row); (void) hipFree(g->w_ent_es); (void) hipFree(g->w_ent_os); (void) hipFree(g->w_qs);
-    (void) hipFree(g->w_ts); (void) hipFree(g->kept_rec);
+    (void) hipFree(g->w_ts); (void) hipFree(g->kept_rec); (void) hipFree(g->w_old_of_new); (void) hipFree(g->w_anchors);
     delete g;
 }
 
@@ -459,6 +459,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         a.flag_bit = 1u << metric;
         a.metric = metric;
         a.anchors = g->anchors;
+        a.w_anchors = g->w_anchors;
+        a.old_of_new = g->w_old_of_new;
         a.n_anchors = (uint32_t) g->h_anchors.size();
         a.det_off = g->det_off;
         a.unit_begin = unit_begin;

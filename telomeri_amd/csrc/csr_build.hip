@@ -16,6 +16,7 @@
 // touching the reference's semantics is a kernel in this file.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "tlm_common.h"
@@ -262,13 +263,72 @@ __global__ void det_count_kernel(uint32_t n_anchors, const uint32_t *__restrict_
     cnt[a] = c;
 }
 
-// walk layout: padded degrees, then (after an exclusive scan) the per-node record and the row copies
-__global__ void padded_degree_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ pd) {
+// ---- locality renumbering for the walk layout ---------------------------------------------
+// Walks start at anchors and move through the anchors' neighbourhoods, testing the visited flag of every
+// neighbour of the current node.  With the reference's first-seen numbering those flags are scattered over
+// the whole N-bit set; numbering the nodes by (nearest anchor, BFS level from it, reference index) puts the
+// neighbours of a node into a window of a few hundred ids, so a wave's 64 probes fall into one or two cache
+// lines.  The renumbering is internal to the walk layout: every result is reported in reference indices.
+__global__ void bfs_init_kernel(uint32_t n_anchors, const uint32_t *__restrict__ anchors, unsigned long long *__restrict__ key,
+                                uint32_t *__restrict__ frontier) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_anchors) return;
+    key[anchors[k]] = (unsigned long long) k;          // level 0, source k
+    frontier[k] = anchors[k];
+}
+
+__global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t n_f, const uint32_t *__restrict__ frontier, uint32_t level,
+                                                         const uint32_t *__restrict__ row_ptr, const uint2 *__restrict__ ents,
+                                                         unsigned long long *__restrict__ key, uint32_t *__restrict__ next,
+                                                         uint32_t *__restrict__ n_next) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t f = wave; f < n_f; f += n_waves) {
+        const uint32_t u = frontier[f];
+        const unsigned long long nk = ((unsigned long long) (level + 1) << 32) | (key[u] & 0xFFFFFFFFull);
+        for (uint32_t e = row_ptr[u] + lane; e < row_ptr[u + 1]; e += 64) {
+            const uint32_t v = ents[e].x & 0x7FFFFFFFu;
+            // the minimum over all discoverers of v in this level is deterministic; exactly one of them sees "unseen"
+            const unsigned long long old = atomicMin(&key[v], nk);
+            if (old == ~0ull) next[atomicAdd(n_next, 1u)] = v;
+        }
+    }
+}
+
+__global__ void bfs_sortkey_kernel(uint32_t n_nodes, const unsigned long long *__restrict__ key,
+                                   unsigned long long *__restrict__ sortkey, uint32_t *__restrict__ ids) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_nodes) pd[i] = (row_ptr[i + 1] - row_ptr[i] + 3u) & ~3u;
+    if (i >= n_nodes) return;
+    const unsigned long long k = key[i];
+    // (source anchor, level); nodes no anchor reaches keep ~0 and sort last (no walk ever visits them)
+    sortkey[i] = k == ~0ull ? ~0ull : ((k & 0xFFFFFFFFull) << 32) | (k >> 32);
+    ids[i] = i;
+}
+
+__global__ void iota_perm_kernel(uint32_t n_nodes, uint32_t *__restrict__ old_of_new) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) old_of_new[i] = i;
+}
+
+__global__ void invert_perm_kernel(uint32_t n_nodes, const uint32_t *__restrict__ old_of_new, uint32_t *__restrict__ new_of_old) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) new_of_old[old_of_new[i]] = i;
+}
+
+// walk layout: padded degrees in walk order, then (after an exclusive scan) the per-node record and the row copies
+__global__ void padded_degree_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                     const uint32_t *__restrict__ old_of_new, uint32_t *__restrict__ pd) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) {
+        const uint32_t o = old_of_new[i];
+        pd[i] = (row_ptr[o + 1] - row_ptr[o] + 3u) & ~3u;
+    }
 }
 
 __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                                          const uint32_t *__restrict__ old_of_new,
+                                                          const uint32_t *__restrict__ new_of_old,
                                                           const uint32_t *__restrict__ w_start,
                                                           const uint8_t *__restrict__ node_flags,
                                                           const uint2 *__restrict__ ent_es,
@@ -280,14 +340,23 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t node = wave; node < n_nodes; node += n_waves) {
-        const uint32_t r0 = row_ptr[node], deg = row_ptr[node + 1] - r0, w0 = w_start[node];
+    for (uint32_t node = wave; node < n_nodes; node += n_waves) {     // node = index in walk order
+        const uint32_t o = old_of_new[node];
+        const uint32_t r0 = row_ptr[o], deg = row_ptr[o + 1] - r0, w0 = w_start[node];
         const uint32_t pdeg = (deg + 3u) & ~3u;
-        if (lane == 0) w_row[node] = make_uint2(w0, deg | ((uint32_t) node_flags[node] << 24));
+        if (lane == 0) w_row[node] = make_uint2(w0, deg | ((uint32_t) node_flags[o] << 24));
         for (uint32_t j = lane; j < pdeg; j += 64) {
             const bool real = j < deg;
-            w_ent_es[w0 + j] = real ? ent_es[r0 + j] : make_uint2(0u, 0u);
-            w_ent_os[w0 + j] = real ? ent_os[r0 + j] : make_uint2(0u, 0u);
+            uint2 es = make_uint2(0u, 0u), os = make_uint2(0u, 0u);
+            if (real) {
+                es = ent_es[r0 + j];
+                os = ent_os[r0 + j];
+                const uint32_t w = new_of_old[es.x & 0x7FFFFFFFu] | (es.x & 0x80000000u);   // list order is kept
+                es.x = w;
+                os.x = w;
+            }
+            w_ent_es[w0 + j] = es;
+            w_ent_os[w0 + j] = os;
             w_qs[w0 + j] = real ? q_start[r0 + j] : 0u;
             w_ts[w0 + j] = real ? t_start[r0 + j] : 0u;
         }
@@ -315,45 +384,6 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     }
     uint32_t h_cnts[8];
     TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, sizeof(h_cnts), hipMemcpyDeviceToHost, s));
-    // walk layout
-    {
-        DevBuf pd, ws;
-        if (int rc = dev_alloc(pd, ((size_t) N + 1) * 4)) return rc;
-        if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
-        uint64_t apad = 0;
-        if (N) {
-            hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, pd.as<uint32_t>());
-            size_t tb = 0;
-            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
-                                            rocprim::plus<uint32_t>(), s));
-            DevBuf tmp;
-            if (int rc = dev_alloc(tmp, tb)) return rc;
-            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
-                                            rocprim::plus<uint32_t>(), s));
-            uint32_t last_start = 0, last_pd = 0;
-            TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipMemcpyAsync(&last_pd, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipStreamSynchronize(s));
-            apad = (uint64_t) last_start + last_pd;
-            // 3 padding entries per node at most; the u32 scan must not have wrapped
-            TLM_CHECK(g->n_adj + 3ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
-        }
-        g->n_adj_pad = apad;
-        TLM_HIP(hipMalloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_qs, (apad + 256) * 4));
-        TLM_HIP(hipMalloc((void **) &g->w_ts, (apad + 256) * 4));
-        // 256 zero entries of slack after the last row: a lane's 4-entry read never leaves the buffer
-        TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
-        TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
-        if (N) {
-            hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
-                               ws.as<uint32_t>(), g->node_flags, g->ent_es, g->ent_os, g->q_start, g->t_start, g->w_row,
-                               g->w_ent_es, g->w_ent_os, g->w_qs, g->w_ts);
-        }
-        TLM_HIP(hipStreamSynchronize(s));
-    }
     std::vector<uint8_t> h_anchor(N);
     if (N) TLM_HIP(hipMemcpyAsync(h_anchor.data(), g->node_anchor, N, hipMemcpyDeviceToHost, s));
     TLM_HIP(hipStreamSynchronize(s));
@@ -368,10 +398,108 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     g->info.n_nodes = N;
     g->info.n_adj = g->n_adj;
     TLM_HIP(hipMalloc((void **) &g->anchors, (na ? na : 1) * sizeof(uint32_t)));
+    TLM_HIP(hipMalloc((void **) &g->w_anchors, (na ? na : 1) * sizeof(uint32_t)));
     TLM_HIP(hipMalloc((void **) &g->det_off, ((size_t) na + 1) * sizeof(uint64_t)));
     g->h_det_off.assign((size_t) na + 1, 0);
+    if (na) TLM_HIP(hipMemcpyAsync(g->anchors, g->h_anchors.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+
+    // ---- walk order: (nearest anchor, BFS level, reference index); identity if TLM_NO_LOCALIZE is set
+    TLM_HIP(hipMalloc((void **) &g->w_old_of_new, ((size_t) N + 1) * 4));
+    DevBuf new_of_old;
+    if (int rc = dev_alloc(new_of_old, ((size_t) N + 1) * 4)) return rc;
+    const bool localize = N && na && !std::getenv("TLM_NO_LOCALIZE");
+    g->info.bfs_levels = 0;
+    if (N) hipLaunchKernelGGL(iota_perm_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->w_old_of_new);
+    if (localize) {
+        DevBuf key, f0, f1, cnt, sortkey, sortkey_out, ids;
+        if (int rc = dev_alloc(key, (size_t) N * 8)) return rc;
+        if (int rc = dev_alloc(f0, (size_t) N * 4)) return rc;
+        if (int rc = dev_alloc(f1, (size_t) N * 4)) return rc;
+        if (int rc = dev_alloc(cnt, 4)) return rc;
+        if (int rc = dev_alloc(sortkey, (size_t) N * 8)) return rc;
+        if (int rc = dev_alloc(sortkey_out, (size_t) N * 8)) return rc;
+        if (int rc = dev_alloc(ids, (size_t) N * 4)) return rc;
+        TLM_HIP(hipMemsetAsync(key.p, 0xFF, (size_t) N * 8, s));
+        hipLaunchKernelGGL(bfs_init_kernel, dim3((na + 255) / 256), dim3(256), 0, s, na, g->anchors,
+                           key.as<unsigned long long>(), f0.as<uint32_t>());
+        uint32_t n_f = na, level = 0;
+        uint32_t *cur = f0.as<uint32_t>(), *nxt = f1.as<uint32_t>();
+        while (n_f) {
+            TLM_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
+            hipLaunchKernelGGL(bfs_expand_kernel, dim3(grid_for((uint64_t) n_f * 64)), dim3(256), 0, s, n_f, cur, level,
+                               g->row_ptr, g->ent_es, key.as<unsigned long long>(), nxt, cnt.as<uint32_t>());
+            TLM_HIP(hipMemcpyAsync(&n_f, cnt.p, 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipStreamSynchronize(s));
+            std::swap(cur, nxt);
+            level++;
+            TLM_CHECK(level <= N, TLM_EINTERNAL, "BFS did not terminate");
+        }
+        g->info.bfs_levels = level;
+        hipLaunchKernelGGL(bfs_sortkey_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, key.as<unsigned long long>(),
+                           sortkey.as<unsigned long long>(), ids.as<uint32_t>());
+        size_t tb = 0;
+        TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, sortkey.as<unsigned long long>(), sortkey_out.as<unsigned long long>(),
+                                          ids.as<uint32_t>(), g->w_old_of_new, (size_t) N, 0, 64, s));
+        DevBuf tmp;
+        if (int rc = dev_alloc(tmp, tb)) return rc;
+        TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, sortkey.as<unsigned long long>(), sortkey_out.as<unsigned long long>(),
+                                          ids.as<uint32_t>(), g->w_old_of_new, (size_t) N, 0, 64, s));
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+    if (N) hipLaunchKernelGGL(invert_perm_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->w_old_of_new,
+                              new_of_old.as<uint32_t>());
     if (na) {
-        TLM_HIP(hipMemcpyAsync(g->anchors, g->h_anchors.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        std::vector<uint32_t> h_new(N);
+        TLM_HIP(hipMemcpyAsync(h_new.data(), new_of_old.p, (size_t) N * 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        std::vector<uint32_t> wa(na);
+        for (uint32_t k = 0; k < na; k++) wa[k] = h_new[g->h_anchors[k]];
+        TLM_HIP(hipMemcpyAsync(g->w_anchors, wa.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+
+    // ---- walk layout
+    {
+        DevBuf pd, ws;
+        if (int rc = dev_alloc(pd, ((size_t) N + 1) * 4)) return rc;
+        if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
+        uint64_t apad = 0;
+        if (N) {
+            TLM_CHECK(g->n_adj + 3ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
+            hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, g->w_old_of_new,
+                               pd.as<uint32_t>());
+            size_t tb = 0;
+            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+                                            rocprim::plus<uint32_t>(), s));
+            DevBuf tmp;
+            if (int rc = dev_alloc(tmp, tb)) return rc;
+            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+                                            rocprim::plus<uint32_t>(), s));
+            uint32_t last_start = 0, last_pd = 0;
+            TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(&last_pd, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipStreamSynchronize(s));
+            apad = (uint64_t) last_start + last_pd;
+        }
+        g->n_adj_pad = apad;
+        TLM_HIP(hipMalloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2)));
+        TLM_HIP(hipMalloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2)));
+        TLM_HIP(hipMalloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2)));
+        TLM_HIP(hipMalloc((void **) &g->w_qs, (apad + 256) * 4));
+        TLM_HIP(hipMalloc((void **) &g->w_ts, (apad + 256) * 4));
+        // 256 zero entries of slack after the last row: a lane's 4-entry read never leaves the buffer
+        TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
+        TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
+        if (N) {
+            hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
+                               g->w_old_of_new, new_of_old.as<uint32_t>(), ws.as<uint32_t>(), g->node_flags, g->ent_es,
+                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qs, g->w_ts);
+        }
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+
+    // ---- DET unit table (reference layout)
+    if (na) {
         DevBuf cnt;
         if (int rc = dev_alloc(cnt, na * sizeof(uint64_t))) return rc;
         hipLaunchKernelGGL(det_count_kernel, dim3((na + 63) / 64), dim3(64), 0, s, na, g->anchors, g->row_ptr, g->ent_es,
@@ -383,11 +511,12 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     }
     TLM_HIP(hipMemcpyAsync(g->det_off, g->h_det_off.data(), ((size_t) na + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
     return TLM_OK;
 }
 
 extern "C" int tlm_graph_kept_records(const tlm_graph *g, uint32_t *rec_host) {
-    TLM_CHECK(g && rec_host, TLM_EINVAL, "tlm_graph_kept_records: null argument");
+    TLM_CHECK(g && (rec_host || g->info.n_kept == 0), TLM_EINVAL, "tlm_graph_kept_records: null argument");
     TLM_CHECK(g->kept_rec || g->info.n_kept == 0, TLM_EINVAL, "tlm_graph_kept_records: graph was not made by tlm_graph_build");
     TLM_HIP(hipSetDevice(g->device));
     if (g->info.n_kept) TLM_HIP(hipMemcpy(rec_host, g->kept_rec, g->info.n_kept * 4, hipMemcpyDeviceToHost));

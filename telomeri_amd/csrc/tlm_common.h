@@ -64,6 +64,8 @@ struct tlm_graph {
     uint2 *w_row = nullptr;            // [N] {padded row start, degree | order-safety flags << 24}
     uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
     uint32_t *w_qs = nullptr, *w_ts = nullptr;         // [n_adj_pad]
+    uint32_t *w_old_of_new = nullptr;  // [N] reference node index of each walk-order node
+    uint32_t *w_anchors = nullptr;     // [n_anchors] walk-order index of each anchor
     int32_t *node_name_id = nullptr;
     uint32_t *kept_rec = nullptr;      // [n_kept] global record index of each kept record (tlm_graph_build only)
     uint32_t *anchors = nullptr;       // [n_anchors] node index, ascending

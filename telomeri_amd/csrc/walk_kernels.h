@@ -25,8 +25,10 @@ struct WalkArgs {
     uint32_t n_nodes;
     uint32_t flag_bit;              // 1 << metric
     int32_t metric;
+    const uint32_t *old_of_new;     // reference node index of a walk-order node (results are reported in those)
     // units
-    const uint32_t *anchors;
+    const uint32_t *anchors;        // reference node index of each anchor (seeds, first node's length)
+    const uint32_t *w_anchors;      // walk-order index of each anchor
     uint32_t n_anchors;
     const uint64_t *det_off;
     uint64_t unit_begin;

@@ -155,7 +155,7 @@ __device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int
         } else {
             for (uint32_t i = lane; i < n_out; i += 64) {
                 const uint32_t node = ws.pn[i];
-                a.ar_nodes[off + i] = node;
+                a.ar_nodes[off + i] = a.old_of_new[node];          // reference index
                 a.ar_slots[off + i] = (i < m) ? (ws.pe[i] - a.rows[node].x) : 0xFFFFFFFFu;
             }
         }
@@ -257,7 +257,11 @@ __device__ __forceinline__ bool lane_candidates(const Chunk &c, const uint32_t *
 #pragma unroll
     for (int k = 0; k < 4; k++) {       // the four probes are independent: all in flight together
         const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
+#ifdef TLM_ABLATE_NOBM      /* timing-only build: no visited probes (results are wrong) */
+        w[k] = (i < deg) ? 0u : 0xFFFFFFFFu;
+#else
         w[k] = (i < deg) ? bm[(c.nb[k] & 0x7FFFFFFFu) >> 5] : 0xFFFFFFFFu;
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -322,7 +326,11 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
         const bool has = lane_candidates<SQRT>(c, bm, 0u, deg, lane, mv, lane_sum, w);
         if (!__ballot(has)) return s;                                               // :72 dead end
         s.ncand = 1;
+#ifdef TLM_ABLATE_NOSCAN    /* timing-only build: no prefix scan (results are wrong) */
+        const double incl = lane_sum * (double) (lane + 1);
+#else
         const double incl = wave_incl_scan_f64(lane_sum);
+#endif
         const double random = mt_canonical(mt, mti, lane) * readlane_f64(incl, 63);  // :104
         draws++;
         const uint64_t hm = __ballot(has && incl >= random);
@@ -426,16 +434,17 @@ __device__ Selection select_serial(const WalkArgs &a, const uint32_t *bm, volati
 
 template <bool SQRT>
 __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint32_t *mt, int lane, uint32_t ui,
-                        uint32_t start, uint32_t r) {
+                        uint32_t start, uint32_t start_ref, uint32_t r) {
+    // `start` and every node id below are walk-order indices; start_ref is the anchor's reference index
     int mti = 624;
-    mt_seed(mt, lane, walk_seed_dev(a.metric, start, r));
+    mt_seed(mt, lane, walk_seed_dev(a.metric, start_ref, r));
     uint32_t n = start;
     uint32_t m = 0;          // p.edges_.size()
     uint32_t nlog = 1;
     int64_t acc = 0;         // sum of the increments of edges 0..m-2 (all but the last pushed one)
     uint32_t pend_qs = 0, pend_ts = 0;   // q_start / t_start of the last pushed edge, in flight
     bool have_pend = false;
-    const int64_t len0 = (int64_t) a.node_len[start];
+    const int64_t len0 = (int64_t) a.node_len[start_ref];
     int backtracks = 0;
     uint32_t steps = 0, draws = 0;
     uint64_t evals = 0;
@@ -549,12 +558,12 @@ __device__ __forceinline__ uint64_t det_key(uint32_t bits, uint32_t i) {
 
 template <bool SQRT>
 __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uint32_t ui, uint32_t start,
-                         uint32_t first_slot) {
+                         uint32_t start_ref, uint32_t first_slot) {
     const uint32_t first = rfl(a.rows[start].x) + first_slot;
     const uint2 ent0 = a.ents[first];
     const uint32_t second = rfl(ent0.x & 0x7FFFFFFFu);
     const bool second_anchor = rfl(ent0.x >> 31) != 0;
-    const int64_t len0 = (int64_t) a.node_len[start];
+    const int64_t len0 = (int64_t) a.node_len[start_ref];
     uint32_t m = 1, nlog = 2;
     int64_t acc = edge_delta(a, first);
     uint32_t steps = 0;
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_mc_kernel(WalkArgs a) {
         const uint64_t unit = a.unit_begin + ui;
         const uint32_t a_rank = (uint32_t) (unit / (uint64_t) a.rebuild_attempts);
         const uint32_t r = (uint32_t) (unit % (uint64_t) a.rebuild_attempts);
-        mc_walk<SQRT>(a, ws, mt_s[wib], lane, ui, rfl(a.anchors[a_rank]), r);
+        mc_walk<SQRT>(a, ws, mt_s[wib], lane, ui, rfl(a.w_anchors[a_rank]), rfl(a.anchors[a_rank]), r);
     }
 }
 
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
             if (a.det_off[mid] <= unit) lo = mid;
             else hi = mid;
         }
-        det_walk<SQRT>(a, ws, lane, ui, rfl(a.anchors[lo]), (uint32_t) (unit - a.det_off[lo]));
+        det_walk<SQRT>(a, ws, lane, ui, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]), (uint32_t) (unit - a.det_off[lo]));
     }
 }
 
