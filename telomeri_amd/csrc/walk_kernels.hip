@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t walk_seed_dev(int metric, uint32_t anchor_no
     return 5489u + 0x9E3779B9u * (anchor_node + 1u) + 0x85EBCA6Bu * r + 0xC2B2AE35u * (uint32_t) metric;
 }
 
-__device__ inline void mt_seed(volatile uint32_t *mt, int lane, uint32_t seed) {
+__device__ inline void mt_seed(uint32_t *mt, int lane, uint32_t seed) {
     // mt[i] = 1812433253 * (mt[i-1] ^ (mt[i-1] >> 30)) + i : a serial chain, computed redundantly
     // by every lane (wave-uniform); lane i&63 keeps word i and the wave stores 64 words at a time.
     uint32_t x = seed, mine = 0;
@@ -33,9 +33,10 @@ __device__ inline void mt_seed(volatile uint32_t *mt, int lane, uint32_t seed) {
         }
         x = 1812433253u * (x ^ (x >> 30)) + (uint32_t) (i + 1);
     }
+    wave_sync();    // LDS is ordered per wave; this only keeps the compiler from caching or moving the accesses
 }
 
-__device__ inline void mt_twist(volatile uint32_t *mt, int lane) {
+__device__ inline void mt_twist(uint32_t *mt, int lane) {
     // In-place regeneration in chunks of 64 words.  Word i needs old mt[i], old mt[i+1] and
     // mt[(i+397)%624], which is an OLD word for i < 227 (it lies >= 6 chunks ahead) and a NEW word
     // for i >= 227 (it lies >= 3 chunks behind); word 623 needs the new mt[0].  Within a chunk all
@@ -63,7 +64,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 
 // uniform_real_distribution<double>(0,1)(gen): two draws, low word first, RN(x0 + x1*2^32) / 2^64,
 // clamped below 1.  The index is always even, so a pair never straddles a twist.
-__device__ inline double mt_canonical(volatile uint32_t *mt, int &idx, int lane) {
+__device__ inline double mt_canonical(uint32_t *mt, int &idx, int lane) {
     if (idx >= 624) {
         mt_twist(mt, lane);
         idx = 0;
@@ -79,6 +80,24 @@ __device__ inline double mt_canonical(volatile uint32_t *mt, int &idx, int lane)
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
+
+// Visited set of a Monte-Carlo walk.  Node ids are walk-order indices (graph build: nearest anchor, BFS level), so
+// the nodes a walk meets lie in a band of ids around its start anchor.  The band [lo, lo + WIN_BITS) lives in LDS
+// (one bit per node, cleared at walk start): a probe of a neighbour inside it is an LDS read, no global round trip.
+// Ids outside the band use the wave's N-bit map in HBM, exactly as the deterministic kernel does for every id; the
+// split is by id, so the set is exact whatever the numbering looks like.
+constexpr uint32_t WIN_BITS = 1u << 15;                 // 4 KB of LDS per wave
+constexpr uint32_t WIN_WORDS = WIN_BITS / 32;
+struct Visited {
+    uint32_t *win;
+    uint32_t lo;
+    uint32_t *bm;
+};
+
+__device__ __forceinline__ bool visited_test(const Visited &v, uint32_t n) {      // slow paths only
+    const uint32_t d = n - v.lo;
+    return d < WIN_BITS ? ((v.win[d >> 5] >> (d & 31u)) & 1u) != 0 : bm_test(v.bm, n);
+}
 
 __device__ __forceinline__ int64_t edge_delta(const WalkArgs &a, uint32_t e) {
     return (int64_t) a.q_start[e] - (int64_t) a.t_start[e];    // Path.cpp:14
@@ -193,8 +212,6 @@ struct Selection {
     bool forced;         // taken by the forced-anchor rule (:57-60)
     uint32_t ncand;      // unvisited neighbours seen (0 with pick < 0 = dead end)
     uint32_t evals;      // adjacency entries examined
-    uint32_t word;       // visited-bitmap word of `nbr` as probed (valid iff has_word): marking needs no re-read
-    bool has_word;
 };
 
 template <bool SQRT>
@@ -250,23 +267,32 @@ __device__ __forceinline__ int forced_in_chunk(const Chunk &c, uint32_t base, ui
 // One lane's view of a chunk after the visited test: metric of each candidate, -1 for "not a candidate"
 // (safe nodes have no negative metrics), and the lane's sum.
 template <bool SQRT>
-__device__ __forceinline__ bool lane_candidates(const Chunk &c, const uint32_t *bm, uint32_t base, uint32_t deg, int lane,
-                                                double (&mv)[4], double &lane_sum, uint32_t (&w)[4]) {
+__device__ __forceinline__ bool lane_candidates(const Chunk &c, const Visited &vs, uint32_t base, uint32_t deg, int lane,
+                                                double (&mv)[4], double &lane_sum) {
     bool has = false;
     lane_sum = 0.0;
+    uint32_t w[4];
+    bool far = false;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {       // the four probes are independent: all in flight together
+    for (int k = 0; k < 4; k++) {       // probes inside the LDS band
         const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
+        const uint32_t d = (c.nb[k] & 0x7FFFFFFFu) - vs.lo;
+        const bool in = i < deg;
 #ifdef TLM_ABLATE_NOBM      /* timing-only build: no visited probes (results are wrong) */
-        w[k] = (i < deg) ? 0u : 0xFFFFFFFFu;
+        w[k] = in ? 0u : 1u;
 #else
-        w[k] = (i < deg) ? bm[(c.nb[k] & 0x7FFFFFFFu) >> 5] : 0xFFFFFFFFu;
+        w[k] = !in ? 1u : d < WIN_BITS ? (vs.win[d >> 5] >> (d & 31u)) & 1u : 2u;      // 2 = look in HBM
 #endif
+        far |= w[k] == 2u;
+    }
+    if (__ballot(far)) {                // rare: a neighbour outside the band
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (w[k] == 2u) w[k] = bm_test(vs.bm, c.nb[k] & 0x7FFFFFFFu) ? 1u : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
-        const bool cand = i < deg && !((w[k] >> (c.nb[k] & 31u)) & 1u);              // :63
+        const bool cand = w[k] == 0u;                                                // :63
         mv[k] = cand ? metric_f64<SQRT>(c.mb[k]) : -1.0;
         if (cand) {
             lane_sum += mv[k];                                                       // :64
@@ -278,9 +304,8 @@ __device__ __forceinline__ bool lane_candidates(const Chunk &c, const uint32_t *
 
 // The hit lies in lane `hl` (its inclusive prefix reached `random`, the one before did not): find the first
 // candidate k of that lane whose prefix reaches `random` (:108-113) and report it.
-__device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4],
-                                                const uint32_t (&w)[4], double excl, double random, uint32_t base,
-                                                int hl) {
+__device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4], double excl,
+                                                double random, uint32_t base, int hl) {
     int myk = -1;
 #pragma unroll
     for (int k = 3; k >= 0; k--) {           // backwards, so that the FIRST k satisfying the test wins
@@ -294,20 +319,16 @@ __device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, co
     const uint32_t e0 = readlane_u32(c.nb[0], hl), e1 = readlane_u32(c.nb[1], hl);
     const uint32_t e2 = readlane_u32(c.nb[2], hl), e3 = readlane_u32(c.nb[3], hl);
     const uint32_t e = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
-    const uint32_t w0 = readlane_u32(w[0], hl), w1 = readlane_u32(w[1], hl);
-    const uint32_t w2 = readlane_u32(w[2], hl), w3 = readlane_u32(w[3], hl);
-    s.word = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
-    s.has_word = true;
     s.pick = (int) base + hl * 4 + k;
     s.nbr = e & 0x7FFFFFFFu;
     s.anchor = (e >> 31) != 0;
 }
 
 template <bool SQRT>
-__device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uint32_t *bm, volatile uint32_t *mt, int &mti,
+__device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Visited &vs, uint32_t *mt, int &mti,
                                                     int lane, uint32_t row, uint32_t deg, uint32_t start,
                                                     uint32_t &draws) {
-    Selection s{-1, 0u, false, false, 0u, deg, 0u, false};
+    Selection s{-1, 0u, false, false, 0u, deg};
     if (deg <= 256u) {
         // the whole list in one chunk: one load, one visited probe, ONE scan (it yields the total and every
         // lane's prefix), no second pass over memory
@@ -322,8 +343,7 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
             return s;
         }
         double mv[4], lane_sum;
-        uint32_t w[4];
-        const bool has = lane_candidates<SQRT>(c, bm, 0u, deg, lane, mv, lane_sum, w);
+        const bool has = lane_candidates<SQRT>(c, vs, 0u, deg, lane, mv, lane_sum);
         if (!__ballot(has)) return s;                                               // :72 dead end
         s.ncand = 1;
 #ifdef TLM_ABLATE_NOSCAN    /* timing-only build: no prefix scan (results are wrong) */
@@ -334,7 +354,7 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
         const double random = mt_canonical(mt, mti, lane) * readlane_f64(incl, 63);  // :104
         draws++;
         const uint64_t hm = __ballot(has && incl >= random);
-        if (hm) resolve_in_lane(s, c, mv, w, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
+        if (hm) resolve_in_lane(s, c, mv, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
         return s;
     }
     // ---- longer lists, pass 1 (:53-67): total over the unvisited neighbours, chunk after chunk
@@ -351,8 +371,7 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
             return s;
         }
         double mv[4], lane_sum;
-        uint32_t w[4];
-        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum, w);
+        const bool has = lane_candidates<SQRT>(c, vs, base, deg, lane, mv, lane_sum);
         if (__ballot(has)) {
             total += readlane_f64(wave_incl_scan_f64(lane_sum), 63);
             s.ncand = 1;
@@ -366,14 +385,13 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
     for (uint32_t base = 0; base < deg; base += 256) {
         const Chunk c = load_chunk(a.ents, row, base, deg, lane);
         double mv[4], lane_sum;
-        uint32_t w[4];
-        const bool has = lane_candidates<SQRT>(c, bm, base, deg, lane, mv, lane_sum, w);
+        const bool has = lane_candidates<SQRT>(c, vs, base, deg, lane, mv, lane_sum);
         if (!__ballot(has)) continue;
         const double incl = wave_incl_scan_f64(lane_sum) + carry;
         carry = readlane_f64(incl, 63);
         const uint64_t hm = __ballot(has && incl >= random);
         if (hm) {
-            resolve_in_lane(s, c, mv, w, incl - lane_sum, random, base, __ffsll((unsigned long long) hm) - 1);
+            resolve_in_lane(s, c, mv, incl - lane_sum, random, base, __ffsll((unsigned long long) hm) - 1);
             return s;
         }
     }
@@ -383,9 +401,9 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const uin
 // Unsafe node (a metric is negative / not finite, or the sums are not exact in a double): the additions are made
 // one candidate after the other in list order, as PathManager.cpp:64,109 makes them.  Rare; never on real overlaps.
 template <bool SQRT>
-__device__ Selection select_serial(const WalkArgs &a, const uint32_t *bm, volatile uint32_t *mt, int &mti,
+__device__ Selection select_serial(const WalkArgs &a, const Visited &vs, uint32_t *mt, int &mti,
                                                 int lane, uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws) {
-    Selection s{-1, 0u, false, false, 0u, deg, 0u, false};
+    Selection s{-1, 0u, false, false, 0u, deg};
     double total = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         double run = 0.0;
@@ -411,7 +429,7 @@ __device__ Selection select_serial(const WalkArgs &a, const uint32_t *bm, volati
                     return s;
                 }
             }
-            const bool cand = valid && !bm_test(bm, nbr);                          // :63
+            const bool cand = valid && !visited_test(vs, valid ? nbr : vs.lo);       // :63
             uint64_t cm = __ballot(cand);
             if (pass == 0) s.ncand += (uint32_t) __popcll((unsigned long long) cm);
             const double mv = cand ? metric_f64<SQRT>(ent.y) : 0.0;
@@ -433,14 +451,19 @@ __device__ Selection select_serial(const WalkArgs &a, const uint32_t *bm, volati
 }
 
 template <bool SQRT>
-__device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint32_t *mt, int lane, uint32_t ui,
-                        uint32_t start, uint32_t start_ref, uint32_t r) {
+__device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, int lane,
+                        uint32_t ui, uint32_t start, uint32_t start_ref, uint32_t r) {
     // `start` and every node id below are walk-order indices; start_ref is the anchor's reference index
     int mti = 624;
     mt_seed(mt, lane, walk_seed_dev(a.metric, start_ref, r));
+    Visited vs;
+    vs.win = win;
+    vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
+    vs.bm = ws.bm;
+    for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
     uint32_t n = start;
     uint32_t m = 0;          // p.edges_.size()
-    uint32_t nlog = 1;
+    uint32_t nlog = 0;       // marks that went to the HBM map (ids outside the LDS band)
     int64_t acc = 0;         // sum of the increments of edges 0..m-2 (all but the last pushed one)
     uint32_t pend_qs = 0, pend_ts = 0;   // q_start / t_start of the last pushed edge, in flight
     bool have_pend = false;
@@ -452,8 +475,11 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
     uint8_t status = ST_ABANDONED;
     if (lane == 0) {
         ws.pn[0] = start;                               // :39
-        ws.bm[start >> 5] |= 1u << (start & 31);        // :33
-        ws.lg[0] = start;
+    }
+    wave_sync();
+    if (lane == 0) {                                    // :33, start lies inside the band by construction
+        const uint32_t d = start - vs.lo;
+        win[d >> 5] |= 1u << (d & 31u);
     }
     wave_sync();
     for (;;) {                                          // :48
@@ -462,8 +488,8 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
         const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
         // ---- selection scan (:53-115)
-        const Selection s = safe ? select_blocked<SQRT>(a, ws.bm, mt, mti, lane, row, deg, start, draws)
-                                 : select_serial<SQRT>(a, ws.bm, mt, mti, lane, row, deg, start, draws);
+        const Selection s = safe ? select_blocked<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws)
+                                 : select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws);
         evals += s.evals;
         steps++;
         if (s.pick < 0) {
@@ -485,7 +511,7 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
                         const uint32_t i = base + lane;
                         const bool valid = i < bdeg;
                         const uint32_t nbr = valid ? (a.ents[brow + i].x & 0x7FFFFFFFu) : 0u;
-                        if (__ballot(valid && !bm_test(ws.bm, nbr))) t = true;
+                        if (__ballot(valid && !visited_test(vs, valid ? nbr : vs.lo))) t = true;
                     }
                 } while (m != 0 && !t);
                 if (m == 0) break;                      // :90-95
@@ -507,16 +533,18 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, volatile uint3
             break;
         }
         const uint32_t eidx = row + (uint32_t) s.pick;
+        const uint32_t md = s.nbr - vs.lo;
+        const bool mark_far = md >= WIN_BITS && !s.forced;     // a forced pick ends the walk: nothing probes it again
         if (lane == 0) {
             ws.pe[m] = eidx;
             ws.pn[m + 1] = s.nbr;
-            // visited mark without a read-modify-write round trip: the probe already fetched the word.  A forced
-            // pick is an anchor, the walk ends with it and nothing is probed afterwards.
-            if (s.has_word) ws.bm[s.nbr >> 5] = s.word | (1u << (s.nbr & 31));
-            else if (!s.forced) ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
-            ws.lg[nlog] = s.nbr;
+            if (md < WIN_BITS) atomicOr(win + (md >> 5), 1u << (md & 31u));     // :123 (ds_or_b32)
+            else if (mark_far) {
+                ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
+                ws.lg[nlog] = s.nbr;
+            }
         }
-        nlog++;
+        if (mark_far) nlog++;
         // :125 -- Path::length() after this push excludes the new last edge (Path.cpp:12-15): it is len0 plus the
         // increments of all EARLIER edges.  The increment of the edge pushed in the previous step was requested
         // then (pend_*) and is only consumed here, a whole step later, so its latency is never waited for.
@@ -712,8 +740,9 @@ __device__ __forceinline__ bool next_work(const WalkArgs &a, int lane, uint32_t 
 }
 
 template <bool SQRT>
-__global__ __launch_bounds__(WALK_BLOCK) void walk_mc_kernel(WalkArgs a) {
+__global__ __launch_bounds__(WALK_BLOCK, 4) void walk_mc_kernel(WalkArgs a) {
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
+    __shared__ uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
@@ -722,7 +751,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_mc_kernel(WalkArgs a) {
         const uint64_t unit = a.unit_begin + ui;
         const uint32_t a_rank = (uint32_t) (unit / (uint64_t) a.rebuild_attempts);
         const uint32_t r = (uint32_t) (unit % (uint64_t) a.rebuild_attempts);
-        mc_walk<SQRT>(a, ws, mt_s[wib], lane, ui, rfl(a.w_anchors[a_rank]), rfl(a.anchors[a_rank]), r);
+        mc_walk<SQRT>(a, ws, mt_s[wib], win_s[wib], lane, ui, rfl(a.w_anchors[a_rank]), rfl(a.anchors[a_rank]), r);
     }
 }
 
