@@ -30,18 +30,18 @@ extern "C" uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r) 
 
 struct Workspace {   // walk scratch kept across calls (bench loops); bitmaps stay all-zero between walks
     uint32_t waves = 0, cap = 0, bm_words = 0;
-    uint32_t *sc_nodes = nullptr, *sc_edges = nullptr, *sc_log = nullptr, *bitmaps = nullptr;
+    uint32_t *scratch = nullptr, *bitmaps = nullptr;
     uint64_t ar_cap = 0;
-    uint32_t *ar_nodes = nullptr, *ar_slots = nullptr;
+    uint2 *arena = nullptr;
     uint32_t *cursor = nullptr;              // [4]: work cursor (u32) + pad, arena cursor (u64)
     void release_scratch() {
-        (void) hipFree(sc_nodes); (void) hipFree(sc_edges); (void) hipFree(sc_log); (void) hipFree(bitmaps);
-        sc_nodes = sc_edges = sc_log = bitmaps = nullptr;
+        (void) hipFree(scratch); (void) hipFree(bitmaps);
+        scratch = bitmaps = nullptr;
         waves = cap = bm_words = 0;
     }
     void release_arena() {
-        (void) hipFree(ar_nodes); (void) hipFree(ar_slots);
-        ar_nodes = ar_slots = nullptr;
+        (void) hipFree(arena);
+        arena = nullptr;
         ar_cap = 0;
     }
 };
@@ -136,8 +136,8 @@ extern "C" void tlm_graph_destroy(tlm_graph *g) {
     (void) hipFree(g->q_start); (void) hipFree(g->t_start); (void) hipFree(g->q_end); (void) hipFree(g->t_end);
     (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
     (void) hipFree(g->node_flags); (void) hipFree(g->node_name_id); (void) hipFree(g->anchors); (void) hipFree(g->det_off);
-    (void) hipFree(g->w_row); (void) hipFree(g->w_ent_es); (void) hipFree(g->w_ent_os); (void) hipFree(g->w_qs);
-    (void) hipFree(g->w_ts); (void) hipFree(g->kept_rec); (void) hipFree(g->w_old_of_new); (void) hipFree(g->w_anchors);
+    (void) hipFree(g->w_row); (void) hipFree(g->w_ent_es); (void) hipFree(g->w_ent_os); (void) hipFree(g->w_qt);
+    (void) hipFree(g->kept_rec); (void) hipFree(g->w_old_of_new); (void) hipFree(g->w_anchors);
     delete g;
 }
 
@@ -255,8 +255,7 @@ extern "C" int tlm_graph_anchor_table(const tlm_graph *g, uint32_t *anchor_nodes
 // result packing kernels
 
 // Exclusive scan over the units of (accepted ? 1 : 0) and (accepted ? n_nodes : 0); one workgroup.
-__global__ __launch_bounds__(1024) void scan_units_kernel(uint32_t n_units, const uint8_t *__restrict__ status,
-                                                          const uint32_t *__restrict__ nnodes,
+__global__ __launch_bounds__(1024) void scan_units_kernel(uint32_t n_units, const UnitOut *__restrict__ units,
                                                           uint32_t *__restrict__ p_index, uint64_t *__restrict__ n_off,
                                                           uint64_t *__restrict__ totals) {
     __shared__ uint64_t s_cnt[1024];
@@ -265,8 +264,8 @@ __global__ __launch_bounds__(1024) void scan_units_kernel(uint32_t n_units, cons
     const int t = threadIdx.x;
     for (uint32_t base = 0; base < n_units; base += 1024) {
         const uint32_t i = base + t;
-        const bool acc = i < n_units && status[i] == ST_ACCEPTED;
-        const uint64_t c = acc ? 1 : 0, v = acc ? nnodes[i] : 0;
+        const bool acc = i < n_units && units[i].status == ST_ACCEPTED;
+        const uint64_t c = acc ? 1 : 0, v = acc ? units[i].nnodes : 0;
         s_cnt[t] = c;
         s_sum[t] = v;
         __syncthreads();
@@ -290,32 +289,29 @@ __global__ __launch_bounds__(1024) void scan_units_kernel(uint32_t n_units, cons
 }
 
 __global__ __launch_bounds__(256) void pack_paths_kernel(uint32_t n_units, uint64_t unit_begin,
-                                                         const uint8_t *__restrict__ status,
-                                                         const uint32_t *__restrict__ nnodes,
-                                                         const int64_t *__restrict__ u_len,
-                                                         const uint64_t *__restrict__ u_off,
+                                                         const UnitOut *__restrict__ units,
                                                          const uint32_t *__restrict__ p_index,
                                                          const uint64_t *__restrict__ n_off,
-                                                         const uint32_t *__restrict__ ar_nodes,
-                                                         const uint32_t *__restrict__ ar_slots,
-                                                         uint64_t *__restrict__ o_unit, int64_t *__restrict__ o_len,
-                                                         uint64_t *__restrict__ o_off, uint32_t *__restrict__ o_nodes,
-                                                         uint32_t *__restrict__ o_slots) {
+                                                         const uint2 *__restrict__ arena, uint64_t *__restrict__ o_unit,
+                                                         int64_t *__restrict__ o_len, uint64_t *__restrict__ o_off,
+                                                         uint32_t *__restrict__ o_nodes, uint32_t *__restrict__ o_slots) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t ui = wave; ui < n_units; ui += n_waves) {
-        if (status[ui] != ST_ACCEPTED) continue;
-        const uint32_t pi = p_index[ui], n = nnodes[ui];
-        const uint64_t src = u_off[ui], dst = n_off[ui];
+        const UnitOut u = units[ui];
+        if (u.status != ST_ACCEPTED) continue;
+        const uint32_t pi = p_index[ui], n = u.nnodes;
+        const uint64_t src = u.off, dst = n_off[ui];
         if (lane == 0) {
             o_unit[pi] = unit_begin + ui;
-            o_len[pi] = u_len[ui];
+            o_len[pi] = u.len;
             o_off[pi] = dst;
         }
         for (uint32_t i = lane; i < n; i += 64) {
-            o_nodes[dst + i] = ar_nodes[src + i];
-            o_slots[dst + i] = ar_slots[src + i];
+            const uint2 e = arena[src + i];
+            o_nodes[dst + i] = e.x;
+            o_slots[dst + i] = e.y;
         }
     }
 }
@@ -326,16 +322,12 @@ __global__ __launch_bounds__(256) void pack_paths_kernel(uint32_t n_units, uint6
 namespace {
 
 struct UnitBufs {
-    uint8_t *status = nullptr;
-    uint32_t *nnodes = nullptr, *steps = nullptr, *draws = nullptr;
-    int64_t *len = nullptr;
-    uint64_t *evals = nullptr, *off = nullptr;
+    UnitOut *units = nullptr;
     uint32_t *p_index = nullptr;
     uint64_t *n_off = nullptr, *totals = nullptr;
     uint32_t *work_list = nullptr;
     ~UnitBufs() {
-        (void) hipFree(status); (void) hipFree(nnodes); (void) hipFree(steps); (void) hipFree(draws); (void) hipFree(len);
-        (void) hipFree(evals); (void) hipFree(off); (void) hipFree(p_index); (void) hipFree(n_off); (void) hipFree(totals);
+        (void) hipFree(units); (void) hipFree(p_index); (void) hipFree(n_off); (void) hipFree(totals);
         (void) hipFree(work_list);
     }
 };
@@ -349,9 +341,7 @@ int ensure_scratch(CtxImpl *c, uint32_t waves, uint32_t cap, uint32_t bm_words) 
     Workspace &w = c->ws;
     if (w.waves >= waves && w.cap == cap && w.bm_words == bm_words) return TLM_OK;
     w.release_scratch();
-    if (int rc = dmalloc(&w.sc_nodes, (size_t) waves * cap)) return rc;
-    if (int rc = dmalloc(&w.sc_edges, (size_t) waves * cap)) return rc;
-    if (int rc = dmalloc(&w.sc_log, (size_t) waves * cap)) return rc;
+    if (int rc = dmalloc(&w.scratch, (size_t) waves * cap * 3)) return rc;
     if (int rc = dmalloc(&w.bitmaps, (size_t) waves * bm_words)) return rc;
     TLM_HIP(hipMemsetAsync(w.bitmaps, 0, (size_t) waves * bm_words * 4, c->stream));
     w.waves = waves;
@@ -364,17 +354,14 @@ int ensure_scratch(CtxImpl *c, uint32_t waves, uint32_t cap, uint32_t bm_words) 
 int ensure_arena(CtxImpl *c, uint64_t need, uint64_t keep) {
     Workspace &w = c->ws;
     if (w.ar_cap >= need) return TLM_OK;
-    uint32_t *nn = nullptr, *ns = nullptr;
+    uint2 *nn = nullptr;
     if (int rc = dmalloc(&nn, (size_t) need)) return rc;
-    if (int rc = dmalloc(&ns, (size_t) need)) { (void) hipFree(nn); return rc; }
     if (keep) {
-        TLM_HIP(hipMemcpyAsync(nn, w.ar_nodes, keep * 4, hipMemcpyDeviceToDevice, c->stream));
-        TLM_HIP(hipMemcpyAsync(ns, w.ar_slots, keep * 4, hipMemcpyDeviceToDevice, c->stream));
+        TLM_HIP(hipMemcpyAsync(nn, w.arena, keep * sizeof(uint2), hipMemcpyDeviceToDevice, c->stream));
         TLM_HIP(hipStreamSynchronize(c->stream));
     }
     w.release_arena();
-    w.ar_nodes = nn;
-    w.ar_slots = ns;
+    w.arena = nn;
     w.ar_cap = need;
     return TLM_OK;
 }
@@ -405,22 +392,14 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
     std::memset(&cnt, 0, sizeof(cnt));
 
     UnitBufs u;
-    if (int rc = dmalloc(&u.status, n_units)) return rc;
-    if (int rc = dmalloc(&u.nnodes, n_units)) return rc;
-    if (int rc = dmalloc(&u.steps, n_units)) return rc;
-    if (int rc = dmalloc(&u.draws, n_units)) return rc;
-    if (int rc = dmalloc(&u.len, n_units)) return rc;
-    if (int rc = dmalloc(&u.evals, n_units)) return rc;
-    if (int rc = dmalloc(&u.off, n_units)) return rc;
+    if (int rc = dmalloc(&u.units, n_units)) return rc;
     if (int rc = dmalloc(&u.p_index, n_units)) return rc;
     if (int rc = dmalloc(&u.n_off, n_units)) return rc;
     if (int rc = dmalloc(&u.totals, 2)) return rc;
     if (int rc = dmalloc(&u.work_list, n_units)) return rc;
-    TLM_HIP(hipMemsetAsync(u.status, ST_NOT_RUN, n_units ? n_units : 1, s));
+    TLM_HIP(hipMemsetAsync(u.units, 0xFF, (size_t) (n_units ? n_units : 1) * sizeof(UnitOut), s));   // status = not run
 
-    std::vector<uint8_t> h_status(n_units);
-    std::vector<uint64_t> h_off(n_units);
-    std::vector<uint32_t> h_nn(n_units);
+    std::vector<UnitOut> h_units(n_units);
 
     if (n_units) {
         const uint32_t N = g->n_nodes;
@@ -446,14 +425,14 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
             if (int rc = ensure_arena(c, std::max<uint64_t>(1u << 20, want), 0)) return rc;
         }
         unsigned long long *ar_cursor = (unsigned long long *) (c->ws.cursor + 2);
+        (void) ar_cursor;
         TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 16, s));
 
         WalkArgs a;
         std::memset(&a, 0, sizeof(a));
         a.rows = g->w_row;
         a.ents = (metric == TLM_METRIC_ES || metric == TLM_METRIC_ES_SQRT) ? g->w_ent_es : g->w_ent_os;
-        a.q_start = g->w_qs;
-        a.t_start = g->w_ts;
+        a.qt = g->w_qt;
         a.node_len = g->node_len;
         a.n_nodes = N;
         a.flag_bit = 1u << metric;
@@ -468,9 +447,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         a.backtrack_attempts = is_mc ? p->backtrack_attempts : 0;
         a.len_threshold = is_mc ? p->len_threshold : 0;
         a.cursor = c->ws.cursor;
-        a.u_status = u.status; a.u_nnodes = u.nnodes; a.u_steps = u.steps; a.u_draws = u.draws;
-        a.u_len = u.len; a.u_evals = u.evals; a.u_off = u.off;
-        a.ar_cursor = ar_cursor;
+        a.units = u.units;
         const bool sq = metric >= 2;
 
         std::vector<uint32_t> work;     // empty = identity
@@ -479,11 +456,12 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         for (int round = 0; round < 64; round++) {
             a.n_work = n_work;
             a.work_list = work.empty() ? nullptr : u.work_list;
-            a.sc_nodes = c->ws.sc_nodes; a.sc_edges = c->ws.sc_edges; a.sc_log = c->ws.sc_log;
+            a.scratch = c->ws.scratch;
             a.cap = c->ws.cap;
             a.bitmaps = c->ws.bitmaps;
             a.bm_words = c->ws.bm_words;
-            a.ar_nodes = c->ws.ar_nodes; a.ar_slots = c->ws.ar_slots; a.ar_cap = c->ws.ar_cap;
+            a.arena = c->ws.arena;
+            a.ar_cap = c->ws.ar_cap;
             uint32_t launch_waves = std::min<uint32_t>(cur_waves, ((n_work + 3) / 4) * 4);
             launch_waves = std::max<uint32_t>(4u, launch_waves);
             TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 4, s));
@@ -492,7 +470,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
             else tlm_launch_walk_det(s, launch_waves / 4, sq, a);
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ctx->ev1, s));
-            TLM_HIP(hipMemcpyAsync(h_status.data(), u.status, n_units, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_units * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipEventSynchronize(ctx->ev1));
             TLM_HIP(hipStreamSynchronize(s));
             float ms = 0;
@@ -502,18 +480,16 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
             // overflow handling: re-run the affected units with a full-size path buffer / a larger arena
             std::vector<uint32_t> sc_ovf, ar_ovf;
             for (uint32_t i = 0; i < n_units; i++) {
-                if (h_status[i] == ST_SCRATCH_OVF) sc_ovf.push_back(i);
-                else if (h_status[i] == ST_ARENA_OVF) ar_ovf.push_back(i);
-                else TLM_CHECK(h_status[i] != ST_NOT_RUN, TLM_EINTERNAL, "walk: unit %u was not run", i);
+                const uint32_t st = h_units[i].status;
+                if (st == ST_SCRATCH_OVF) sc_ovf.push_back(i);
+                else if (st == ST_ARENA_OVF) ar_ovf.push_back(i);
+                else TLM_CHECK(st <= ST_NEGATIVE, TLM_EINTERNAL, "walk: unit %u was not run (status %u)", i, st);
             }
             if (sc_ovf.empty() && ar_ovf.empty()) break;
             TLM_CHECK(round < 63, TLM_EINTERNAL, "walk: overflow re-runs did not converge");
             if (!ar_ovf.empty()) {
-                TLM_HIP(hipMemcpyAsync(h_off.data(), u.off, (size_t) n_units * 8, hipMemcpyDeviceToHost, s));
-                TLM_HIP(hipMemcpyAsync(h_nn.data(), u.nnodes, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
-                TLM_HIP(hipStreamSynchronize(s));
                 uint64_t keep = ~0ull, extra = 0;
-                for (uint32_t i : ar_ovf) { keep = std::min(keep, h_off[i]); extra += h_nn[i]; }
+                for (uint32_t i : ar_ovf) { keep = std::min<uint64_t>(keep, h_units[i].off); extra += h_units[i].nnodes; }
                 // every reservation after the first failed one failed too, so [0, keep) is all valid paths
                 if (int rc = ensure_arena(c, (keep + extra) + (keep + extra) / 4 + (1u << 20), keep)) return rc;
                 unsigned long long k = keep;
@@ -538,8 +514,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         }
 
         // pack accepted paths in unit order
-        hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, s, n_units, u.status, u.nnodes, u.p_index, u.n_off,
-                           u.totals);
+        hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, s, n_units, u.units, u.p_index, u.n_off, u.totals);
         uint64_t h_tot[2] = {0, 0};
         TLM_HIP(hipMemcpyAsync(h_tot, u.totals, 16, hipMemcpyDeviceToHost, s));
         TLM_HIP(hipStreamSynchronize(s));
@@ -553,37 +528,29 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
     if (int rc = dmalloc(&ps->slots, ps->n_nodes_total)) return rc;
     if (n_units) {
         uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
-        hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, u.status,
-                           u.nnodes, u.len, u.off, u.p_index, u.n_off, c->ws.ar_nodes, c->ws.ar_slots, ps->unit, ps->length,
-                           ps->off, ps->nodes, ps->slots);
+        hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, u.units,
+                           u.p_index, u.n_off, c->ws.arena, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
         TLM_HIP(hipGetLastError());
     }
     TLM_HIP(hipMemcpyAsync(ps->off + ps->n_paths, &ps->n_nodes_total, 8, hipMemcpyHostToDevice, s));
 
-    // per-unit outcomes to the host
+    // per-unit outcomes to the host (the last launch's copy of `units` is current: re-runs only rewrite their units)
     ps->stats.resize(n_units);
     if (n_units) {
-        std::vector<uint32_t> h_steps(n_units), h_draws(n_units);
-        std::vector<int64_t> h_len(n_units);
-        std::vector<uint64_t> h_evals(n_units);
-        TLM_HIP(hipMemcpyAsync(h_status.data(), u.status, n_units, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipMemcpyAsync(h_nn.data(), u.nnodes, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipMemcpyAsync(h_steps.data(), u.steps, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipMemcpyAsync(h_draws.data(), u.draws, (size_t) n_units * 4, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipMemcpyAsync(h_len.data(), u.len, (size_t) n_units * 8, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipMemcpyAsync(h_evals.data(), u.evals, (size_t) n_units * 8, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_units * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
         TLM_HIP(hipStreamSynchronize(s));
         for (uint32_t i = 0; i < n_units; i++) {
             tlm_unit_stat &st = ps->stats[i];
-            st.status = h_status[i];
-            st.n_nodes = h_nn[i];
-            st.steps = h_steps[i];
-            st.evals = h_evals[i];
-            st.draws = h_draws[i];
-            st.length = h_len[i];
-            cnt.steps += h_steps[i];
-            cnt.evals += h_evals[i];
-            cnt.draws += h_draws[i];
+            const UnitOut &o = h_units[i];
+            st.status = (uint8_t) o.status;
+            st.n_nodes = o.nnodes;
+            st.steps = o.steps;
+            st.evals = o.evals;
+            st.draws = o.draws;
+            st.length = o.len;
+            cnt.steps += o.steps;
+            cnt.evals += o.evals;
+            cnt.draws += o.draws;
         }
     }
     TLM_HIP(hipStreamSynchronize(s));

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
                                                           const uint32_t *__restrict__ q_start,
                                                           const uint32_t *__restrict__ t_start, uint2 *__restrict__ w_row,
                                                           uint2 *__restrict__ w_ent_es, uint2 *__restrict__ w_ent_os,
-                                                          uint32_t *__restrict__ w_qs, uint32_t *__restrict__ w_ts) {
+                                                          uint2 *__restrict__ w_qt) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -357,8 +357,7 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
             }
             w_ent_es[w0 + j] = es;
             w_ent_os[w0 + j] = os;
-            w_qs[w0 + j] = real ? q_start[r0 + j] : 0u;
-            w_ts[w0 + j] = real ? t_start[r0 + j] : 0u;
+            w_qt[w0 + j] = real ? make_uint2(q_start[r0 + j], t_start[r0 + j]) : make_uint2(0u, 0u);
         }
     }
 }
@@ -485,15 +484,14 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         TLM_HIP(hipMalloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2)));
         TLM_HIP(hipMalloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2)));
         TLM_HIP(hipMalloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_qs, (apad + 256) * 4));
-        TLM_HIP(hipMalloc((void **) &g->w_ts, (apad + 256) * 4));
+        TLM_HIP(hipMalloc((void **) &g->w_qt, (apad + 256) * sizeof(uint2)));
         // 256 zero entries of slack after the last row: a lane's 4-entry read never leaves the buffer
         TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
         TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
         if (N) {
             hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
                                g->w_old_of_new, new_of_old.as<uint32_t>(), ws.as<uint32_t>(), g->node_flags, g->ent_es,
-                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qs, g->w_ts);
+                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt);
         }
         TLM_HIP(hipStreamSynchronize(s));
     }

@@ -63,7 +63,7 @@ struct tlm_graph {
     uint64_t n_adj_pad = 0;
     uint2 *w_row = nullptr;            // [N] {padded row start, degree | order-safety flags << 24}
     uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
-    uint32_t *w_qs = nullptr, *w_ts = nullptr;         // [n_adj_pad]
+    uint2 *w_qt = nullptr;             // [n_adj_pad] {q_start, t_start}
     uint32_t *w_old_of_new = nullptr;  // [N] reference node index of each walk-order node
     uint32_t *w_anchors = nullptr;     // [n_anchors] walk-order index of each anchor
     int32_t *node_name_id = nullptr;

@@ -16,16 +16,26 @@
 
 #include "tlm_common.h"
 
+// Outcome of one walk unit (device -> host), one record per unit of a call.
+struct UnitOut {
+    uint64_t evals;
+    uint64_t off;          // arena offset of the accepted path
+    int64_t len;           // last Path::length()
+    uint32_t nnodes, steps, draws;
+    uint32_t status;       // ST_*
+};
+
+// Kernel arguments.  Kept small on purpose: every pointer is two SGPRs that stay live across the walk loop.
 struct WalkArgs {
-    // graph (tlm_graph, walk layout: rows padded to 4 entries)
+    // graph (tlm_graph, walk layout: rows padded to 4 entries, nodes in locality order)
     const uint2 *rows;              // per node {row start, degree | order-safety flags << 24}
     const uint2 *ents;              // w_ent_es or w_ent_os
-    const uint32_t *q_start, *t_start;
-    const uint32_t *node_len;
+    const uint2 *qt;                // per entry {q_start, t_start}: the length increment of Path::updateLength
+    const uint32_t *node_len;       // reference order
+    const uint32_t *old_of_new;     // reference node index of a walk-order node (results are reported in those)
     uint32_t n_nodes;
     uint32_t flag_bit;              // 1 << metric
     int32_t metric;
-    const uint32_t *old_of_new;     // reference node index of a walk-order node (results are reported in those)
     // units
     const uint32_t *anchors;        // reference node index of each anchor (seeds, first node's length)
     const uint32_t *w_anchors;      // walk-order index of each anchor
@@ -36,22 +46,16 @@ struct WalkArgs {
     const uint32_t *work_list;      // unit - unit_begin per work item, or null = identity
     int32_t rebuild_attempts, backtrack_attempts;
     int64_t len_threshold;
-    // per-wave scratch
-    uint32_t *sc_nodes, *sc_edges, *sc_log;
-    uint32_t cap;                   // entries per wave in each scratch array
+    // per-wave scratch: [wave][3][cap] = path nodes, path edge indices, mark log
+    uint32_t *scratch;
+    uint32_t cap;
     uint32_t *bitmaps;
-    uint32_t bm_words;              // words per wave
-    // work queue
+    uint32_t bm_words;              // 32-bit words per wave
+    // work cursor at cursor[0], arena cursor (u64) at cursor[2..3]
     uint32_t *cursor;
-    // per-unit outputs
-    uint8_t *u_status;
-    uint32_t *u_nnodes, *u_steps, *u_draws;
-    int64_t *u_len;
-    uint64_t *u_evals, *u_off;
-    // arena of accepted paths
-    uint32_t *ar_nodes, *ar_slots;
+    UnitOut *units;
+    uint2 *arena;                   // accepted paths: {reference node, edge slot}
     uint64_t ar_cap;
-    unsigned long long *ar_cursor;
 };
 
 constexpr int WALK_BLOCK = 256;                 // 4 independent waves per workgroup

@@ -100,7 +100,8 @@ __device__ __forceinline__ bool visited_test(const Visited &v, uint32_t n) {    
 }
 
 __device__ __forceinline__ int64_t edge_delta(const WalkArgs &a, uint32_t e) {
-    return (int64_t) a.q_start[e] - (int64_t) a.t_start[e];    // Path.cpp:14
+    const uint2 qt = a.qt[e];
+    return (int64_t) qt.x - (int64_t) qt.y;                    // Path.cpp:14
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -167,26 +168,28 @@ __device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int
     uint64_t off = 0;
     if (status == ST_ACCEPTED) {
         unsigned long long o = 0;
-        if (lane == 0) o = atomicAdd(a.ar_cursor, (unsigned long long) n_out);
+        if (lane == 0) o = atomicAdd(reinterpret_cast<unsigned long long *>(a.cursor + 2), (unsigned long long) n_out);
         off = __shfl(o, 0);
         if (off + n_out > a.ar_cap) {
             status = ST_ARENA_OVF;
         } else {
             for (uint32_t i = lane; i < n_out; i += 64) {
                 const uint32_t node = ws.pn[i];
-                a.ar_nodes[off + i] = a.old_of_new[node];          // reference index
-                a.ar_slots[off + i] = (i < m) ? (ws.pe[i] - a.rows[node].x) : 0xFFFFFFFFu;
+                a.arena[off + i] = make_uint2(a.old_of_new[node],                     // reference index
+                                              (i < m) ? (ws.pe[i] - a.rows[node].x) : 0xFFFFFFFFu);
             }
         }
     }
     if (lane == 0) {
-        a.u_status[ui] = status;
-        a.u_nnodes[ui] = n_out;
-        a.u_len[ui] = len_final;
-        a.u_steps[ui] = steps;
-        a.u_evals[ui] = evals;
-        a.u_draws[ui] = draws;
-        a.u_off[ui] = off;
+        UnitOut u;
+        u.evals = evals;
+        u.off = off;
+        u.len = len_final;
+        u.nnodes = n_out;
+        u.steps = steps;
+        u.draws = draws;
+        u.status = status;
+        a.units[ui] = u;
     }
     for (uint32_t i = lane; i < nlog; i += 64) ws.bm[ws.lg[i] >> 5] = 0u;
     wave_sync();
@@ -306,15 +309,15 @@ __device__ __forceinline__ bool lane_candidates(const Chunk &c, const Visited &v
 // candidate k of that lane whose prefix reaches `random` (:108-113) and report it.
 __device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4], double excl,
                                                 double random, uint32_t base, int hl) {
-    int myk = -1;
-#pragma unroll
-    for (int k = 3; k >= 0; k--) {           // backwards, so that the FIRST k satisfying the test wins
-        double p = excl;
-#pragma unroll
-        for (int j = 0; j <= k; j++)
-            if (mv[j] >= 0.0) p += mv[j];
-        if (mv[k] >= 0.0 && p >= random) myk = k;                                    // :110
-    }
+    // running prefix inside the lane (every sum is exact on a safe node)
+    const double p0 = excl + (mv[0] >= 0.0 ? mv[0] : 0.0);
+    const double p1 = p0 + (mv[1] >= 0.0 ? mv[1] : 0.0);
+    const double p2 = p1 + (mv[2] >= 0.0 ? mv[2] : 0.0);
+    const double p3 = p2 + (mv[3] >= 0.0 ? mv[3] : 0.0);
+    const int myk = (mv[0] >= 0.0 && p0 >= random) ? 0                              // :110, first k wins
+                    : (mv[1] >= 0.0 && p1 >= random) ? 1
+                    : (mv[2] >= 0.0 && p2 >= random) ? 2
+                    : (mv[3] >= 0.0 && p3 >= random) ? 3 : -1;
     const int k = __builtin_amdgcn_readlane(myk, hl);
     const uint32_t e0 = readlane_u32(c.nb[0], hl), e1 = readlane_u32(c.nb[1], hl);
     const uint32_t e2 = readlane_u32(c.nb[2], hl), e3 = readlane_u32(c.nb[3], hl);
@@ -519,8 +522,9 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
                 n = rfl(ws.pn[m]);                      // :98
                 {   // the new last edge's increment becomes the pending one again
                     const uint32_t le = rfl(ws.pe[m - 1]);
-                    pend_qs = a.q_start[le];
-                    pend_ts = a.t_start[le];
+                    const uint2 qt = a.qt[le];
+                    pend_qs = qt.x;
+                    pend_ts = qt.y;
                     have_pend = true;
                 }
                 continue;
@@ -550,8 +554,11 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
         // then (pend_*) and is only consumed here, a whole step later, so its latency is never waited for.
         if (have_pend) acc += (int64_t) pend_qs - (int64_t) pend_ts;
         const int64_t len = len0 + acc;
-        pend_qs = a.q_start[eidx];
-        pend_ts = a.t_start[eidx];
+        {
+            const uint2 qt = a.qt[eidx];
+            pend_qs = qt.x;
+            pend_ts = qt.y;
+        }
         have_pend = true;
         m++;
         n = s.nbr;
@@ -721,9 +728,9 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
 
 __device__ __forceinline__ WaveScratch wave_scratch(const WalkArgs &a, uint32_t wave) {
     WaveScratch ws;
-    ws.pn = a.sc_nodes + (size_t) wave * a.cap;
-    ws.pe = a.sc_edges + (size_t) wave * a.cap;
-    ws.lg = a.sc_log + (size_t) wave * a.cap;
+    ws.pn = a.scratch + (size_t) wave * 3u * a.cap;
+    ws.pe = ws.pn + a.cap;
+    ws.lg = ws.pe + a.cap;
     ws.bm = a.bitmaps + (size_t) wave * a.bm_words;
     return ws;
 }
