@@ -344,7 +344,10 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
         const uint32_t o = old_of_new[node];
         const uint32_t r0 = row_ptr[o], deg = row_ptr[o + 1] - r0, w0 = w_start[node];
         const uint32_t pdeg = (deg + 3u) & ~3u;
-        if (lane == 0) w_row[node] = make_uint2(w0, deg | ((uint32_t) node_flags[o] << 24));
+        bool anchor_nbr = false;        // does the list hold an anchor?  (bit 28: the forced-anchor test can be skipped)
+        for (uint32_t j = lane; j < deg; j += 64) anchor_nbr |= (ent_es[r0 + j].x >> 31) != 0;
+        const uint32_t fl = (uint32_t) node_flags[o] | (__ballot(anchor_nbr) ? 16u : 0u);
+        if (lane == 0) w_row[node] = make_uint2(w0, deg | (fl << 24));
         for (uint32_t j = lane; j < pdeg; j += 64) {
             const bool real = j < deg;
             uint2 es = make_uint2(0u, 0u), os = make_uint2(0u, 0u);

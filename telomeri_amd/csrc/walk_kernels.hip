@@ -86,8 +86,9 @@ __device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t n) { return
 // (one bit per node, cleared at walk start): a probe of a neighbour inside it is an LDS read, no global round trip.
 // Ids outside the band use the wave's N-bit map in HBM, exactly as the deterministic kernel does for every id; the
 // split is by id, so the set is exact whatever the numbering looks like.
-constexpr uint32_t WIN_BITS = 1u << 15;                 // 4 KB of LDS per wave
+constexpr uint32_t WIN_BITS = 1u << 14;                 // 2 KB of LDS per wave
 constexpr uint32_t WIN_WORDS = WIN_BITS / 32;
+constexpr uint32_t AFTER_SLOTS = 8;                     // closing sums of the first 8 chunks (2048 entries) of a long list
 struct Visited {
     uint32_t *win;
     uint32_t lo;
@@ -329,15 +330,15 @@ __device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, co
 
 template <bool SQRT>
 __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Visited &vs, uint32_t *mt, int &mti,
-                                                    int lane, uint32_t row, uint32_t deg, uint32_t start,
-                                                    uint32_t &draws) {
+                                                    double *after, int lane, uint32_t row, uint32_t deg, uint32_t start,
+                                                    bool anchor_nbr, uint32_t &draws) {
     Selection s{-1, 0u, false, false, 0u, deg};
     if (deg <= 256u) {
         // the whole list in one chunk: one load, one visited probe, ONE scan (it yields the total and every
         // lane's prefix), no second pass over memory
         const Chunk c = load_chunk(a.ents, row, 0u, deg, lane);
         uint32_t fn = 0;
-        const int fpos = forced_in_chunk(c, 0u, deg, start, lane, fn);
+        const int fpos = anchor_nbr ? forced_in_chunk(c, 0u, deg, start, lane, fn) : -1;
         if (fpos >= 0) {
             s.pick = fpos;
             s.nbr = fn;
@@ -360,12 +361,15 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Vis
         if (hm) resolve_in_lane(s, c, mv, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
         return s;
     }
-    // ---- longer lists, pass 1 (:53-67): total over the unvisited neighbours, chunk after chunk
+    // ---- longer lists, pass 1 (:53-67): total over the unvisited neighbours, chunk after chunk.  The running sum
+    // after each of the first AFTER_SLOTS chunks is parked in LDS: the prefix is non-decreasing, so pass 2 only
+    // has to look into the one chunk where it crosses `random`.
     double total = 0.0;
-    for (uint32_t base = 0; base < deg; base += 256) {
+    uint32_t ci = 0;
+    for (uint32_t base = 0; base < deg; base += 256, ci++) {
         const Chunk c = load_chunk(a.ents, row, base, deg, lane);
         uint32_t fn = 0;
-        const int fpos = forced_in_chunk(c, base, deg, start, lane, fn);
+        const int fpos = anchor_nbr ? forced_in_chunk(c, base, deg, start, lane, fn) : -1;
         if (fpos >= 0) {
             s.pick = (int) base + fpos;
             s.nbr = fn;
@@ -379,13 +383,23 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Vis
             total += readlane_f64(wave_incl_scan_f64(lane_sum), 63);
             s.ncand = 1;
         }
+        if (ci < AFTER_SLOTS && lane == 0) after[ci] = total;
     }
     if (s.ncand == 0) return s;
+    wave_sync();                                                                    // `after` is read by every lane below
     const double random = mt_canonical(mt, mti, lane) * total;                      // :104
     draws++;
     // ---- pass 2 (:107-114): the first candidate whose inclusive prefix reaches `random`
     double carry = 0.0;
-    for (uint32_t base = 0; base < deg; base += 256) {
+    ci = 0;
+    for (uint32_t base = 0; base < deg; base += 256, ci++) {
+        if (ci < AFTER_SLOTS) {
+            const double closing = after[ci];
+            if (closing < random) {          // the hit is further down the list
+                carry = closing;
+                continue;
+            }
+        }
         const Chunk c = load_chunk(a.ents, row, base, deg, lane);
         double mv[4], lane_sum;
         const bool has = lane_candidates<SQRT>(c, vs, base, deg, lane, mv, lane_sum);
@@ -454,7 +468,7 @@ __device__ Selection select_serial(const WalkArgs &a, const Visited &vs, uint32_
 }
 
 template <bool SQRT>
-__device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, int lane,
+__device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after, int lane,
                         uint32_t ui, uint32_t start, uint32_t start_ref, uint32_t r) {
     // `start` and every node id below are walk-order indices; start_ref is the anchor's reference index
     int mti = 624;
@@ -490,8 +504,9 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
         const uint32_t row = rfl(rec.x);
         const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
+        const bool anchor_nbr = ((rfl(rec.y) >> 28) & 1u) != 0;
         // ---- selection scan (:53-115)
-        const Selection s = safe ? select_blocked<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws)
+        const Selection s = safe ? select_blocked<SQRT>(a, vs, mt, mti, after, lane, row, deg, start, anchor_nbr, draws)
                                  : select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws);
         evals += s.evals;
         steps++;
@@ -747,9 +762,10 @@ __device__ __forceinline__ bool next_work(const WalkArgs &a, int lane, uint32_t 
 }
 
 template <bool SQRT>
-__global__ __launch_bounds__(WALK_BLOCK, 4) void walk_mc_kernel(WalkArgs a) {
+__global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
     __shared__ uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
+    __shared__ double after_s[WALK_WAVES_PER_BLOCK][AFTER_SLOTS];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
@@ -758,7 +774,7 @@ __global__ __launch_bounds__(WALK_BLOCK, 4) void walk_mc_kernel(WalkArgs a) {
         const uint64_t unit = a.unit_begin + ui;
         const uint32_t a_rank = (uint32_t) (unit / (uint64_t) a.rebuild_attempts);
         const uint32_t r = (uint32_t) (unit % (uint64_t) a.rebuild_attempts);
-        mc_walk<SQRT>(a, ws, mt_s[wib], win_s[wib], lane, ui, rfl(a.w_anchors[a_rank]), rfl(a.anchors[a_rank]), r);
+        mc_walk<SQRT>(a, ws, mt_s[wib], win_s[wib], after_s[wib], lane, ui, rfl(a.w_anchors[a_rank]), rfl(a.anchors[a_rank]), r);
     }
 }
 
