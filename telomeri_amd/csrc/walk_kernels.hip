@@ -136,22 +136,39 @@ __device__ __forceinline__ double wave_incl_scan_f64(double v) {
     return v;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v, uint64_t identity) {      // lanes without a source read `identity`
+    const int lo = __builtin_amdgcn_update_dpp((int) (uint32_t) identity, (int) (uint32_t) v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int) (uint32_t) (identity >> 32), (int) (uint32_t) (v >> 32), CTRL, ROW_MASK,
+                                               0xf, false);
+    return ((uint64_t) (uint32_t) hi << 32) | (uint64_t) (uint32_t) lo;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    return ((uint64_t) readlane_u32((uint32_t) (v >> 32), l) << 32) | (uint64_t) readlane_u32((uint32_t) v, l);
+}
+
+// maximum / minimum of a 64-bit key over the wave, result wave-uniform (scan shape: lane 63 ends up with it)
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint64_t o = __shfl_xor((unsigned long long) v, d);
-        v = o > v ? o : v;
-    }
-    return v;
+    uint64_t o;
+    o = dpp_u64<0x111, 0xf>(v, 0); v = o > v ? o : v;
+    o = dpp_u64<0x112, 0xf>(v, 0); v = o > v ? o : v;
+    o = dpp_u64<0x114, 0xf>(v, 0); v = o > v ? o : v;
+    o = dpp_u64<0x118, 0xf>(v, 0); v = o > v ? o : v;
+    o = dpp_u64<0x142, 0xa>(v, 0); v = o > v ? o : v;
+    o = dpp_u64<0x143, 0xc>(v, 0); v = o > v ? o : v;
+    return readlane_u64(v, 63);
 }
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint64_t o = __shfl_xor((unsigned long long) v, d);
-        v = o < v ? o : v;
-    }
-    return v;
+    uint64_t o;
+    o = dpp_u64<0x111, 0xf>(v, ~0ull); v = o < v ? o : v;
+    o = dpp_u64<0x112, 0xf>(v, ~0ull); v = o < v ? o : v;
+    o = dpp_u64<0x114, 0xf>(v, ~0ull); v = o < v ? o : v;
+    o = dpp_u64<0x118, 0xf>(v, ~0ull); v = o < v ? o : v;
+    o = dpp_u64<0x142, 0xa>(v, ~0ull); v = o < v ? o : v;
+    o = dpp_u64<0x143, 0xc>(v, ~0ull); v = o < v ? o : v;
+    return readlane_u64(v, 63);
 }
 
 struct WaveScratch {
@@ -606,31 +623,78 @@ __device__ __forceinline__ uint64_t det_key(uint32_t bits, uint32_t i) {
     return ((uint64_t) ord << 32) | (uint64_t) (0xFFFFFFFFu - i);
 }
 
+// visited flags of one lane's 4 entries: LDS band first, HBM map for ids outside it (rare)
+__device__ __forceinline__ void lane_visited(const Chunk &c, const Visited &vs, uint32_t base, uint32_t deg, int lane,
+                                             bool (&vis)[4]) {
+    uint32_t w[4];
+    bool far = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
+        const uint32_t d = (c.nb[k] & 0x7FFFFFFFu) - vs.lo;
+        w[k] = i >= deg ? 1u : d < WIN_BITS ? (vs.win[d >> 5] >> (d & 31u)) & 1u : 2u;
+        far |= w[k] == 2u;
+    }
+    if (__ballot(far)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (w[k] == 2u) w[k] = bm_test(vs.bm, c.nb[k] & 0x7FFFFFFFu) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) vis[k] = w[k] != 0u;
+}
+
 template <bool SQRT>
-__device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uint32_t ui, uint32_t start,
+__device__ __forceinline__ uint64_t det_key_of(const Chunk &c, int k, uint32_t pos) {
+    float mf = __uint_as_float(c.mb[k]);
+    if (SQRT) mf = sqrtf(mf);
+    return det_key(__float_as_uint(mf), pos);
+}
+
+// set / clear a visited flag (lane 0 only)
+__device__ __forceinline__ void visited_set(const Visited &vs, uint32_t n) {
+    const uint32_t d = n - vs.lo;
+    if (d < WIN_BITS) atomicOr(vs.win + (d >> 5), 1u << (d & 31u));
+    else vs.bm[n >> 5] |= 1u << (n & 31);
+}
+
+__device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
+    const uint32_t d = n - vs.lo;
+    if (d < WIN_BITS) atomicAnd(vs.win + (d >> 5), ~(1u << (d & 31u)));
+    else vs.bm[n >> 5] &= ~(1u << (n & 31));
+}
+
+template <bool SQRT>
+__device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, int lane, uint32_t ui, uint32_t start,
                          uint32_t start_ref, uint32_t first_slot) {
+    Visited vs;
+    vs.win = win;
+    vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
+    vs.bm = ws.bm;
+    for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
     const uint32_t first = rfl(a.rows[start].x) + first_slot;
     const uint2 ent0 = a.ents[first];
     const uint32_t second = rfl(ent0.x & 0x7FFFFFFFu);
     const bool second_anchor = rfl(ent0.x >> 31) != 0;
     const int64_t len0 = (int64_t) a.node_len[start_ref];
-    uint32_t m = 1, nlog = 2;
+    uint32_t m = 1, nlog = 0;           // nlog: marks that went to the HBM map
     int64_t acc = edge_delta(a, first);
     uint32_t steps = 0;
     uint64_t evals = 0;
     uint8_t status = ST_ABANDONED;
+    wave_sync();
     if (lane == 0) {
         ws.pn[0] = start;                                   // :216
         ws.pe[0] = first;                                   // :217
         ws.pn[1] = second;                                  // :222
-        ws.bm[start >> 5] |= 1u << (start & 31);            // :215
-        ws.lg[0] = start;
+        visited_set(vs, start);                             // :215
     }
     wave_sync();
     if (lane == 0) {
-        ws.bm[second >> 5] |= 1u << (second & 31);          // :221
-        ws.lg[1] = second;
+        visited_set(vs, second);                            // :221
+        if (second - vs.lo >= WIN_BITS) ws.lg[0] = second;
     }
+    if (second - vs.lo >= WIN_BITS) nlog = 1;               // start lies inside the band by construction
     wave_sync();
     bool all_ok = false;
     if (second_anchor) {
@@ -646,20 +710,25 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
             const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
             bool go_back = false;
             uint32_t chosen = 0;
+            // the first 256 entries stay in registers through all three passes; longer lists re-read the rest
+            const Chunk c0 = load_chunk(a.ents, row, 0u, deg, lane);
             if (deg == 0 || skip_n_best >= deg - 1) {       // :245, :267
                 go_back = true;
             } else {
                 evals += deg;
                 steps++;
+                // rank 0 = maximum key, rank deg-1 = minimum key (:289-296)
                 uint64_t kmax = 0, kmin = ~0ull;
-                for (uint32_t base = 0; base < deg; base += 64) {
-                    const uint32_t i = base + lane;
-                    if (i < deg) {
-                        float mf = __uint_as_float(a.ents[row + i].y);
-                        if (SQRT) mf = sqrtf(mf);
-                        const uint64_t k = det_key(__float_as_uint(mf), i);
-                        kmax = k > kmax ? k : kmax;
-                        kmin = k < kmin ? k : kmin;
+                for (uint32_t base = 0; base < deg; base += 256) {
+                    const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
+                        if (pos < deg) {
+                            const uint64_t key = det_key_of<SQRT>(c, k, pos);
+                            kmax = key > kmax ? key : kmax;
+                            kmin = key < kmin ? key : kmin;
+                        }
                     }
                 }
                 kmax = wave_max_u64(kmax);
@@ -667,17 +736,16 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
                 const uint32_t best_i = 0xFFFFFFFFu - (uint32_t) kmax;     // rank 0
                 const uint32_t worst_i = 0xFFFFFFFFu - (uint32_t) kmin;    // rank deg-1: never eligible (:302)
                 uint64_t kc = 0;
-                for (uint32_t base = 0; base < deg; base += 64) {
-                    const uint32_t i = base + lane;
-                    if (i < deg) {
-                        const uint2 ent = a.ents[row + i];
-                        const bool elig = i != worst_i && !(skip_n_best != 0 && i == best_i)
-                                          && !bm_test(ws.bm, ent.x & 0x7FFFFFFFu);           // :308
-                        if (elig) {
-                            float mf = __uint_as_float(ent.y);
-                            if (SQRT) mf = sqrtf(mf);
-                            const uint64_t k = det_key(__float_as_uint(mf), i);
-                            kc = k > kc ? k : kc;
+                for (uint32_t base = 0; base < deg; base += 256) {
+                    const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+                    bool vis[4];
+                    lane_visited(c, vs, base, deg, lane, vis);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
+                        if (pos < deg && pos != worst_i && !(skip_n_best != 0 && pos == best_i) && !vis[k]) {   // :308
+                            const uint64_t key = det_key_of<SQRT>(c, k, pos);
+                            kc = key > kc ? key : kc;
                         }
                     }
                 }
@@ -694,7 +762,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
                 m--;                                        // pop node + edge
                 acc -= edge_delta(a, rfl(ws.pe[m]));
                 node = rfl(ws.pn[m]);
-                if (lane == 0) ws.bm[node >> 5] &= ~(1u << (node & 31));     // :262,284,335
+                if (lane == 0) visited_clear(vs, node);     // :262,284,335
                 wave_sync();
                 continue;
             }
@@ -703,11 +771,20 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
             const bool chosen_anchor = rfl(cent.x >> 31) != 0;
             // :340-347: the FIRST entry in list order with the same (q_index, t_index) is pushed
             uint32_t pushed = chosen;
-            for (uint32_t base = 0; base < deg; base += 64) {
-                const uint32_t i = base + lane;
-                const uint64_t hm = __ballot(i < deg && (a.ents[row + (i < deg ? i : 0)].x & 0x7FFFFFFFu) == chosen_nbr);
-                if (hm) {
-                    pushed = base + (uint32_t) (__ffsll((unsigned long long) hm) - 1);
+            for (uint32_t base = 0; base < deg; base += 256) {
+                const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
+                    const uint64_t hm = __ballot(pos < deg && (c.nb[k] & 0x7FFFFFFFu) == chosen_nbr);
+                    if (hm) {
+                        const uint32_t p = base + 4u * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k;
+                        best = p < best ? p : best;
+                    }
+                }
+                if (best != 0xFFFFFFFFu) {
+                    pushed = best;
                     break;
                 }
             }
@@ -716,13 +793,14 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, int lane, uin
                 break;
             }
             const uint32_t eidx = row + pushed;
+            const bool far_mark = node - vs.lo >= WIN_BITS;
             if (lane == 0) {
                 ws.pe[m] = eidx;
                 ws.pn[m + 1] = chosen_nbr;
-                ws.bm[node >> 5] |= 1u << (node & 31);      // :355 marks the node being left
-                ws.lg[nlog] = node;
+                visited_set(vs, node);                      // :355 marks the node being left
+                if (far_mark) ws.lg[nlog] = node;
             }
-            nlog++;
+            if (far_mark) nlog++;
             acc += edge_delta(a, eidx);
             m++;
             node = chosen_nbr;                              // :356
@@ -780,6 +858,7 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
 
 template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
+    __shared__ uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
@@ -792,7 +871,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
             if (a.det_off[mid] <= unit) lo = mid;
             else hi = mid;
         }
-        det_walk<SQRT>(a, ws, lane, ui, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]), (uint32_t) (unit - a.det_off[lo]));
+        det_walk<SQRT>(a, ws, win_s[wib], lane, ui, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]), (uint32_t) (unit - a.det_off[lo]));
     }
 }
 
