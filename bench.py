@@ -41,6 +41,7 @@ def main() -> None:
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--no-det", action="store_true", help="skip the deterministic builders (diagnostics only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--separate-launches", action="store_true", help="one launch per builder and metric (diagnostics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (reported as cores)")
     args = ap.parse_args()
@@ -90,14 +91,23 @@ def main() -> None:
     d0, d1 = int(det_off[a0]), int(det_off[a1])
 
     def one_step():
+        # the four builders of Main.cpp:237-243; the two metrics of a builder share one persistent launch
         sets, ctrs = [], []
-        for metric in (capi.METRIC_ES, capi.METRIC_OS):
-            ps = g.walk_mc(metric, wp, *mc_range)
-            sets.append(ps); ctrs.append(("mc", ps.counters))
-        if not args.no_det:
+        if args.separate_launches:
             for metric in (capi.METRIC_ES, capi.METRIC_OS):
-                ps = g.walk_det(metric, d0, d1)
-                sets.append(ps); ctrs.append(("det", ps.counters))
+                ps = g.walk_mc(metric, wp, *mc_range)
+                sets.append(ps); ctrs.append(("mc", ps.counters))
+        else:
+            a, b = g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range)
+            sets += [a, b]; ctrs += [("mc", a.counters), ("mc", b.counters)]
+        if not args.no_det:
+            if args.separate_launches:
+                for metric in (capi.METRIC_ES, capi.METRIC_OS):
+                    ps = g.walk_det(metric, d0, d1)
+                    sets.append(ps); ctrs.append(("det", ps.counters))
+            else:
+                a, b = g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
+                sets += [a, b]; ctrs += [("det", a.counters), ("det", b.counters)]
         if world > 1:
             packed = [pathgather.PackedPaths(*ps.to_device_tensors(dev)) for ps in sets]
             gathered = pathgather.allgather_paths(packed)

@@ -186,6 +186,16 @@ int tlm_walk_mc(tlm_ctx *ctx, const tlm_graph *g, int metric, const tlm_walk_par
 int tlm_walk_det(tlm_ctx *ctx, const tlm_graph *g, int metric, uint64_t unit_begin, uint64_t unit_end,
                  tlm_pathset **out, tlm_counters *ctr);
 
+/* The same for TWO metrics of the same units in ONE persistent launch (reference Main.cpp:237-243 runs every builder
+ * under EXTENSION_SCORE and under OVERLAP_SCORE): the two walk sets share the device's work queue, which shortens the
+ * tail of the launch.  out2[0] / ctr2[0] belong to metric_a, out2[1] / ctr2[1] to metric_b; results are identical to two
+ * single-metric calls.  The launch's kernel_ms / kernel_launches are booked on ctr2[0].  Both metrics must be plain or
+ * both *_SQRT. */
+int tlm_walk_mc2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, const tlm_walk_params *p,
+                 uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out2, tlm_counters *ctr2);
+int tlm_walk_det2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, uint64_t unit_begin, uint64_t unit_end,
+                  tlm_pathset **out2, tlm_counters *ctr2);
+
 /* ---- a9: packed Path set -------------------------------------------------------------------- */
 /* path i = nodes[off[i] .. off[i+1]); slots[k] = position, inside nodes[k]'s list, of the edge to
  * nodes[k+1] (0xFFFFFFFF at a path's last node); unit[i] ascending; length[i] = Path::length(). */

@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
     L.tlm_walk_seed.restype = C.c_uint32
     L.tlm_walk_mc.argtypes = [V, V, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, P(V), P(Counters)]
     L.tlm_walk_det.argtypes = [V, V, C.c_int, C.c_uint64, C.c_uint64, P(V), P(Counters)]
+    L.tlm_walk_mc2.argtypes = [V, V, C.c_int, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, P(V), P(Counters)]
+    L.tlm_walk_det2.argtypes = [V, V, C.c_int, C.c_int, C.c_uint64, C.c_uint64, P(V), P(Counters)]
     L.tlm_pathset_sizes.argtypes = [V, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
     L.tlm_pathset_export.argtypes = [V, C.c_int, V, V, V, V, V]
     L.tlm_pathset_unit_stats.argtypes = [V, V]
@@ -275,6 +277,24 @@ class Graph:
         _check(lib().tlm_walk_mc(self.ctx._h, self._h, metric, C.byref(wp), unit_begin, unit_end, C.byref(h),
                                  C.byref(ctr)), "tlm_walk_mc")
         return PathSet(h, ctr, self.ctx)
+
+    def walk_mc2(self, metric_a: int, metric_b: int, wp: WalkParams, unit_begin: int = 0, unit_end: Optional[int] = None):
+        """Both metrics in one persistent launch -> (PathSet_a, PathSet_b); kernel time is booked on the first."""
+        if unit_end is None:
+            unit_end = self.mc_units(wp)
+        h = (C.c_void_p * 2)()
+        ctr = (Counters * 2)()
+        _check(lib().tlm_walk_mc2(self.ctx._h, self._h, metric_a, metric_b, C.byref(wp), unit_begin, unit_end, h, ctr),
+               "tlm_walk_mc2")
+        return PathSet(C.c_void_p(h[0]), ctr[0], self.ctx), PathSet(C.c_void_p(h[1]), ctr[1], self.ctx)
+
+    def walk_det2(self, metric_a: int, metric_b: int, unit_begin: int = 0, unit_end: Optional[int] = None):
+        if unit_end is None:
+            unit_end = self.det_units()
+        h = (C.c_void_p * 2)()
+        ctr = (Counters * 2)()
+        _check(lib().tlm_walk_det2(self.ctx._h, self._h, metric_a, metric_b, unit_begin, unit_end, h, ctr), "tlm_walk_det2")
+        return PathSet(C.c_void_p(h[0]), ctr[0], self.ctx), PathSet(C.c_void_p(h[1]), ctr[1], self.ctx)
 
     def walk_det(self, metric: int, unit_begin: int = 0, unit_end: Optional[int] = None) -> PathSet:
         if unit_end is None:

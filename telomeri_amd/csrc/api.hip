@@ -366,11 +366,17 @@ int ensure_arena(CtxImpl *c, uint64_t need, uint64_t keep) {
     return TLM_OK;
 }
 
-int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tlm_walk_params *p, uint64_t unit_begin,
-              uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr) {
-    TLM_CHECK(ctx && g && out, TLM_EINVAL, "walk: null argument");
+// One launch over `n_slots` (1 or 2) metrics of the same units: work item = slot * n_units + unit.  Two metrics in one
+// persistent launch share the work queue, which halves the share of the tail (walk lengths differ by 2.5x).
+int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const int *metrics, const tlm_walk_params *p,
+              uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr) {
+    TLM_CHECK(ctx && g && out && metrics, TLM_EINVAL, "walk: null argument");
     TLM_CHECK(g->ctx == ctx, TLM_EINVAL, "walk: graph belongs to another context");
-    TLM_CHECK(metric >= 0 && metric <= 3, TLM_EINVAL, "walk: metric %d", metric);
+    TLM_CHECK(n_slots == 1 || n_slots == 2, TLM_EINVAL, "walk: one or two metrics per launch");
+    for (int k = 0; k < n_slots; k++) {
+        TLM_CHECK(metrics[k] >= 0 && metrics[k] <= 3, TLM_EINVAL, "walk: metric %d", metrics[k]);
+        TLM_CHECK((metrics[k] >= 2) == (metrics[0] >= 2), TLM_EINVAL, "walk: sqrt and plain metrics cannot share a launch");
+    }
     TLM_CHECK(!is_mc || (p && p->rebuild_attempts >= 0 && p->backtrack_attempts >= 0), TLM_EINVAL, "walk: bad parameters");
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     TLM_HIP(hipSetDevice(ctx->device));
@@ -380,26 +386,34 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
     if (unit_end > total) unit_end = total;
     if (unit_begin > unit_end) unit_begin = unit_end;
     const uint64_t n_units64 = unit_end - unit_begin;
-    TLM_CHECK(n_units64 < (1ull << 31), TLM_ELIMIT, "walk: %llu units in one call (limit 2^31)", (unsigned long long) n_units64);
+    TLM_CHECK(n_units64 * (uint64_t) n_slots < (1ull << 31), TLM_ELIMIT, "walk: %llu units in one call (limit 2^31)",
+              (unsigned long long) n_units64);
     const uint32_t n_units = (uint32_t) n_units64;
+    const uint32_t n_all = n_units * (uint32_t) n_slots;
 
-    tlm_pathset *ps = new tlm_pathset();
-    ps->ctx = ctx;
-    ps->device = ctx->device;
-    ps->n_units = n_units;
-    struct Guard { tlm_pathset *p; ~Guard() { if (p) tlm_pathset_destroy(p); } } guard{ps};
-    tlm_counters cnt;
-    std::memset(&cnt, 0, sizeof(cnt));
+    tlm_pathset *pss[2] = {nullptr, nullptr};
+    struct Guard {
+        tlm_pathset **p;
+        ~Guard() { if (p) { tlm_pathset_destroy(p[0]); tlm_pathset_destroy(p[1]); } }
+    } guard{pss};
+    for (int k = 0; k < n_slots; k++) {
+        pss[k] = new tlm_pathset();
+        pss[k]->ctx = ctx;
+        pss[k]->device = ctx->device;
+        pss[k]->n_units = n_units;
+    }
+    tlm_counters cnt[2];
+    std::memset(cnt, 0, sizeof(cnt));
 
     UnitBufs u;
-    if (int rc = dmalloc(&u.units, n_units)) return rc;
+    if (int rc = dmalloc(&u.units, n_all)) return rc;
     if (int rc = dmalloc(&u.p_index, n_units)) return rc;
     if (int rc = dmalloc(&u.n_off, n_units)) return rc;
     if (int rc = dmalloc(&u.totals, 2)) return rc;
-    if (int rc = dmalloc(&u.work_list, n_units)) return rc;
-    TLM_HIP(hipMemsetAsync(u.units, 0xFF, (size_t) (n_units ? n_units : 1) * sizeof(UnitOut), s));   // status = not run
+    if (int rc = dmalloc(&u.work_list, n_all)) return rc;
+    TLM_HIP(hipMemsetAsync(u.units, 0xFF, (size_t) (n_all ? n_all : 1) * sizeof(UnitOut), s));   // status = not run
 
-    std::vector<UnitOut> h_units(n_units);
+    std::vector<UnitOut> h_units(n_all);
 
     if (n_units) {
         const uint32_t N = g->n_nodes;
@@ -409,34 +423,39 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         const uint32_t bm_words = (N + 31) / 32 + 1;
         // persistent grid = what is resident at once: blocks/CU from the occupancy query (a block is 4
         // waves), optionally capped by the tuning knob; never more than 8 blocks (32 waves) per CU
-        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, metric >= 2), 8);
+        const bool sq = metrics[0] >= 2;
+        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq), 8);
         if (ctx->waves_per_cu) bpc = std::max(1, std::min(bpc, ctx->waves_per_cu / WALK_WAVES_PER_BLOCK));
         uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) bpc * WALK_WAVES_PER_BLOCK;
-        waves = std::min<uint32_t>(waves, ((n_units + 3) / 4) * 4);
+        waves = std::min<uint32_t>(waves, ((n_all + 3) / 4) * 4);
         waves = std::max<uint32_t>(4u, (waves / 4) * 4);
-        cnt.waves = waves;
+        cnt[0].waves = waves;
         if (int rc = ensure_scratch(c, waves, cap, bm_words)) return rc;
         // arena for the accepted paths: the worst case (every unit accepted at full buffer length) when
         // that fits 8 GiB, else a guess that the overflow re-run below corrects
         {
-            const uint64_t worst = (uint64_t) n_units * cap;
+            const uint64_t worst = (uint64_t) n_all * cap;
             const uint64_t budget = (8ull << 30) / 8;
-            const uint64_t want = worst <= budget ? worst : std::max<uint64_t>(budget, (uint64_t) n_units * 256u);
+            const uint64_t want = worst <= budget ? worst : std::max<uint64_t>(budget, (uint64_t) n_all * 256u);
             if (int rc = ensure_arena(c, std::max<uint64_t>(1u << 20, want), 0)) return rc;
         }
         unsigned long long *ar_cursor = (unsigned long long *) (c->ws.cursor + 2);
-        (void) ar_cursor;
         TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 16, s));
 
+        auto ents_of = [&](int m) { return (m == TLM_METRIC_ES || m == TLM_METRIC_ES_SQRT) ? g->w_ent_es : g->w_ent_os; };
         WalkArgs a;
         std::memset(&a, 0, sizeof(a));
         a.rows = g->w_row;
-        a.ents = (metric == TLM_METRIC_ES || metric == TLM_METRIC_ES_SQRT) ? g->w_ent_es : g->w_ent_os;
+        a.ents = ents_of(metrics[0]);
+        a.flag_bit = 1u << metrics[0];
+        a.metric = metrics[0];
+        a.ents1 = ents_of(metrics[n_slots - 1]);
+        a.flag_bit1 = 1u << metrics[n_slots - 1];
+        a.metric1 = metrics[n_slots - 1];
+        a.n_units = n_units;
         a.qt = g->w_qt;
         a.node_len = g->node_len;
         a.n_nodes = N;
-        a.flag_bit = 1u << metric;
-        a.metric = metric;
         a.anchors = g->anchors;
         a.w_anchors = g->w_anchors;
         a.old_of_new = g->w_old_of_new;
@@ -448,10 +467,9 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
         a.len_threshold = is_mc ? p->len_threshold : 0;
         a.cursor = c->ws.cursor;
         a.units = u.units;
-        const bool sq = metric >= 2;
 
         std::vector<uint32_t> work;     // empty = identity
-        uint32_t n_work = n_units;
+        uint32_t n_work = n_all;
         uint32_t cur_cap = cap, cur_waves = waves;
         for (int round = 0; round < 64; round++) {
             a.n_work = n_work;
@@ -470,16 +488,16 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
             else tlm_launch_walk_det(s, launch_waves / 4, sq, a);
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ctx->ev1, s));
-            TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_units * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipEventSynchronize(ctx->ev1));
             TLM_HIP(hipStreamSynchronize(s));
             float ms = 0;
             TLM_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            cnt.kernel_ms += ms;
-            cnt.kernel_launches++;
+            cnt[0].kernel_ms += ms;          // the launch is shared by the slots: it is booked on the first one
+            cnt[0].kernel_launches++;
             // overflow handling: re-run the affected units with a full-size path buffer / a larger arena
             std::vector<uint32_t> sc_ovf, ar_ovf;
-            for (uint32_t i = 0; i < n_units; i++) {
+            for (uint32_t i = 0; i < n_all; i++) {
                 const uint32_t st = h_units[i].status;
                 if (st == ST_SCRATCH_OVF) sc_ovf.push_back(i);
                 else if (st == ST_ARENA_OVF) ar_ovf.push_back(i);
@@ -512,53 +530,55 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
             TLM_HIP(hipMemcpyAsync(u.work_list, work.data(), (size_t) n_work * 4, hipMemcpyHostToDevice, s));
             TLM_HIP(hipStreamSynchronize(s));
         }
-
-        // pack accepted paths in unit order
-        hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, s, n_units, u.units, u.p_index, u.n_off, u.totals);
-        uint64_t h_tot[2] = {0, 0};
-        TLM_HIP(hipMemcpyAsync(h_tot, u.totals, 16, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipStreamSynchronize(s));
-        ps->n_paths = h_tot[0];
-        ps->n_nodes_total = h_tot[1];
     }
-    if (int rc = dmalloc(&ps->unit, ps->n_paths)) return rc;
-    if (int rc = dmalloc(&ps->length, ps->n_paths)) return rc;
-    if (int rc = dmalloc(&ps->off, ps->n_paths + 1)) return rc;
-    if (int rc = dmalloc(&ps->nodes, ps->n_nodes_total)) return rc;
-    if (int rc = dmalloc(&ps->slots, ps->n_nodes_total)) return rc;
-    if (n_units) {
-        uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
-        hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, u.units,
-                           u.p_index, u.n_off, c->ws.arena, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
-        TLM_HIP(hipGetLastError());
-    }
-    TLM_HIP(hipMemcpyAsync(ps->off + ps->n_paths, &ps->n_nodes_total, 8, hipMemcpyHostToDevice, s));
 
-    // per-unit outcomes to the host (the last launch's copy of `units` is current: re-runs only rewrite their units)
-    ps->stats.resize(n_units);
-    if (n_units) {
-        TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_units * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipStreamSynchronize(s));
+    // per slot: pack the accepted paths in unit order, collect the per-unit records
+    for (int k = 0; k < n_slots; k++) {
+        tlm_pathset *ps = pss[k];
+        const UnitOut *du = u.units + (size_t) k * n_units;
+        if (n_units) {
+            hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, s, n_units, du, u.p_index, u.n_off, u.totals);
+            uint64_t h_tot[2] = {0, 0};
+            TLM_HIP(hipMemcpyAsync(h_tot, u.totals, 16, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipStreamSynchronize(s));
+            ps->n_paths = h_tot[0];
+            ps->n_nodes_total = h_tot[1];
+        }
+        if (int rc = dmalloc(&ps->unit, ps->n_paths)) return rc;
+        if (int rc = dmalloc(&ps->length, ps->n_paths)) return rc;
+        if (int rc = dmalloc(&ps->off, ps->n_paths + 1)) return rc;
+        if (int rc = dmalloc(&ps->nodes, ps->n_nodes_total)) return rc;
+        if (int rc = dmalloc(&ps->slots, ps->n_nodes_total)) return rc;
+        if (n_units) {
+            uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
+            hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, du,
+                               u.p_index, u.n_off, c->ws.arena, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
+            TLM_HIP(hipGetLastError());
+        }
+        TLM_HIP(hipMemcpyAsync(ps->off + ps->n_paths, &ps->n_nodes_total, 8, hipMemcpyHostToDevice, s));
+        TLM_HIP(hipStreamSynchronize(s));      // p_index / n_off are reused by the next slot
+        ps->stats.resize(n_units);
         for (uint32_t i = 0; i < n_units; i++) {
             tlm_unit_stat &st = ps->stats[i];
-            const UnitOut &o = h_units[i];
+            const UnitOut &o = h_units[(size_t) k * n_units + i];
             st.status = (uint8_t) o.status;
             st.n_nodes = o.nnodes;
             st.steps = o.steps;
             st.evals = o.evals;
             st.draws = o.draws;
             st.length = o.len;
-            cnt.steps += o.steps;
-            cnt.evals += o.evals;
-            cnt.draws += o.draws;
+            cnt[k].steps += o.steps;
+            cnt[k].evals += o.evals;
+            cnt[k].draws += o.draws;
         }
+        cnt[k].units = n_units;
+        cnt[k].accepted = ps->n_paths;
     }
-    TLM_HIP(hipStreamSynchronize(s));
-    cnt.units = n_units;
-    cnt.accepted = ps->n_paths;
-    if (ctr) *ctr = cnt;
+    for (int k = 0; k < n_slots; k++) {
+        if (ctr) ctr[k] = cnt[k];
+        out[k] = pss[k];
+    }
     guard.p = nullptr;
-    *out = ps;
     return TLM_OK;
 }
 
@@ -567,12 +587,25 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int metric, const tl
 extern "C" int tlm_walk_mc(tlm_ctx *ctx, const tlm_graph *g, int metric, const tlm_walk_params *p, uint64_t unit_begin,
                            uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr) {
     TLM_CHECK(p, TLM_EINVAL, "tlm_walk_mc: null parameters");
-    return run_walks(ctx, g, true, metric, p, unit_begin, unit_end, out, ctr);
+    return run_walks(ctx, g, true, 1, &metric, p, unit_begin, unit_end, out, ctr);
 }
 
 extern "C" int tlm_walk_det(tlm_ctx *ctx, const tlm_graph *g, int metric, uint64_t unit_begin, uint64_t unit_end,
                             tlm_pathset **out, tlm_counters *ctr) {
-    return run_walks(ctx, g, false, metric, nullptr, unit_begin, unit_end, out, ctr);
+    return run_walks(ctx, g, false, 1, &metric, nullptr, unit_begin, unit_end, out, ctr);
+}
+
+extern "C" int tlm_walk_mc2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, const tlm_walk_params *p,
+                            uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out2, tlm_counters *ctr2) {
+    TLM_CHECK(p, TLM_EINVAL, "tlm_walk_mc2: null parameters");
+    const int m[2] = {metric_a, metric_b};
+    return run_walks(ctx, g, true, 2, m, p, unit_begin, unit_end, out2, ctr2);
+}
+
+extern "C" int tlm_walk_det2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, uint64_t unit_begin,
+                             uint64_t unit_end, tlm_pathset **out2, tlm_counters *ctr2) {
+    const int m[2] = {metric_a, metric_b};
+    return run_walks(ctx, g, false, 2, m, nullptr, unit_begin, unit_end, out2, ctr2);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,6 +36,11 @@ struct WalkArgs {
     uint32_t n_nodes;
     uint32_t flag_bit;              // 1 << metric
     int32_t metric;
+    // a launch may carry the same units under a second metric ("slot" 1): work item w = slot * n_units + unit
+    const uint2 *ents1;
+    uint32_t flag_bit1;
+    int32_t metric1;
+    uint32_t n_units;               // units per slot
     // units
     const uint32_t *anchors;        // reference node index of each anchor (seeds, first node's length)
     const uint32_t *w_anchors;      // walk-order index of each anchor

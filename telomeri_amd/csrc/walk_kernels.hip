@@ -839,6 +839,19 @@ __device__ __forceinline__ bool next_work(const WalkArgs &a, int lane, uint32_t 
     return true;
 }
 
+// work item -> (metric slot, unit); returns the arguments specialised for the slot
+__device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, uint32_t &ui) {
+    WalkArgs b = a;
+    const uint32_t slot = cu >= a.n_units ? 1u : 0u;      // at most two slots
+    ui = cu - slot * a.n_units;
+    if (slot) {
+        b.ents = a.ents1;
+        b.flag_bit = a.flag_bit1;
+        b.metric = a.metric1;
+    }
+    return b;
+}
+
 template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
@@ -847,12 +860,15 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
-    uint32_t ui;
-    while (next_work(a, lane, ui)) {
+    uint32_t cu;
+    while (next_work(a, lane, cu)) {
+        uint32_t ui;
+        const WalkArgs b = slot_args(a, cu, ui);
         const uint64_t unit = a.unit_begin + ui;
         const uint32_t a_rank = (uint32_t) (unit / (uint64_t) a.rebuild_attempts);
         const uint32_t r = (uint32_t) (unit % (uint64_t) a.rebuild_attempts);
-        mc_walk<SQRT>(a, ws, mt_s[wib], win_s[wib], after_s[wib], lane, ui, rfl(a.w_anchors[a_rank]), rfl(a.anchors[a_rank]), r);
+        mc_walk<SQRT>(b, ws, mt_s[wib], win_s[wib], after_s[wib], lane, cu, rfl(a.w_anchors[a_rank]),
+                      rfl(a.anchors[a_rank]), r);
     }
 }
 
@@ -862,8 +878,10 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
-    uint32_t ui;
-    while (next_work(a, lane, ui)) {
+    uint32_t cu;
+    while (next_work(a, lane, cu)) {
+        uint32_t ui;
+        const WalkArgs b = slot_args(a, cu, ui);
         const uint64_t unit = a.unit_begin + ui;
         uint32_t lo = 0, hi = a.n_anchors;          // largest k with det_off[k] <= unit
         while (hi - lo > 1) {
@@ -871,7 +889,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
             if (a.det_off[mid] <= unit) lo = mid;
             else hi = mid;
         }
-        det_walk<SQRT>(a, ws, win_s[wib], lane, ui, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]), (uint32_t) (unit - a.det_off[lo]));
+        det_walk<SQRT>(b, ws, win_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
+                       (uint32_t) (unit - a.det_off[lo]));
     }
 }
 

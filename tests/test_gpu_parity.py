@@ -189,6 +189,30 @@ def test_walk_unit_ranges_concatenate(ctx):
     np.testing.assert_array_equal(np.concatenate([d1.to_host().nodes, d2.to_host().nodes]), dw.nodes)
 
 
+def test_two_metric_launch_equals_two_launches(ctx):
+    """tlm_walk_mc2 / tlm_walk_det2: both metrics in one persistent launch, same results as separate launches."""
+    ds = synth.make_config("toy")
+    fp = capi.FilterParams.default()
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    wp = capi.WalkParams.default(rb_att=30)
+    for (ma, mb) in ((capi.METRIC_ES, capi.METRIC_OS), (capi.METRIC_OS_SQRT, capi.METRIC_ES_SQRT)):
+        a, b = dg.walk_mc2(ma, mb, wp, 7, 83)
+        for ps, m in ((a, ma), (b, mb)):
+            ops, octr, ostats = og.walk_mc(m, H.to_oracle_wp(wp), po.SEED_PER_WALK, 7, 83)
+            H.assert_stats_equal(ps.unit_stats(), ostats)
+            H.assert_paths_equal(ps.to_host(), ops)
+            assert (ps.counters.evals, ps.counters.accepted) == (octr.evals, octr.accepted)
+        assert a.counters.kernel_launches >= 1 and b.counters.kernel_launches == 0
+        da, db = dg.walk_det2(ma, mb)
+        for ps, m in ((da, ma), (db, mb)):
+            ops, octr, ostats = og.walk_det(m)
+            H.assert_stats_equal(ps.unit_stats(), ostats)
+            H.assert_paths_equal(ps.to_host(), ops)
+    with pytest.raises(capi.TlmError):
+        dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS_SQRT, wp)
+
+
 def test_walk_overflow_reruns(ctx):
     """A tiny path buffer forces the scratch-overflow re-run; results must not change."""
     ds = synth.make_config("tiny")
