@@ -42,6 +42,8 @@ def main() -> None:
     ap.add_argument("--no-det", action="store_true", help="skip the deterministic builders (diagnostics only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--separate-launches", action="store_true", help="one launch per builder and metric (diagnostics)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo only to rehearse N>1 on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (reported as cores)")
     args = ap.parse_args()
@@ -53,13 +55,16 @@ def main() -> None:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     t0 = time.time()
     ctx = capi.Context(local_rank)
@@ -191,6 +196,29 @@ def main() -> None:
                     "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
         "paths_per_step": paths_total,
     }
+
+    # SURVEY.md §8f row 1, outside the timed region: paths_ = concat of the four sets, filterUnique,
+    # getPathsBetweenAnchors on the device
+    try:
+        sets = list(g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range))
+        if not args.no_det:
+            sets += list(g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1))
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        allp = capi.PathSet.concat(sets)
+        t1 = time.time()
+        uniq = allp.filter_unique()
+        t2 = time.time()
+        pairs = uniq.anchor_pairs()
+        t3 = time.time()
+        nbytes = 8.0 * allp.n_nodes_total          # nodes + slots of every path, read once
+        out["post_passes"] = {"paths_in": allp.n_paths, "paths_unique": uniq.n_paths, "anchor_pairs": len(pairs),
+                              "path_nodes": allp.n_nodes_total, "concat_ms": 1e3 * (t1 - t0),
+                              "filter_unique_ms": 1e3 * (t2 - t1), "anchor_pairs_ms": 1e3 * (t3 - t2),
+                              "filter_unique_GBps": 2 * nbytes / max(t2 - t1, 1e-9) / 1e9}
+        del sets, allp, uniq
+    except Exception as e:      # reported, never fatal for the metric line
+        out["post_passes"] = {"error": str(e)}
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, g, wp, g.download(cold=False), mc_range, capi)

@@ -208,6 +208,18 @@ int tlm_pathset_export(const tlm_pathset *ps, int dst_is_device, uint64_t *unit,
 int tlm_pathset_unit_stats(const tlm_pathset *ps, tlm_unit_stat *stats_host);
 void tlm_pathset_destroy(tlm_pathset *ps);
 
+/* ---- post-passes on Path sets, on the device -------------------------------- */
+/* paths_ after several builder calls on one PathManager (Main.cpp:237-243): the sets in call order; unit[i] gets the
+ * position k of its set in the top byte (k << 56).  n_units of the result is 0. */
+int tlm_pathset_concat(tlm_ctx *ctx, int n, tlm_pathset *const *sets, tlm_pathset **out);
+/* PathManager::filterUnique (PathManager.cpp:432-438): std::unique with Path::operator== (Path.cpp:46-49: same
+ * node sequence) -- only ADJACENT duplicates go, the first of a run stays. */
+int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tlm_pathset **out);
+/* PathManager::getPathsBetweenAnchors (PathManager.cpp:626-645): HOST buffers of n_paths entries each;
+ * order[j] = path index, key[j] = (front node << 32) | back node, sorted by key (the std::map's order over
+ * (front Node*, back Node*)), inside one key in path order.  A bucket is a run of equal keys. */
+int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *order_host, uint64_t *key_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -294,6 +294,48 @@ def mt19937_canonical(seed: int, n: int) -> np.ndarray:
 # ---------------------------------------------------------------------------------------------
 # ref_dump text format (oracle/ref_dump.cpp)
 
+def concat_paths(sets) -> PathSet:
+    """paths_ after several builder calls on one PathManager (reference Main.cpp:237-243): plain concatenation.
+    `unit` keeps the builder position in its top byte."""
+    unit = np.concatenate([s.unit.astype(np.uint64) | (np.uint64(k) << np.uint64(56)) for k, s in enumerate(sets)])
+    length = np.concatenate([s.length for s in sets])
+    counts = np.concatenate([np.diff(s.off.astype(np.int64)) for s in sets])
+    off = np.zeros(counts.shape[0] + 1, np.uint64)
+    off[1:] = np.cumsum(counts)
+    return PathSet(unit, length, off, np.concatenate([s.nodes for s in sets]), np.concatenate([s.slots for s in sets]))
+
+
+def filter_unique(ps: PathSet) -> PathSet:
+    """PathManager::filterUnique (reference PathManager.cpp:432-438): std::unique with Path::operator==
+    (Path.cpp:46-49: same node sequence; edges and length are not compared) -- ADJACENT duplicates only."""
+    keep = []
+    last = None
+    for i in range(len(ps)):
+        a, b = int(ps.off[i]), int(ps.off[i + 1])
+        seq = ps.nodes[a:b]
+        if last is not None and seq.shape == last.shape and np.array_equal(seq, last):
+            continue
+        keep.append(i)
+        last = seq
+    keep = np.array(keep, dtype=np.int64)
+    counts = np.diff(ps.off.astype(np.int64))[keep] if len(keep) else np.zeros(0, np.int64)
+    off = np.zeros(len(keep) + 1, np.uint64)
+    off[1:] = np.cumsum(counts)
+    idx = np.concatenate([np.arange(int(ps.off[i]), int(ps.off[i + 1])) for i in keep]) if len(keep) else np.zeros(0, np.int64)
+    return PathSet(ps.unit[keep], ps.length[keep], off, ps.nodes[idx], ps.slots[idx])
+
+
+def paths_between_anchors(ps: PathSet):
+    """PathManager::getPathsBetweenAnchors (reference PathManager.cpp:626-645): std::map keyed by (front Node*,
+    back Node*) -- iteration order = (front index, back index) -- each bucket in paths_ order.
+    -> list of (front, back, [path indices])."""
+    buckets = {}
+    for i in range(len(ps)):
+        key = (int(ps.nodes[int(ps.off[i])]), int(ps.nodes[int(ps.off[i + 1]) - 1]))
+        buckets.setdefault(key, []).append(i)
+    return [(k[0], k[1], v) for k, v in sorted(buckets.items())]
+
+
 @dataclasses.dataclass
 class RefDump:
     node_anchor: np.ndarray
@@ -302,6 +344,8 @@ class RefDump:
     node_name: List[str]
     adj: Optional[np.ndarray]          # [A, 11] int64: owner slot nbr qs qe ts te os_bits si_bits es_bits strand
     builders: Dict[int, List[Tuple[int, np.ndarray, np.ndarray]]]   # id -> [(length, nodes, slots)]
+    unique: Optional[List[Tuple[int, np.ndarray, np.ndarray]]] = None   # paths_ after the 4 builders + filterUnique
+    pairs: Optional[List[Tuple[int, int, List[int]]]] = None            # getPathsBetweenAnchors over `unique`
 
 
 def parse_ref_dump(path: str) -> RefDump:
@@ -311,6 +355,8 @@ def parse_ref_dump(path: str) -> RefDump:
     names: List[str] = []
     adj: List[List[int]] = []
     builders: Dict[int, List[Tuple[int, np.ndarray, np.ndarray]]] = {}
+    unique = None
+    pairs = None
     cur: Optional[List] = None
     with open(path) as fh:
         head = fh.readline().split()
@@ -326,12 +372,20 @@ def parse_ref_dump(path: str) -> RefDump:
                 f = line.split()
                 cur = []
                 builders[int(f[1])] = cur
+            elif tag == "U":
+                cur = []
+                unique = cur
+            elif tag == "K":
+                pairs = []
+            elif tag == "k":
+                f = [int(x) for x in line.split()[1:]]
+                pairs.append((f[0], f[1], f[3:3 + f[2]]))
             elif tag == "p":
                 v = np.array(line.split()[1:], dtype=np.int64)
                 n = int(v[1])
                 cur.append((int(v[0]), v[2:2 + n].astype(np.uint32), v[2 + n:2 + n + n - 1].astype(np.uint32)))
     return RefDump(np.array(anchors, np.uint8), np.array(lens, np.uint32), np.array(degs, np.int64), names,
-                   np.array(adj, dtype=np.int64) if adj else None, builders)
+                   np.array(adj, dtype=np.int64) if adj else None, builders, unique, pairs)
 
 
 def run_ref_dump(rr: str, cr: str, out: str, args: Optional[List[str]] = None) -> RefDump:

@@ -21,6 +21,10 @@
 //   B <builder id> <accepted paths>          builder id: 0 MC/ES 1 MC/OS 2 DET/ES 3 DET/OS
 //                                            (+4: the *_SQRT metric of the same builder)
 //   p <length> <n_nodes> <node ids...> <edge slots...>
+//   U <paths>                                paths_ of ONE PathManager after the four default builders (Main.cpp:237-243)
+//                                            and filterUnique (Main.cpp:247), in paths_ order; followed by `p` lines
+//   K <pairs>                                getPathsBetweenAnchors (Main.cpp:251-252) in map order
+//   k <front node> <back node> <count> <indices into the U list...>
 #include <OverlapGraph.hpp>
 #include <PathManager.hpp>
 #include <Utils.hpp>
@@ -131,6 +135,35 @@ int main(int argc, char **argv) {
             if (b.mc) pm.buildMonteCarlo(g, b.m);
             else pm.buildDeterministic(g, b.m);
             dump_builder(out, g, pm, b.id);
+        }
+    }
+    if (want_paths) {
+        // the pipeline of Main.cpp:230-252 on one PathManager
+        PathManager pm;
+        pm.params_ = pp;
+        pm.buildMonteCarlo(g, Utils::Metrics::EXTENSION_SCORE);
+        pm.buildMonteCarlo(g, Utils::Metrics::OVERLAP_SCORE);
+        pm.buildDeterministic(g, Utils::Metrics::EXTENSION_SCORE);
+        pm.buildDeterministic(g, Utils::Metrics::OVERLAP_SCORE);
+        pm.filterUnique();
+        auto pba = pm.getPathsBetweenAnchors();
+        std::vector<const Path *> all;
+        for (auto &kv : pba)
+            for (const Path *p : kv.second) all.push_back(p);
+        std::sort(all.begin(), all.end());
+        std::fprintf(out, "U %zu\n", all.size());
+        for (const Path *p : all) {
+            std::fprintf(out, "p %ld %zu", p->length(), p->nodes_.size());
+            for (const OverlapGraph::Node *n : p->nodes_) std::fprintf(out, " %u", n->index);
+            for (const OverlapGraph::Edge *e : p->edges_) std::fprintf(out, " %ld", (long) (e - g.nodes_[e->t_index].edges.data()));
+            std::fprintf(out, "\n");
+        }
+        std::fprintf(out, "K %zu\n", pba.size());
+        for (auto &kv : pba) {
+            std::fprintf(out, "k %u %u %zu", kv.first.first->index, kv.first.second->index, kv.second.size());
+            for (const Path *p : kv.second)
+                std::fprintf(out, " %ld", (long) (std::lower_bound(all.begin(), all.end(), p) - all.begin()));
+            std::fprintf(out, "\n");
         }
     }
     std::fclose(out);

@@ -116,6 +116,9 @@ def lib() -> C.CDLL:
     L.tlm_pathset_export.argtypes = [V, C.c_int, V, V, V, V, V]
     L.tlm_pathset_unit_stats.argtypes = [V, V]
     L.tlm_pathset_destroy.argtypes = [V]
+    L.tlm_pathset_concat.argtypes = [V, C.c_int, P(V), P(V)]
+    L.tlm_pathset_filter_unique.argtypes = [V, V, P(V)]
+    L.tlm_pathset_anchor_pairs.argtypes = [V, V, V, V]
     _lib = L
     return L
 
@@ -185,6 +188,32 @@ class PathSet:
         _check(lib().tlm_pathset_export(self._h, 1, unit.data_ptr(), length.data_ptr(), off.data_ptr(), nodes.data_ptr(),
                                         slots.data_ptr()), "tlm_pathset_export")
         return unit, length, off, nodes, slots
+
+    def filter_unique(self) -> "PathSet":
+        """PathManager::filterUnique on the device."""
+        h = C.c_void_p()
+        _check(lib().tlm_pathset_filter_unique(self._ctx._h, self._h, C.byref(h)), "tlm_pathset_filter_unique")
+        return PathSet(h, self.counters, self._ctx)
+
+    def anchor_pairs(self):
+        """PathManager::getPathsBetweenAnchors -> [(front node, back node, [path indices])] in the map's order."""
+        order = np.zeros(self.n_paths, np.uint32)
+        key = np.zeros(self.n_paths, np.uint64)
+        _check(lib().tlm_pathset_anchor_pairs(self._ctx._h, self._h, _np_ptr(order), _np_ptr(key)), "tlm_pathset_anchor_pairs")
+        out = []
+        if self.n_paths:
+            cut = np.nonzero(np.diff(key))[0] + 1
+            for seg, k in zip(np.split(order, cut), key[np.concatenate([[0], cut])]):
+                out.append((int(k >> np.uint64(32)), int(k & np.uint64(0xFFFFFFFF)), seg.tolist()))
+        return out
+
+    @staticmethod
+    def concat(sets) -> "PathSet":
+        """paths_ after several builder calls (Main.cpp:237-243)."""
+        arr = (C.c_void_p * len(sets))(*[s._h for s in sets])
+        h = C.c_void_p()
+        _check(lib().tlm_pathset_concat(sets[0]._ctx._h, len(sets), arr, C.byref(h)), "tlm_pathset_concat")
+        return PathSet(h, sets[0].counters, sets[0]._ctx)
 
     def unit_stats(self) -> np.ndarray:
         st = np.zeros(max(self.n_units, 1), UNIT_STAT_DTYPE)

@@ -1,0 +1,242 @@
+// telomeri_amd/csrc/pathset_ops.hip -- post-passes on packed Path sets, on the device.
+//
+//   tlm_pathset_concat        paths_ after several builder calls on one PathManager   reference Main.cpp:237-243
+//   tlm_pathset_filter_unique PathManager::filterUnique                                reference PathManager.cpp:432-438
+//                             (std::unique with Path::operator==, Path.cpp:46-49: node sequence only,
+//                              ADJACENT duplicates only)
+//   tlm_pathset_anchor_pairs  PathManager::getPathsBetweenAnchors                      reference PathManager.cpp:626-645
+//                             (std::map keyed by (front Node*, back Node*): buckets in (front, back) index order,
+//                              inside a bucket in paths_ order)
+// They run where the paths already are: a rank filters and buckets its shard before the one all-gather, and the
+// host receives the Path set already deduplicated.  HBM-bound streaming passes over the packed arrays.
+#include <algorithm>
+#include <cstring>
+
+#include "tlm_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+template <class T> int dmalloc(T **p, size_t n) {
+    TLM_HIP(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
+    return TLM_OK;
+}
+
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() { if (p) (void) hipFree(p); }
+};
+
+int alloc_pathset(tlm_ctx *ctx, uint64_t n_paths, uint64_t n_nodes, tlm_pathset **out) {
+    tlm_pathset *ps = new tlm_pathset();
+    ps->ctx = ctx;
+    ps->device = ctx->device;
+    ps->n_paths = n_paths;
+    ps->n_nodes_total = n_nodes;
+    if (dmalloc(&ps->unit, n_paths) || dmalloc(&ps->length, n_paths) || dmalloc(&ps->off, n_paths + 1)
+        || dmalloc(&ps->nodes, n_nodes) || dmalloc(&ps->slots, n_nodes)) {
+        tlm_pathset_destroy(ps);
+        return TLM_EHIP;
+    }
+    *out = ps;
+    return TLM_OK;
+}
+
+__global__ void rebase_kernel(uint64_t n, const uint64_t *__restrict__ src_unit, const uint64_t *__restrict__ src_off,
+                              uint64_t tag, uint64_t node_base, uint64_t *__restrict__ dst_unit, uint64_t *__restrict__ dst_off) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dst_unit[i] = src_unit[i] | tag;
+        dst_off[i] = src_off[i] + node_base;
+    }
+}
+
+// keep[i] = 0 iff path i has the same node sequence as path i-1 (one wave per path)
+__global__ __launch_bounds__(256) void dup_flags_kernel(uint64_t n_paths, const uint64_t *__restrict__ off,
+                                                        const uint32_t *__restrict__ nodes, uint8_t *__restrict__ keep) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n_paths; i += n_waves) {
+        bool same = false;
+        if (i > 0) {
+            const uint64_t a0 = off[i - 1], a1 = off[i], b1 = off[i + 1];
+            if (a1 - a0 == b1 - a1) {
+                same = true;
+                for (uint64_t k = lane; k < a1 - a0 && same; k += 64)
+                    if (nodes[a0 + k] != nodes[a1 + k]) same = false;
+                same = __ballot(!same) == 0;
+            }
+        }
+        if (lane == 0) keep[i] = same ? 0 : 1;
+    }
+}
+
+// exclusive scan of keep[] and of the kept paths' node counts; one workgroup
+__global__ __launch_bounds__(1024) void scan_keep_kernel(uint64_t n_paths, const uint8_t *__restrict__ keep,
+                                                         const uint64_t *__restrict__ off, uint64_t *__restrict__ p_index,
+                                                         uint64_t *__restrict__ n_off, uint64_t *__restrict__ totals) {
+    __shared__ uint64_t s_cnt[1024];
+    __shared__ uint64_t s_sum[1024];
+    uint64_t carry_cnt = 0, carry_sum = 0;
+    const int t = threadIdx.x;
+    for (uint64_t base = 0; base < n_paths; base += 1024) {
+        const uint64_t i = base + t;
+        const bool k = i < n_paths && keep[i];
+        const uint64_t c = k ? 1 : 0, v = k ? off[i + 1] - off[i] : 0;
+        s_cnt[t] = c;
+        s_sum[t] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint64_t a = 0, b = 0;
+            if (t >= d) { a = s_cnt[t - d]; b = s_sum[t - d]; }
+            __syncthreads();
+            s_cnt[t] += a;
+            s_sum[t] += b;
+            __syncthreads();
+        }
+        if (i < n_paths) {
+            p_index[i] = carry_cnt + s_cnt[t] - c;
+            n_off[i] = carry_sum + s_sum[t] - v;
+        }
+        carry_cnt += s_cnt[1023];
+        carry_sum += s_sum[1023];
+        __syncthreads();
+    }
+    if (t == 0) { totals[0] = carry_cnt; totals[1] = carry_sum; }
+}
+
+__global__ __launch_bounds__(256) void copy_kept_kernel(uint64_t n_paths, const uint8_t *__restrict__ keep,
+                                                        const uint64_t *__restrict__ p_index, const uint64_t *__restrict__ n_off,
+                                                        const uint64_t *__restrict__ unit, const int64_t *__restrict__ length,
+                                                        const uint64_t *__restrict__ off, const uint32_t *__restrict__ nodes,
+                                                        const uint32_t *__restrict__ slots, uint64_t *__restrict__ o_unit,
+                                                        int64_t *__restrict__ o_len, uint64_t *__restrict__ o_off,
+                                                        uint32_t *__restrict__ o_nodes, uint32_t *__restrict__ o_slots) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n_paths; i += n_waves) {
+        if (!keep[i]) continue;
+        const uint64_t pi = p_index[i], src = off[i], n = off[i + 1] - off[i], dst = n_off[i];
+        if (lane == 0) {
+            o_unit[pi] = unit[i];
+            o_len[pi] = length[i];
+            o_off[pi] = dst;
+        }
+        for (uint64_t k = lane; k < n; k += 64) {
+            o_nodes[dst + k] = nodes[src + k];
+            o_slots[dst + k] = slots[src + k];
+        }
+    }
+}
+
+__global__ void pair_key_kernel(uint64_t n_paths, const uint64_t *__restrict__ off, const uint32_t *__restrict__ nodes,
+                                unsigned long long *__restrict__ key, uint32_t *__restrict__ idx) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_paths) {
+        key[i] = ((unsigned long long) nodes[off[i]] << 32) | (unsigned long long) nodes[off[i + 1] - 1];
+        idx[i] = (uint32_t) i;
+    }
+}
+
+unsigned blocks_for(uint64_t n, unsigned per) {
+    uint64_t b = (n + per - 1) / per;
+    return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(b, 256u * 16u));
+}
+
+}  // namespace
+
+extern "C" int tlm_pathset_concat(tlm_ctx *ctx, int n, tlm_pathset *const *sets, tlm_pathset **out) {
+    TLM_CHECK(ctx && sets && out && n >= 1 && n <= 255, TLM_EINVAL, "tlm_pathset_concat: bad argument");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    uint64_t np = 0, nn = 0;
+    for (int k = 0; k < n; k++) {
+        TLM_CHECK(sets[k] && sets[k]->ctx == ctx, TLM_EINVAL, "tlm_pathset_concat: set %d is null or of another context", k);
+        np += sets[k]->n_paths;
+        nn += sets[k]->n_nodes_total;
+    }
+    tlm_pathset *ps = nullptr;
+    if (int rc = alloc_pathset(ctx, np, nn, &ps)) return rc;
+    uint64_t pb = 0, nb = 0;
+    for (int k = 0; k < n; k++) {
+        const tlm_pathset *q = sets[k];
+        if (q->n_paths) {
+            hipLaunchKernelGGL(rebase_kernel, dim3((unsigned) ((q->n_paths + 255) / 256)), dim3(256), 0, s, q->n_paths, q->unit,
+                               q->off, (uint64_t) k << 56, nb, ps->unit + pb, ps->off + pb);
+            TLM_HIP(hipMemcpyAsync(ps->length + pb, q->length, q->n_paths * 8, hipMemcpyDeviceToDevice, s));
+        }
+        if (q->n_nodes_total) {
+            TLM_HIP(hipMemcpyAsync(ps->nodes + nb, q->nodes, q->n_nodes_total * 4, hipMemcpyDeviceToDevice, s));
+            TLM_HIP(hipMemcpyAsync(ps->slots + nb, q->slots, q->n_nodes_total * 4, hipMemcpyDeviceToDevice, s));
+        }
+        pb += q->n_paths;
+        nb += q->n_nodes_total;
+    }
+    TLM_HIP(hipMemcpyAsync(ps->off + np, &nn, 8, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    *out = ps;
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tlm_pathset **out) {
+    TLM_CHECK(ctx && in && out && in->ctx == ctx, TLM_EINVAL, "tlm_pathset_filter_unique: bad argument");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = in->n_paths;
+    Tmp keep, pidx, noff, tot;
+    TLM_HIP(hipMalloc(&keep.p, n ? n : 1));
+    TLM_HIP(hipMalloc(&pidx.p, (n ? n : 1) * 8));
+    TLM_HIP(hipMalloc(&noff.p, (n ? n : 1) * 8));
+    TLM_HIP(hipMalloc(&tot.p, 16));
+    uint64_t h_tot[2] = {0, 0};
+    if (n) {
+        hipLaunchKernelGGL(dup_flags_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, in->off, in->nodes, (uint8_t *) keep.p);
+        hipLaunchKernelGGL(scan_keep_kernel, dim3(1), dim3(1024), 0, s, n, (const uint8_t *) keep.p, in->off, (uint64_t *) pidx.p,
+                           (uint64_t *) noff.p, (uint64_t *) tot.p);
+        TLM_HIP(hipMemcpyAsync(h_tot, tot.p, 16, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+    tlm_pathset *ps = nullptr;
+    if (int rc = alloc_pathset(ctx, h_tot[0], h_tot[1], &ps)) return rc;
+    if (n) {
+        hipLaunchKernelGGL(copy_kept_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, (const uint8_t *) keep.p,
+                           (const uint64_t *) pidx.p, (const uint64_t *) noff.p, in->unit, in->length, in->off, in->nodes,
+                           in->slots, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
+    }
+    TLM_HIP(hipMemcpyAsync(ps->off + ps->n_paths, &ps->n_nodes_total, 8, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    *out = ps;
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *order_host, uint64_t *key_host) {
+    TLM_CHECK(ctx && ps && ps->ctx == ctx, TLM_EINVAL, "tlm_pathset_anchor_pairs: bad argument");
+    TLM_CHECK(ps->n_paths < (1ull << 32), TLM_ELIMIT, "tlm_pathset_anchor_pairs: too many paths");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = ps->n_paths;
+    if (!n) return TLM_OK;
+    Tmp key, idx, key2, idx2, tmp;
+    TLM_HIP(hipMalloc(&key.p, n * 8));
+    TLM_HIP(hipMalloc(&idx.p, n * 4));
+    TLM_HIP(hipMalloc(&key2.p, n * 8));
+    TLM_HIP(hipMalloc(&idx2.p, n * 4));
+    hipLaunchKernelGGL(pair_key_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, ps->off, ps->nodes,
+                       (unsigned long long *) key.p, (uint32_t *) idx.p);
+    size_t tb = 0;
+    TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *) key.p, (unsigned long long *) key2.p, (uint32_t *) idx.p,
+                                      (uint32_t *) idx2.p, (size_t) n, 0, 64, s));
+    TLM_HIP(hipMalloc(&tmp.p, tb ? tb : 16));
+    TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (unsigned long long *) key.p, (unsigned long long *) key2.p, (uint32_t *) idx.p,
+                                      (uint32_t *) idx2.p, (size_t) n, 0, 64, s));      // stable: paths_ order inside a bucket
+    if (order_host) TLM_HIP(hipMemcpyAsync(order_host, idx2.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (key_host) TLM_HIP(hipMemcpyAsync(key_host, key2.p, n * 8, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    return TLM_OK;
+}

@@ -132,12 +132,27 @@ int main(int argc, char **argv) {
             }
         }
     }
-    if (out) std::fclose(out);
     pm.filterUnique();                                                                // Main.cpp:247
+    auto pba = pm.getPathsBetweenAnchors();                                           // Main.cpp:251-252
+    if (out) {
+        std::fprintf(out, "U %zu\n", pm.paths().size());
+        for (const Path &p : pm.paths()) {
+            std::fprintf(out, "p %ld %zu", p.length(), p.nodes_.size());
+            for (const auto *n : p.nodes_) std::fprintf(out, " %u", n->index);
+            for (const auto *e : p.edges_) std::fprintf(out, " %ld", (long) (e - graph.nodes_[e->t_index].edges.data()));
+            std::fprintf(out, "\n");
+        }
+        std::fprintf(out, "K %zu\n", pba.size());
+        for (const auto &kv : pba) {
+            std::fprintf(out, "k %u %u %zu", kv.first.first->index, kv.first.second->index, kv.second.size());
+            for (const Path *p : kv.second) std::fprintf(out, " %ld", (long) (p - pm.paths().data()));
+            std::fprintf(out, "\n");
+        }
+        std::fclose(out);
+    }
     std::cout << "Done (" << lap() << "s)" << std::endl << pm.stats() << std::endl;
     std::cout << "edge-extension evals: " << evals << " in " << kernel_ms << " ms of walk kernels ("
               << (kernel_ms > 0 ? evals / (kernel_ms * 1e-3) : 0.0) << " evals/s)" << std::endl;
-    auto pba = pm.getPathsBetweenAnchors();                                           // Main.cpp:251-252
     std::cout << "Anchor pairs with paths: " << pba.size() << std::endl;
     std::cout << "Grouping, consensus and scaffold output are not part of this build (DESIGN.md §8); "
               << pos[4] << " not written." << std::endl;

@@ -51,17 +51,30 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
         std::cerr << "telomeri_hip: walk failed: " << tlm_last_error() << std::endl;
         std::exit(1);
     }
-    uint64_t n_paths = 0, n_nodes = 0, n_units = 0;
-    tlm_pathset_sizes(ps, &n_paths, &n_nodes, &n_units);
-    std::vector<uint64_t> unit(n_paths), off(n_paths + 1);
+    graph_ = &g;
+    uint64_t n_paths = 0;
+    tlm_pathset_sizes(ps, &n_paths, nullptr, nullptr);
+    append_from(g, ps);
+    dev_sets_.push_back(ps);             // stays on the device for filterUnique / getPathsBetweenAnchors
+    last_counters = Counters{c.units, c.steps, c.evals, c.draws, c.accepted, c.kernel_ms};
+    std::cout << "Found " << n_paths << " paths." << std::endl;      // PathManager.cpp:172,387
+}
+
+PathManager::~PathManager() {
+    for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
+}
+
+void PathManager::append_from(const OverlapGraph &g, tlm_pathset *ps) {
+    uint64_t n_paths = 0, n_nodes = 0;
+    tlm_pathset_sizes(ps, &n_paths, &n_nodes, nullptr);
+    std::vector<uint64_t> off(n_paths + 1);
     std::vector<int64_t> length(n_paths);
     std::vector<uint32_t> nodes(n_nodes), slots(n_nodes);
-    if (tlm_pathset_export(ps, 0, unit.data(), length.data(), off.data(), nodes.data(), slots.data()) != TLM_OK) {
+    if (tlm_pathset_export(ps, 0, nullptr, length.data(), off.data(), nodes.data(), slots.data()) != TLM_OK) {
         std::cerr << "telomeri_hip: export failed: " << tlm_last_error() << std::endl;
         std::exit(1);
     }
-    tlm_pathset_destroy(ps);
-    // materialise Path objects in unit order = the reference's append order (PathManager.cpp:154,226,382)
+    // Path objects in set order = the reference's append order (PathManager.cpp:154,226,382)
     paths_.reserve(paths_.size() + n_paths);
     for (uint64_t i = 0; i < n_paths; i++) {
         Path p;
@@ -76,8 +89,20 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
         p.setLength((long) length[i]);
         paths_.push_back(std::move(p));
     }
-    last_counters = Counters{c.units, c.steps, c.evals, c.draws, c.accepted, c.kernel_ms};
-    std::cout << "Found " << n_paths << " paths." << std::endl;      // PathManager.cpp:172,387
+}
+
+tlm_pathset *PathManager::single_set() {
+    if (dev_sets_.empty()) return nullptr;
+    if (dev_sets_.size() > 1) {
+        tlm_pathset *all = nullptr;
+        if (tlm_pathset_concat(OverlapGraph::context(), (int) dev_sets_.size(), dev_sets_.data(), &all) != TLM_OK) {
+            std::cerr << "telomeri_hip: concat failed: " << tlm_last_error() << std::endl;
+            std::exit(1);
+        }
+        for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
+        dev_sets_.assign(1, all);
+    }
+    return dev_sets_[0];
 }
 
 void PathManager::buildMonteCarlo(const OverlapGraph &g, const Utils::Metrics &metric) {
@@ -90,8 +115,18 @@ void PathManager::buildDeterministic(const OverlapGraph &g, const Utils::Metrics
     build(g, metric, false);
 }
 
-void PathManager::filterUnique() {      // PathManager.cpp:432-438: ADJACENT duplicates only
-    paths_.erase(std::unique(paths_.begin(), paths_.end()), paths_.end());
+void PathManager::filterUnique() {      // PathManager.cpp:432-438: ADJACENT duplicates only; on the device
+    tlm_pathset *all = single_set();
+    if (!all) return;
+    tlm_pathset *uniq = nullptr;
+    if (tlm_pathset_filter_unique(OverlapGraph::context(), all, &uniq) != TLM_OK) {
+        std::cerr << "telomeri_hip: filterUnique failed: " << tlm_last_error() << std::endl;
+        std::exit(1);
+    }
+    tlm_pathset_destroy(all);
+    dev_sets_.assign(1, uniq);
+    paths_.clear();
+    append_from(*graph_, uniq);
 }
 
 std::tuple<ulong, ulong, ulong> PathManager::getMinMaxSumPathLength() {
@@ -120,8 +155,19 @@ std::string PathManager::stats() {      // the report of PathManager.cpp:440-465
 }
 
 std::map<std::pair<const OverlapGraph::Node *, const OverlapGraph::Node *>, std::vector<const Path *>>
-PathManager::getPathsBetweenAnchors() {  // PathManager.cpp:626-645: buckets by (front, back) in paths_ order
+PathManager::getPathsBetweenAnchors() {  // PathManager.cpp:626-645: buckets by (front, back), each in paths_ order
     std::map<std::pair<const OverlapGraph::Node *, const OverlapGraph::Node *>, std::vector<const Path *>> out;
-    for (const Path &p : paths_) out[{p.nodes_.front(), p.nodes_.back()}].push_back(&p);
+    tlm_pathset *all = single_set();
+    if (!all) return out;
+    std::vector<uint32_t> order(paths_.size());
+    std::vector<uint64_t> key(paths_.size());
+    if (tlm_pathset_anchor_pairs(OverlapGraph::context(), all, order.data(), key.data()) != TLM_OK) {
+        std::cerr << "telomeri_hip: getPathsBetweenAnchors failed: " << tlm_last_error() << std::endl;
+        std::exit(1);
+    }
+    for (size_t j = 0; j < order.size(); j++) {      // keys ascending = the map's (Node*, Node*) order
+        const Path &p = paths_[order[j]];
+        out[{p.nodes_.front(), p.nodes_.back()}].push_back(&p);
+    }
     return out;
 }

@@ -25,6 +25,7 @@
 
 struct tlm_ctx;
 struct tlm_graph;
+struct tlm_pathset;
 
 typedef unsigned int uint;
 typedef unsigned long ulong;
@@ -115,8 +116,16 @@ bool startsWithInsensitive(const std::string &str, const std::string &temp);
 
 class PathManager {
     std::vector<Path> paths_;
+    // the same paths on the device, one set per builder call (or one filtered set): filterUnique and
+    // getPathsBetweenAnchors run there
+    std::vector<tlm_pathset *> dev_sets_;
+    const OverlapGraph *graph_ = nullptr;
 
 public:
+    PathManager() = default;
+    ~PathManager();
+    PathManager(const PathManager &) = delete;
+    PathManager &operator=(const PathManager &) = delete;
     struct Parameters {                 // PathManager.hpp:27-40
         int rebuild_attempts;
         int backtrack_attempts;
@@ -143,6 +152,8 @@ public:
 
 private:
     void build(const OverlapGraph &g, const Utils::Metrics &metric, bool mc);
+    void append_from(const OverlapGraph &g, tlm_pathset *ps);   // materialise Path objects from a device set
+    tlm_pathset *single_set();                                   // concatenation of dev_sets_ (owned by dev_sets_)
 };
 
 #endif

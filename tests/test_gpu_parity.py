@@ -213,6 +213,34 @@ def test_two_metric_launch_equals_two_launches(ctx):
         dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS_SQRT, wp)
 
 
+@pytest.mark.parametrize("name,mode", [("quirks", "min"), ("tiny", "avg"), ("toy", "avg")])
+def test_filter_unique_and_anchor_pairs_on_device(ctx, name, mode):
+    """SURVEY.md §8f row 1 on the packed Path sets: concat (paths_ of one PathManager), filterUnique,
+    getPathsBetweenAnchors -- against the oracle's restatement (pinned to the reference in test_oracle_golden.py)."""
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    fp = capi.FilterParams.default(mode)
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    wp = capi.WalkParams.default(rb_att=40, bt_att=5)
+    owp = H.to_oracle_wp(wp)
+    dsets = list(dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp)) + list(dg.walk_det2(capi.METRIC_ES, capi.METRIC_OS))
+    osets = [og.walk_mc(m, owp, po.SEED_PER_WALK)[0] for m in (0, 1)] + [og.walk_det(m)[0] for m in (0, 1)]
+    dall = capi.PathSet.concat(dsets)
+    oall = po.concat_paths(osets)
+    H.assert_paths_equal(dall.to_host(), oall)
+    duniq = dall.filter_unique()
+    ouniq = po.filter_unique(oall)
+    H.assert_paths_equal(duniq.to_host(), ouniq)
+    if name == "quirks":
+        assert len(ouniq) < len(oall)          # the contig<->contig edge makes every trial of one anchor identical
+    assert duniq.anchor_pairs() == po.paths_between_anchors(ouniq)
+    assert dall.anchor_pairs() == po.paths_between_anchors(oall)
+    # idempotent, and an empty set stays empty
+    H.assert_paths_equal(duniq.filter_unique().to_host(), ouniq)
+    empty = dg.walk_det(capi.METRIC_ES, 0, 0)
+    assert empty.filter_unique().n_paths == 0 and empty.anchor_pairs() == []
+
+
 def test_walk_overflow_reruns(ctx):
     """A tiny path buffer forces the scratch-overflow re-run; results must not change."""
     ds = synth.make_config("tiny")

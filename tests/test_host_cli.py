@@ -59,6 +59,18 @@ def test_cli_against_reference_dump(binary, name):
             assert l1 == l2
             np.testing.assert_array_equal(n1, n2)
             np.testing.assert_array_equal(s1, s2)
+    # filterUnique + getPathsBetweenAnchors (device post-passes behind the host's members), against the oracle's
+    # restatement over the same per-walk-seeded paths
+    osets = [g.walk_mc(m, wp, po.SEED_PER_WALK)[0] for m in (po.METRIC_ES, po.METRIC_OS)] + [g.walk_det(m)[0] for m in (0, 1)]
+    ouniq = po.filter_unique(po.concat_paths(osets))
+    assert len(got.unique) == len(ouniq)
+    for i, (l1, n1, s1) in enumerate(got.unique):
+        l2, n2, s2 = ouniq.path(i)
+        assert l1 == l2
+        np.testing.assert_array_equal(n1, n2)
+        np.testing.assert_array_equal(s1, s2)
+    assert got.pairs == po.paths_between_anchors(ouniq)
+    assert "- total_num: %d" % len(ouniq) in res.stdout
     # Monte-Carlo builders, against the oracle under per-walk seeding
     for b, metric in ((0, po.METRIC_ES), (1, po.METRIC_OS)):
         ps = g.walk_mc(metric, wp, po.SEED_PER_WALK)[0]

@@ -96,6 +96,31 @@ def test_synthetic_sets_graph_and_paths(name):
     assert n_checked > 50
 
 
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+def test_filter_unique_and_anchor_pairs(name):
+    """paths_ of one PathManager after the four builders, filterUnique, getPathsBetweenAnchors."""
+    meta = G.load_json(name + ".json")
+    fp, wp = G.args_to_params(meta["args"])
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
+        ref = po.parse_ref_dump(G.gunzip_to(tmp, name + ".dump.gz"))
+        g = po.Graph()
+        assert g.load_paf(rr, False, fp) and g.load_paf(cr, True, fp)
+    sets = [g.walk_mc(po.METRIC_ES, wp, po.SEED_SHARED)[0], g.walk_mc(po.METRIC_OS, wp, po.SEED_SHARED)[0],
+            g.walk_det(po.METRIC_ES)[0], g.walk_det(po.METRIC_OS)[0]]
+    allp = po.concat_paths(sets)
+    uniq = po.filter_unique(allp)
+    assert len(uniq) == len(ref.unique)
+    assert len(uniq) <= len(allp)
+    for i, (length, nodes, slots) in enumerate(ref.unique):
+        l2, n2, s2 = uniq.path(i)
+        assert l2 == length
+        np.testing.assert_array_equal(n2, nodes)
+        np.testing.assert_array_equal(s2, slots)
+    pairs = po.paths_between_anchors(uniq)
+    assert [(a, b, idx) for a, b, idx in pairs] == [(a, b, idx) for a, b, idx in ref.pairs]
+
+
 def test_per_walk_seed_first_unit_equals_shared_stream_when_seed_matches():
     """Per-walk seeding only moves the seeding point: a walk whose per-walk seed is S equals the FIRST walk of a
     shared stream seeded S.  Checked through the oracle's own RNG helper against libstdc++ vectors above; here:
