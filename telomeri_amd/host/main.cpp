@@ -40,6 +40,7 @@ int main(int argc, char **argv) {
     PathManager pm;
     const char *mode_string = "AVG";
     std::string dump;
+    bool parse_only = false;
     std::vector<char *> pos;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -63,7 +64,19 @@ int main(int argc, char **argv) {
         else if (a == "--w-size") { if (!parse_ulong(need("--w-size"), u)) return 1; pm.params_.window_size = u; }
         else if (a == "--r-thr") { if (!parse_perc(need("--r-thr"), f)) return 1; pm.params_.ratio_threshold = f; }
         else if (a == "--dump") dump = need("--dump");
+        else if (a == "--parse-only") parse_only = true;
+        else if (a == "--test-load-num") { if (!parse_ulong(need("--test-load-num"), u)) return 1; graph.test_load_num_ = (uint) u; }
         else pos.push_back(argv[i]);
+    }
+    if (parse_only) {       // host tokeniser alone: `telomeri_hip --parse-only <file.paf>...`, no GPU involved
+        for (char *f : pos) {
+            ulong n = 0;
+            if (!graph.tokenize(f, false, n)) return 1;
+            std::cout << "parsed " << n << " records from " << f << " in " << graph.last_parse_ms() << " ms ("
+                      << (graph.last_parse_was_parallel() ? "parallel" : "sequential") << ")" << std::endl;
+        }
+        std::cout << "names " << graph.parsed_names() << " checksum " << graph.parse_checksum() << std::endl;
+        return 0;
     }
     if (pos.size() != 5) {
         std::cerr << "Please provide a path to read-read and contig-read files!\n"
@@ -87,7 +100,13 @@ int main(int argc, char **argv) {
         return s;
     };
     std::cout << "\nLoading overlaps..." << std::endl;
-    if (!graph.load(pos[0], false) || !graph.load(pos[1], true)) return 1;          // Main.cpp:223
+    double parse_ms = 0, build_ms = 0, dl_ms = 0;
+    for (int k = 0; k < 2; k++) {                                                     // Main.cpp:223
+        if (!graph.load(pos[k], k == 1)) return 1;
+        parse_ms += graph.last_parse_ms(); build_ms += graph.last_build_ms(); dl_ms += graph.last_download_ms();
+    }
+    std::cout << "load breakdown: tokenise+intern " << parse_ms << " ms (" << (graph.last_parse_was_parallel() ? "parallel" : "sequential")
+              << "), device graph build " << build_ms << " ms, download+materialise " << dl_ms << " ms" << std::endl;
     std::cout << "Done (" << lap() << "s)" << std::endl << graph.stats() << std::endl;
 
     std::cout << "Calculating paths..." << std::endl;

@@ -8,6 +8,13 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <thread>
+#include <unordered_map>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -83,50 +90,254 @@ OverlapGraph::~OverlapGraph() {
     if (dev_) tlm_graph_destroy(dev_);
 }
 
+// ---- PAF ingestion ---------------------------------------------------------
+// The reference reads the file as ONE token stream with operator>> (OverlapGraph.cpp:109-127): 12 typed tokens,
+// then exactly 4 more, whatever the line structure.  Tokenising is the host's share of load and dominates its
+// wall-clock once filtering/scoring/adjacency run on the GPU, so it is done on all cores:
+//   * the file is mmap'ed and cut into byte ranges at line ends, one per thread;
+//   * a range is "clean" when every non-empty line has exactly 16 tokens, its 9 numeric tokens are plain
+//     [+-]digits inside int range and its strand token is one character.  On clean input line-wise parsing IS the
+//     token stream, so the threads parse independently (names -> per-thread tables, merged in file order);
+//   * anything else (ragged lines, "12abc", overflow, test_load_num_) falls back to the sequential token-stream
+//     reader below, which reproduces operator>> exactly, including where the reference silently stops.
+namespace {
+
+struct Chunk {
+    std::vector<int32_t> q_loc, t_loc, q_len, q_start, q_end, t_len, t_start, t_end, matches;
+    std::vector<uint8_t> strand;
+    std::vector<std::pair<const char *, uint32_t>> names;      // local name table, first-seen order
+    bool clean = true;
+};
+
+struct NameHash {
+    // open addressing over (ptr, len) keys; values are local ids
+    std::vector<int32_t> slot;
+    std::vector<uint64_t> hash;
+    const std::vector<std::pair<const char *, uint32_t>> *names = nullptr;
+    size_t mask = 0, used = 0;
+    static uint64_t fnv(const char *s, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; i++) { h ^= (unsigned char) s[i]; h *= 1099511628211ull; }
+        return h;
+    }
+    void init(const std::vector<std::pair<const char *, uint32_t>> *nm, size_t cap = 1 << 12) {
+        names = nm; slot.assign(cap, -1); hash.assign(cap, 0); mask = cap - 1; used = 0;
+    }
+    void grow() {
+        std::vector<int32_t> os; std::vector<uint64_t> oh;
+        os.swap(slot); oh.swap(hash);
+        slot.assign(os.size() * 2, -1); hash.assign(os.size() * 2, 0); mask = slot.size() - 1;
+        for (size_t i = 0; i < os.size(); i++)
+            if (os[i] >= 0) {
+                size_t j = oh[i] & mask;
+                while (slot[j] >= 0) j = (j + 1) & mask;
+                slot[j] = os[i]; hash[j] = oh[i];
+            }
+    }
+    // returns the id of (s, n); *fresh = true if it was not present (the caller appends it to `names` first)
+    int32_t find_or_add(const char *s, size_t n, int32_t next_id, bool *fresh) {
+        const uint64_t h = fnv(s, n);
+        size_t j = h & mask;
+        while (slot[j] >= 0) {
+            const auto &nm = (*names)[(size_t) slot[j]];
+            if (hash[j] == h && nm.second == n && std::memcmp(nm.first, s, n) == 0) { *fresh = false; return slot[j]; }
+            j = (j + 1) & mask;
+        }
+        slot[j] = next_id; hash[j] = h; *fresh = true;
+        if (++used * 2 > slot.size()) grow();
+        return next_id;
+    }
+};
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// strict integer: the whole token must be [+-]digits and fit an int
+inline bool strict_int(const char *s, const char *e, int32_t &v) {
+    if (s >= e) return false;
+    bool neg = false;
+    if (*s == '+' || *s == '-') { neg = *s == '-'; s++; }
+    if (s >= e || e - s > 10) return false;
+    long long acc = 0;
+    for (; s < e; s++) {
+        if (*s < '0' || *s > '9') return false;
+        acc = acc * 10 + (*s - '0');
+    }
+    if (neg) acc = -acc;
+    if (acc > INT_MAX || acc < INT_MIN) return false;
+    v = (int32_t) acc;
+    return true;
+}
+
+void parse_range(const char *p, const char *end, Chunk &c) {
+    NameHash nh;
+    nh.init(&c.names);
+    const char *tok[16];
+    const char *tend[16];
+    while (p < end) {
+        const char *eol = (const char *) std::memchr(p, '\n', (size_t) (end - p));
+        if (!eol) eol = end;
+        int nt = 0;
+        const char *q = p;
+        while (q < eol) {
+            while (q < eol && is_ws(*q)) q++;
+            if (q >= eol) break;
+            if (nt == 16) { nt = 17; break; }
+            tok[nt] = q;
+            while (q < eol && !is_ws(*q)) q++;
+            tend[nt++] = q;
+        }
+        p = eol + 1;
+        if (nt == 0) continue;                       // blank line: no tokens, the stream just moves on
+        int32_t v[9];
+        static const int num_idx[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
+        bool ok = nt == 16 && tend[4] - tok[4] == 1;
+        for (int k = 0; ok && k < 9; k++) ok = strict_int(tok[num_idx[k]], tend[num_idx[k]], v[k]);
+        if (!ok) { c.clean = false; return; }
+        bool fresh;
+        int32_t qi = nh.find_or_add(tok[0], (size_t) (tend[0] - tok[0]), (int32_t) c.names.size(), &fresh);
+        if (fresh) c.names.emplace_back(tok[0], (uint32_t) (tend[0] - tok[0]));
+        int32_t ti = nh.find_or_add(tok[5], (size_t) (tend[5] - tok[5]), (int32_t) c.names.size(), &fresh);
+        if (fresh) c.names.emplace_back(tok[5], (uint32_t) (tend[5] - tok[5]));
+        c.q_loc.push_back(qi); c.t_loc.push_back(ti);
+        c.q_len.push_back(v[0]); c.q_start.push_back(v[1]); c.q_end.push_back(v[2]);
+        c.t_len.push_back(v[3]); c.t_start.push_back(v[4]); c.t_end.push_back(v[5]);
+        c.matches.push_back(v[6]);
+        c.strand.push_back(*tok[4] == '-');
+    }
+}
+
+}   // namespace
+
 bool OverlapGraph::load(char *filepath, bool anchors) {
-    std::ifstream in(filepath, std::ios::binary);
-    if (!in) {
+    ulong ctr = 0;
+    if (!tokenize(filepath, anchors, ctr)) return false;
+    if (!rebuild()) return false;
+    std::cout << "Loaded " << edges_.size() << '/' << ctr << " edges from " << filepath << std::endl;   // :150
+    return true;
+}
+
+uint64_t OverlapGraph::parse_checksum() const {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *) p;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    for (const File &f : files_) {
+        for (const auto *col : {&f.q_id, &f.t_id, &f.q_len, &f.q_start, &f.q_end, &f.t_len, &f.t_start, &f.t_end, &f.matches})
+            mix(col->data(), col->size() * 4);
+        mix(f.strand.data(), f.strand.size());
+    }
+    for (const std::string &n : names_) mix(n.data(), n.size() + 1);
+    return h;
+}
+
+bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int fd = ::open(filepath, O_RDONLY);
+    if (fd < 0) {
         std::cerr << "Cannot open file: " << filepath << std::endl;          // OverlapGraph.cpp:100-103
         return false;
     }
-    std::string buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-    in.close();
+    struct stat st;
+    ::fstat(fd, &st);
+    const size_t size = (size_t) st.st_size;
+    const char *data = size ? (const char *) ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    if (size && data == MAP_FAILED) {
+        ::close(fd);
+        std::cerr << "Cannot open file: " << filepath << std::endl;
+        return false;
+    }
 
     files_.emplace_back();
     File &f = files_.back();
     f.anchors = anchors;
-    Reader r{buf.data(), buf.data() + buf.size()};
-    ulong ctr = 0;
-    for (;;) {                                                               // OverlapGraph.cpp:109-121
-        const char *qn, *tn, *dummy;
-        size_t qn_n, tn_n, dn;
-        int q_len, q_start, q_end, t_len, t_start, t_end, matches, block_len, mapq;
-        char strand;
-        if (!(r.token(qn, qn_n) && r.integer(q_len) && r.integer(q_start) && r.integer(q_end) && r.character(strand)
-              && r.token(tn, tn_n) && r.integer(t_len) && r.integer(t_start) && r.integer(t_end) && r.integer(matches)
-              && r.integer(block_len) && r.integer(mapq)))
-            break;
-        for (int k = 0; k < 4; k++) r.token(dummy, dn);                      // :124-127: exactly 4 more tokens
-        ++ctr;
-        auto intern = [&](const char *s, size_t n) -> int32_t {
-            std::string key(s, n);
-            auto it = name_id_.find(key);
-            if (it != name_id_.end()) return it->second;
-            const int32_t id = (int32_t) names_.size();
-            names_.push_back(key);
-            name_id_.emplace(std::move(key), id);
-            return id;
-        };
-        f.q_id.push_back(intern(qn, qn_n));
-        f.t_id.push_back(intern(tn, tn_n));
-        f.q_len.push_back(q_len); f.q_start.push_back(q_start); f.q_end.push_back(q_end);
-        f.t_len.push_back(t_len); f.t_start.push_back(t_start); f.t_end.push_back(t_end);
-        f.matches.push_back(matches);
-        f.strand.push_back(strand == '-');
-        if (test_load_num_ > 0 && test_load_num_ < ctr) break;                // :145-147
+    ctr = 0;
+    bool parsed = false;
+
+    // ---- parallel line-wise parse of clean input
+    if (test_load_num_ == 0 && size) {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(nt ? nt : 1, 64u), size / (1 << 20) + 1));
+        if (const char *e = std::getenv("TLM_PARSE_THREADS")) nt = (unsigned) std::min(64, std::max(1, std::atoi(e)));
+        std::vector<const char *> cut(nt + 1);
+        cut[0] = data;
+        cut[nt] = data + size;
+        for (unsigned t = 1; t < nt; t++) {
+            const char *p = data + size / nt * t;
+            const char *nl = (const char *) std::memchr(p, '\n', (size_t) (data + size - p));
+            cut[t] = nl ? nl + 1 : data + size;
+        }
+        std::vector<Chunk> chunks(nt);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { parse_range(cut[t], cut[t + 1], chunks[t]); });
+        for (auto &x : th) x.join();
+        bool clean = true;
+        for (const Chunk &c : chunks) clean &= c.clean;
+        if (clean) {
+            // merge: global name ids in file order (any injective numbering would do for the device; first-seen
+            // order keeps names_ deterministic), then append the columns
+            size_t total = 0;
+            for (const Chunk &c : chunks) total += c.q_loc.size();
+            f.q_id.reserve(total); f.t_id.reserve(total);
+            for (Chunk &c : chunks) {
+                std::vector<int32_t> glob(c.names.size());
+                for (size_t i = 0; i < c.names.size(); i++) {
+                    std::string key(c.names[i].first, c.names[i].second);
+                    auto it = name_id_.find(key);
+                    if (it == name_id_.end()) {
+                        it = name_id_.emplace(key, (int32_t) names_.size()).first;
+                        names_.push_back(std::move(key));
+                    }
+                    glob[i] = it->second;
+                }
+                for (int32_t v : c.q_loc) f.q_id.push_back(glob[(size_t) v]);
+                for (int32_t v : c.t_loc) f.t_id.push_back(glob[(size_t) v]);
+                auto app = [](std::vector<int32_t> &d, std::vector<int32_t> &s) { d.insert(d.end(), s.begin(), s.end()); };
+                app(f.q_len, c.q_len); app(f.q_start, c.q_start); app(f.q_end, c.q_end);
+                app(f.t_len, c.t_len); app(f.t_start, c.t_start); app(f.t_end, c.t_end); app(f.matches, c.matches);
+                f.strand.insert(f.strand.end(), c.strand.begin(), c.strand.end());
+            }
+            ctr = total;
+            parsed = true;
+        }
     }
-    if (!rebuild()) return false;
-    std::cout << "Loaded " << edges_.size() << '/' << ctr << " edges from " << filepath << std::endl;   // :150
+
+    // ---- sequential token stream: the reference's exact operator>> behaviour for everything else
+    if (!parsed) {
+        Reader r{data, data + size};
+        for (;;) {                                                           // OverlapGraph.cpp:109-121
+            const char *qn, *tn, *dummy;
+            size_t qn_n, tn_n, dn;
+            int q_len, q_start, q_end, t_len, t_start, t_end, matches, block_len, mapq;
+            char strand;
+            if (!(r.token(qn, qn_n) && r.integer(q_len) && r.integer(q_start) && r.integer(q_end) && r.character(strand)
+                  && r.token(tn, tn_n) && r.integer(t_len) && r.integer(t_start) && r.integer(t_end)
+                  && r.integer(matches) && r.integer(block_len) && r.integer(mapq)))
+                break;
+            for (int k = 0; k < 4; k++) r.token(dummy, dn);                  // :124-127: exactly 4 more tokens
+            ++ctr;
+            auto intern = [&](const char *s, size_t n) -> int32_t {
+                std::string key(s, n);
+                auto it = name_id_.find(key);
+                if (it != name_id_.end()) return it->second;
+                const int32_t id = (int32_t) names_.size();
+                names_.push_back(key);
+                name_id_.emplace(std::move(key), id);
+                return id;
+            };
+            f.q_id.push_back(intern(qn, qn_n));
+            f.t_id.push_back(intern(tn, tn_n));
+            f.q_len.push_back(q_len); f.q_start.push_back(q_start); f.q_end.push_back(q_end);
+            f.t_len.push_back(t_len); f.t_start.push_back(t_start); f.t_end.push_back(t_end);
+            f.matches.push_back(matches);
+            f.strand.push_back(strand == '-');
+            if (test_load_num_ > 0 && test_load_num_ < ctr) break;            // :145-147
+        }
+    }
+    if (size) ::munmap((void *) data, size);
+    ::close(fd);
+    parse_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    parsed_parallel_ = parsed;
     return true;
 }
 
@@ -161,6 +372,7 @@ bool OverlapGraph::rebuild() {
     build_ms_ = gi.build_ms;
 
     // download and materialise the reference's data members
+    const auto t_dl = std::chrono::steady_clock::now();
     const size_t N = gi.n_nodes, A = (size_t) gi.n_adj;
     std::vector<uint64_t> row_ptr(N + 1);
     std::vector<uint32_t> nbr(A), qs(A), qe(A), ts(A), te(A), node_len(N), kept(gi.n_kept);
@@ -202,6 +414,7 @@ bool OverlapGraph::rebuild() {
         edges_.push_back(nodes_[tn].edges[cursor[tn]++]);
         cursor[qn]++;
     }
+    download_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count();
     return true;
 }
 

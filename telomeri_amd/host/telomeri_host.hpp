@@ -20,6 +20,7 @@
 #include <ostream>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -78,7 +79,14 @@ public:
     // --- device side (not in the reference) ---
     tlm_graph *device_graph() const { return dev_; }
     static tlm_ctx *context();          // one context per process, device $TLM_DEVICE (default 0)
-    double last_build_ms() const { return build_ms_; }
+    double last_build_ms() const { return build_ms_; }      // device time of the last graph build
+    double last_parse_ms() const { return parse_ms_; }      // host tokenising + interning of the last load
+    double last_download_ms() const { return download_ms_; }
+    bool last_parse_was_parallel() const { return parsed_parallel_; }
+    /** The host half of load alone (no GPU needed): tokenise `filepath` into the pending columns. */
+    bool tokenize(char *filepath, bool anchors, ulong &records);
+    uint64_t parse_checksum() const;    // FNV-1a over every tokenised column and the name table (tests)
+    size_t parsed_names() const { return names_.size(); }
 
 private:
     struct File {                       // one tokenised PAF file (SoA int32 columns)
@@ -88,9 +96,10 @@ private:
     };
     std::vector<File> files_;
     std::vector<std::string> names_;    // name table shared by all files (ids in first-seen order)
-    std::map<std::string, int32_t> name_id_;
+    std::unordered_map<std::string, int32_t> name_id_;
     tlm_graph *dev_ = nullptr;
-    double build_ms_ = 0;
+    double build_ms_ = 0, parse_ms_ = 0, download_ms_ = 0;
+    bool parsed_parallel_ = false;
     bool rebuild();                     // device build over all files loaded so far + download into nodes_/edges_
 };
 

@@ -59,3 +59,40 @@ def test_low_coverage_backtracking():
     ds = synth.make_dataset("lowcov", seed=31, genome_len=260_000, n_contigs=3, contig_len=35_000, n_reads=150,
                             read_len_lo=4_000, read_len_hi=12_000)
     _compare(ds, ["--rb-att", "60", "--bt-att", "3"])
+
+
+def test_token_stream_quirks_against_reference():
+    """Malformed PAF text: where operator>> stops (OverlapGraph.cpp:109-127) -- record counts and graphs of the oracle's
+    loader against the reference binary."""
+    import re
+    import subprocess
+    from test_host_ingest import LINE
+    texts = {
+        "ragged_17": LINE + LINE.replace("dv:f:0.01", "dv:f:0.01\textra") + LINE * 3,
+        "ragged_15": LINE * 2 + LINE.replace("\tdv:f:0.01", "") + LINE * 2,
+        "suffix": LINE + LINE.replace("\t6500\t", "\t65x0\t") + LINE,
+        "overflow": LINE + LINE.replace("\t9000\t", "\t99999999999\t") + LINE,
+        "strand2": LINE + LINE.replace("\t+\t", "\t+-\t") + LINE,
+        "truncated": LINE * 3 + "readC\t100\t1",
+        "blank_crlf": LINE + "\n\n" + LINE.replace("\n", "\r\n") + "   \n" + LINE,
+        "split": LINE.replace("\t+\t", "\n+\n") * 2,
+    }
+    fp = po.FilterParams.default("min")
+    with tempfile.TemporaryDirectory() as tmp:
+        empty = os.path.join(tmp, "empty.paf")
+        open(empty, "w").close()
+        for name, text in texts.items():
+            p = os.path.join(tmp, name + ".paf")
+            open(p, "w", newline="").write(text)
+            out = os.path.join(tmp, name + ".dump")
+            res = subprocess.run([po.REF_DUMP, "--filter-min", "--no-paths", p, empty, out], capture_output=True, text=True)
+            assert res.returncode == 0
+            m = re.search(r"Loaded (\d+)/(\d+) edges from " + re.escape(p), res.stdout)
+            ref = po.parse_ref_dump(out)
+            g = po.Graph()
+            assert g.load_paf(p, False, fp)
+            assert g.records == [int(m.group(2))], name
+            c = g.csr()
+            assert c.n_edges == int(m.group(1)), name
+            if ref.adj is not None:
+                np.testing.assert_array_equal(G.csr_as_dump_rows(c), ref.adj)
