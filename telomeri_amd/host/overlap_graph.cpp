@@ -277,10 +277,13 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
             // merge: global name ids in file order (any injective numbering would do for the device; first-seen
             // order keeps names_ deterministic), then append the columns
             size_t total = 0;
-            for (const Chunk &c : chunks) total += c.q_loc.size();
-            f.q_id.reserve(total); f.t_id.reserve(total);
-            for (Chunk &c : chunks) {
-                std::vector<int32_t> glob(c.names.size());
+            std::vector<size_t> base(nt + 1, 0);
+            for (unsigned t = 0; t < nt; t++) { total += chunks[t].q_loc.size(); base[t + 1] = total; }
+            // name tables: sequential (they are small), file order
+            std::vector<std::vector<int32_t>> glob(nt);
+            for (unsigned t = 0; t < nt; t++) {
+                const Chunk &c = chunks[t];
+                glob[t].resize(c.names.size());
                 for (size_t i = 0; i < c.names.size(); i++) {
                     std::string key(c.names[i].first, c.names[i].second);
                     auto it = name_id_.find(key);
@@ -288,15 +291,30 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
                         it = name_id_.emplace(key, (int32_t) names_.size()).first;
                         names_.push_back(std::move(key));
                     }
-                    glob[i] = it->second;
+                    glob[t][i] = it->second;
                 }
-                for (int32_t v : c.q_loc) f.q_id.push_back(glob[(size_t) v]);
-                for (int32_t v : c.t_loc) f.t_id.push_back(glob[(size_t) v]);
-                auto app = [](std::vector<int32_t> &d, std::vector<int32_t> &s) { d.insert(d.end(), s.begin(), s.end()); };
-                app(f.q_len, c.q_len); app(f.q_start, c.q_start); app(f.q_end, c.q_end);
-                app(f.t_len, c.t_len); app(f.t_start, c.t_start); app(f.t_end, c.t_end); app(f.matches, c.matches);
-                f.strand.insert(f.strand.end(), c.strand.begin(), c.strand.end());
             }
+            // columns: every thread copies its chunk to its place
+            for (auto *col : {&f.q_id, &f.t_id, &f.q_len, &f.q_start, &f.q_end, &f.t_len, &f.t_start, &f.t_end, &f.matches})
+                col->resize(total);
+            f.strand.resize(total);
+            std::vector<std::thread> cp;
+            for (unsigned t = 0; t < nt; t++)
+                cp.emplace_back([&, t] {
+                    const Chunk &c = chunks[t];
+                    const size_t b = base[t], n = c.q_loc.size();
+                    for (size_t i = 0; i < n; i++) {
+                        f.q_id[b + i] = glob[t][(size_t) c.q_loc[i]];
+                        f.t_id[b + i] = glob[t][(size_t) c.t_loc[i]];
+                    }
+                    auto put = [&](std::vector<int32_t> &d, const std::vector<int32_t> &src) {
+                        if (n) std::memcpy(d.data() + b, src.data(), n * 4);
+                    };
+                    put(f.q_len, c.q_len); put(f.q_start, c.q_start); put(f.q_end, c.q_end);
+                    put(f.t_len, c.t_len); put(f.t_start, c.t_start); put(f.t_end, c.t_end); put(f.matches, c.matches);
+                    if (n) std::memcpy(f.strand.data() + b, c.strand.data(), n);
+                });
+            for (auto &x : cp) x.join();
             ctr = total;
             parsed = true;
         }
@@ -386,18 +404,27 @@ bool OverlapGraph::rebuild() {
     nodes_.clear();
     nodes_.resize(N);
     std::vector<uint32_t> node_of_name(names_.size(), 0xFFFFFFFFu);
-    for (size_t i = 0; i < N; i++) {
-        Node &n = nodes_[i];
-        n.anchor = anchor[i] != 0;
-        n.index = (uint) i;
-        n.length = node_len[i];
-        n.name = names_[(size_t) name_id[i]];
-        node_of_name[(size_t) name_id[i]] = (uint32_t) i;
-        n.edges.resize((size_t) (row_ptr[i + 1] - row_ptr[i]));
-        for (size_t k = 0; k < n.edges.size(); k++) {
-            const size_t e = (size_t) row_ptr[i] + k;
-            n.edges[k] = Edge{nbr[e], (uint) i, qs[e], qe[e], ts[e], te[e], os[e], si[e], es[e], strand[e] != 0};
-        }
+    {
+        unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        if (N < 4096) nt = 1;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                for (size_t i = N * t / nt; i < N * (t + 1) / nt; i++) {
+                    Node &n = nodes_[i];
+                    n.anchor = anchor[i] != 0;
+                    n.index = (uint) i;
+                    n.length = node_len[i];
+                    n.name = names_[(size_t) name_id[i]];
+                    node_of_name[(size_t) name_id[i]] = (uint32_t) i;
+                    n.edges.resize((size_t) (row_ptr[i + 1] - row_ptr[i]));
+                    for (size_t k = 0; k < n.edges.size(); k++) {
+                        const size_t e = (size_t) row_ptr[i] + k;
+                        n.edges[k] = Edge{nbr[e], (uint) i, qs[e], qe[e], ts[e], te[e], os[e], si[e], es[e], strand[e] != 0};
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
     }
     // edges_ in record order (OverlapGraph.cpp:241): the k-th kept record's unswapped copy is the next unread
     // entry of its target's list (per-node order is record order, each record adds one entry to either list)
