@@ -25,6 +25,10 @@
 //                                            and filterUnique (Main.cpp:247), in paths_ order; followed by `p` lines
 //   K <pairs>                                getPathsBetweenAnchors (Main.cpp:251-252) in map order
 //   k <front node> <back node> <count> <indices into the U list...>
+//   G <len_thr> <w_size> <r_thr>             (--groups) PathManager::constructGroups + the PathGroup members with THESE
+//                                            parameters on each pair's paths (independent of the walk parameters)
+//   q <front> <back> <groups>
+//   g <paths> <paths after discardNotFrequent> <consensus length or -1> <valid_path_number> <first length> <last length>
 #include <OverlapGraph.hpp>
 #include <PathManager.hpp>
 #include <Utils.hpp>
@@ -64,7 +68,8 @@ static void dump_builder(FILE *out, const OverlapGraph &g, PathManager &pm, int 
 int main(int argc, char **argv) {
     OverlapGraph::FilterParameters fp = {OverlapGraph::AVG, 0, 0.0f, ULONG_MAX, 1.0f};   // Main.cpp:56-62
     PathManager::Parameters pp = {2000, 60, 4700000ul, 1000ul, 0.9f};                    // Main.cpp:63-69
-    bool want_graph = true, want_paths = true, want_sqrt = false;
+    bool want_graph = true, want_paths = true, want_sqrt = false, want_groups = false;
+    PathManager::Parameters gp = {2000, 60, 4700000ul, 1000ul, 0.9f};
     std::vector<char *> pos;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -86,6 +91,12 @@ int main(int argc, char **argv) {
         else if (a == "--no-graph") want_graph = false;
         else if (a == "--no-paths") want_paths = false;
         else if (a == "--sqrt") want_sqrt = true;
+        else if (a == "--groups") {
+            want_groups = true;
+            gp.len_threshold = std::atol(next());
+            gp.window_size = std::strtoul(next(), nullptr, 10);
+            gp.ratio_threshold = std::strtof(next(), nullptr);
+        }
         else pos.push_back(argv[i]);
     }
     if (pos.size() != 3) {
@@ -164,6 +175,23 @@ int main(int argc, char **argv) {
             for (const Path *p : kv.second)
                 std::fprintf(out, " %ld", (long) (std::lower_bound(all.begin(), all.end(), p) - all.begin()));
             std::fprintf(out, "\n");
+        }
+        if (want_groups) {
+            std::fprintf(out, "G %ld %lu %.9g\n", gp.len_threshold, gp.window_size, (double) gp.ratio_threshold);
+            for (auto &kv : pba) {
+                std::vector<const Path *> v = kv.second;      // constructGroups sorts its argument
+                std::vector<PathGroup> pgs = PathManager::constructGroups(v, gp);
+                std::fprintf(out, "q %u %u %zu\n", kv.first.first->index, kv.first.second->index, pgs.size());
+                for (PathGroup &pg : pgs) {
+                    const size_t before = pg.pig_.size();
+                    pg.discardNotFrequent();
+                    pg.calculateConsensusPath();
+                    pg.calculateValidPathNumber();
+                    std::fprintf(out, "g %zu %zu %ld %d %ld %ld\n", before, pg.pig_.size(),
+                                 pg.consensus ? pg.consensus->length() : -1L, pg.valid_path_number,
+                                 pg.pig_.front()->length(), pg.pig_.back()->length());
+                }
+            }
         }
     }
     std::fclose(out);

@@ -3,10 +3,10 @@
 //   telomeri_hip [options] <rr.paf> <cr.paf> <reads.fasta> <contigs.fasta> <out.fasta>
 //
 // Options and defaults as reference src/Main.cpp:56-69,100-192 (the parser there, not its help text).
-// Stages up to the end of the hot path run as in Main.cpp:212-252: load rr + cr, the four builders,
-// filterUnique, stats.  What follows in the reference (grouping, consensus, Scaffolder: SURVEY.md §8f) is
-// not part of this round; instead `--dump <file>` writes graph and paths in oracle/ref_dump's text format
-// so the result can be compared with the reference's.
+// The stages run as in Main.cpp:212-388: load rr + cr, the four builders, filterUnique, stats, then grouping,
+// consensus, scaffold path and Scaffolder (pipeline.cpp).  `--dump <file>` additionally writes graph and paths in
+// oracle/ref_dump's text format so the result can be compared with the reference's; `--no-scaffold` stops after the
+// hot path.
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -14,6 +14,9 @@
 #include <string>
 
 #include "telomeri_host.hpp"
+
+int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vector<const Path *>> &paths_between_anchors,
+                    const char *reads_file, const char *contigs_file, const char *output_file);
 
 static bool parse_ulong(const char *s, ulong &v) {
     char *end = nullptr;
@@ -40,7 +43,7 @@ int main(int argc, char **argv) {
     PathManager pm;
     const char *mode_string = "AVG";
     std::string dump;
-    bool parse_only = false;
+    bool parse_only = false, no_scaffold = false;
     std::vector<char *> pos;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -65,6 +68,7 @@ int main(int argc, char **argv) {
         else if (a == "--r-thr") { if (!parse_perc(need("--r-thr"), f)) return 1; pm.params_.ratio_threshold = f; }
         else if (a == "--dump") dump = need("--dump");
         else if (a == "--parse-only") parse_only = true;
+        else if (a == "--no-scaffold") no_scaffold = true;      // stop after getPathsBetweenAnchors (hot path only)
         else if (a == "--test-load-num") { if (!parse_ulong(need("--test-load-num"), u)) return 1; graph.test_load_num_ = (uint) u; }
         else pos.push_back(argv[i]);
     }
@@ -173,7 +177,10 @@ int main(int argc, char **argv) {
     std::cout << "edge-extension evals: " << evals << " in " << kernel_ms << " ms of walk kernels ("
               << (kernel_ms > 0 ? evals / (kernel_ms * 1e-3) : 0.0) << " evals/s)" << std::endl;
     std::cout << "Anchor pairs with paths: " << pba.size() << std::endl;
-    std::cout << "Grouping, consensus and scaffold output are not part of this build (DESIGN.md §8); "
-              << pos[4] << " not written." << std::endl;
-    return 0;
+    if (no_scaffold) return 0;
+    const auto t_total = std::chrono::steady_clock::now();
+    const int rc = run_post_stages(pm, pba, pos[2], pos[3], pos[4]);              // Main.cpp:254-388
+    std::cout << "Host stages after the path build: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_total).count()
+              << "s" << std::endl;
+    return rc;
 }

@@ -1,0 +1,37 @@
+// telomeri_amd/host/pipeline.cpp -- the stages of the reference's main() after getPathsBetweenAnchors
+// (src/Main.cpp:254-388): groups, consensus, scaffold path, FASTA.  Shared by telomeri_hip (paths from the GPU) and
+// telomeri_post (paths from a dump file; CPU-only validation of these host stages against the reference).
+#include <chrono>
+#include <iostream>
+
+#include "telomeri_host.hpp"
+
+int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vector<const Path *>> &paths_between_anchors,
+                    const char *reads_file, const char *contigs_file, const char *output_file) {
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&]() {
+        auto t1 = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return s;
+    };
+    std::map<PathManager::AnchorPair, std::vector<PathGroup>> groups_for_anchors;
+    std::map<PathManager::AnchorPair, const Path *> consensus_for_anchors;
+    const long consensus_num = PathManager::selectConsensus(paths_between_anchors, groups_for_anchors, consensus_for_anchors,
+                                                            pm.params_);
+    if (consensus_num == 0) {
+        std::cerr << "No consensus found!" << std::endl;                    // Main.cpp:344-347
+        return 1;
+    }
+    std::cout << "Building the scaffold..." << std::endl;
+    const Path scaffold = pm.constructConsensusPath(paths_between_anchors, consensus_for_anchors, 10);   // Main.cpp:352
+    std::cout << "Done (" << lap() << "s)" << std::endl;
+    std::cout << "\nLoading files for scaffolding..." << std::endl;
+    Scaffolder scaff(scaffold);
+    if (!scaff.load(reads_file) || !scaff.load(contigs_file)) return 1;     // Main.cpp:357-360
+    std::cout << "Done (" << lap() << "s)" << std::endl;
+    std::cout << "Writing result to: " << output_file << std::endl;
+    if (!scaff.write(output_file)) return 1;                                // Main.cpp:385-387
+    std::cout << "Done (" << lap() << "s)" << std::endl;
+    return 0;
+}

@@ -9,8 +9,12 @@
 //   PathManager         reference include/PathManager.hpp:12-65   (builders + filterUnique + stats +
 //                                                                  getPathsBetweenAnchors)
 //   Utils::Metrics ...  reference include/Utils.hpp:17-27,43-75
-// Not here (SURVEY.md §8f "next" rows): PathGroup / PathWindow / constructGroups /
-// constructConsensusPath / Scaffolder.
+//   PathGroup           reference include/PathGroup.hpp:8-56, src/PathGroup.cpp
+//   PathWindow          reference include/PathWindow.hpp:8-36, src/PathWindow.cpp
+//   Scaffolder          reference include/Scaffolder.hpp:11-34, src/Scaffolder.cpp
+// The grouping / consensus / scaffold stages are plain host code: small pointer and
+// std::map logic that the reference keeps on the host too; they are restated with every quirk that the final
+// scaffold depends on (see the comments at each member).
 #ifndef TELOMERI_HOST_HPP
 #define TELOMERI_HOST_HPP
 
@@ -123,6 +127,35 @@ const char *getMetricName(const Metrics &metric);
 bool startsWithInsensitive(const std::string &str, const std::string &temp);
 }   // namespace Utils
 
+class PathWindow {                      // PathWindow.hpp:8-36
+    std::vector<const Path *> piw_;
+    std::map<ulong, int> frqs;
+    int sum_frqs;
+
+public:
+    PathWindow(ulong l, ulong u, const std::vector<const Path *> &sp);   // paths with length in [l, u)
+    std::pair<ulong, int> getLowestFrequencyEntry() const;
+    std::pair<ulong, int> getHighestFrequencyEntry() const;
+    int getSumFreqs() const { return sum_frqs; }
+};
+
+class PathGroup {                       // PathGroup.hpp:8-56
+public:
+    std::vector<const Path *> pig_;
+    std::map<ulong, int> frqs;
+    const Path *consensus;
+    int valid_path_number;
+    PathGroup(std::vector<const Path *>::const_iterator begin, std::vector<const Path *>::const_iterator end);
+    void discardNotFrequent();
+    void calculateConsensusPath();
+    void calculateValidPathNumber();
+
+private:
+    std::pair<ulong, int> getHighestFrequencyEntry() const;
+    void deletePathsBelowThreshold();
+    static constexpr ulong CONSENSUS_THRESHOLD = 100000;
+};
+
 class PathManager {
     std::vector<Path> paths_;
     // the same paths on the device, one set per builder call (or one filtered set): filterUnique and
@@ -155,7 +188,22 @@ public:
     std::map<std::pair<const OverlapGraph::Node *, const OverlapGraph::Node *>, std::vector<const Path *>>
     getPathsBetweenAnchors();           // PathManager.cpp:626-645
 
+    typedef std::pair<const OverlapGraph::Node *, const OverlapGraph::Node *> AnchorPair;
+    /** PathManager.cpp:508-584 (sorts `v` by length as the reference does). */
+    static std::vector<PathGroup> constructGroups(std::vector<const Path *> &v, Parameters params);
+    static std::pair<ulong, ulong> getMinMaxPathLength(std::vector<const Path *> &v);       // :648-662
+    /** PathManager.cpp:664-767. */
+    Path constructConsensusPath(const std::map<AnchorPair, std::vector<const Path *>> &paths_between_contigs,
+                                std::map<AnchorPair, const Path *> &consensus_paths, ulong min_path_num);
+    /** The per-pair stage of main() (Main.cpp:254-342): groups, per-group consensus, tournament among groups.
+     *  Prints the reference's log lines; returns the number of pairs with a consensus. */
+    static long selectConsensus(std::map<AnchorPair, std::vector<const Path *>> &paths_between_anchors,
+                                std::map<AnchorPair, std::vector<PathGroup>> &groups_for_anchors,
+                                std::map<AnchorPair, const Path *> &consensus_for_anchors, const Parameters &params);
+
     const std::vector<Path> &paths() const { return paths_; }   // not in the reference (paths_ is private there)
+    /** Test hook (CPU-only validation of the host stages): take paths produced elsewhere. */
+    void adoptPaths(std::vector<Path> &&p) { paths_ = std::move(p); }
     struct Counters { uint64_t units, steps, evals, draws, accepted; double kernel_ms; };
     Counters last_counters{};
 
@@ -163,6 +211,22 @@ private:
     void build(const OverlapGraph &g, const Utils::Metrics &metric, bool mc);
     void append_from(const OverlapGraph &g, tlm_pathset *ps);   // materialise Path objects from a device set
     tlm_pathset *single_set();                                   // concatenation of dev_sets_ (owned by dev_sets_)
+};
+
+class Scaffolder {                      // Scaffolder.hpp:11-34
+public:
+    const Path &p_;
+    std::vector<std::string> names_;
+    std::vector<std::string> sequences_;
+    explicit Scaffolder(const Path &p) : p_(p) {}
+    bool load(const char *filename);                    // Scaffolder.cpp:12-41
+    bool write(const char *filename);                   // Scaffolder.cpp:43-102
+    std::string substring(std::string &str, ulong start, ulong end);   // inclusive ends (:114-117)
+    std::string &getSequenceFrom(const std::string &name);              // :104-112 (first match)
+    void swapBases(std::string &str);                                   // :129-147
+
+private:
+    std::unordered_map<std::string, size_t> index_;     // name -> first index (the reference scans linearly)
 };
 
 #endif

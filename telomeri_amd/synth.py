@@ -245,3 +245,18 @@ def write_paf(ds: Dataset, rec: Records, path: str, extra_lines: Optional[List[s
                 cols["t_start"][i], cols["t_end"][i], cols["matches"][i], ovl, 60, ovl // 4, cols["matches"][i]))
         for ln in extra_lines or []:
             fh.write(ln.rstrip("\n") + "\n")
+
+
+def write_fasta(ds: Dataset, reads_path: str, contigs_path: str, seed: int = 0) -> None:
+    """Two-line FASTA records (what the reference's Scaffolder reads, Scaffolder.cpp:12-41): a random genome, reads and
+    contigs cut out of it on the forward strand."""
+    rng = np.random.default_rng(seed + 977)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=ds.genome_len)]
+    rs, rl = ds.read_start.cpu().numpy(), ds.read_len.cpu().numpy()
+    with open(reads_path, "w") as fh:
+        for i in range(ds.n_reads):
+            fh.write(">%s\n%s\n" % (ds.name_of(i), genome[rs[i]:rs[i] + rl[i]].tobytes().decode()))
+    cs, cl = ds.contig_start.cpu().numpy(), ds.contig_len.cpu().numpy()
+    with open(contigs_path, "w") as fh:
+        for i in range(ds.n_contigs):
+            fh.write(">%s\n%s\n" % (ds.name_of(ds.n_reads + i), genome[cs[i]:cs[i] + cl[i]].tobytes().decode()))

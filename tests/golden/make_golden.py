@@ -92,11 +92,29 @@ def main() -> None:
         synth.write_paf(ds, ds.cr, cr)
         dump = os.path.join(tmp, name + ".dump")
         d = po.run_ref_dump(rr, cr, dump, args)
+        # the whole reference program on the same inputs + FASTA (telomeri_amd.synth.write_fasta, seed 0): the scaffold
+        reads, contigs, fasta = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "out.fa")
+        synth.write_fasta(ds, reads, contigs)
+        cli = [a for a in args if a != "--sqrt"]
+        res = subprocess.run([po.REF_MAIN] + cli + [rr, cr, reads, contigs, fasta], capture_output=True, text=True)
+        scaffold = {"exit": res.returncode}
+        if res.returncode == 0:
+            body = open(fasta, "rb").read()
+            chain = [ln for ln in res.stdout.splitlines() if ln.startswith(("ctg", "read")) and "-" in ln]
+            scaffold.update({"md5": hashlib.md5(body).hexdigest(), "bytes": len(body), "chain_md5": hashlib.md5(chain[-1].encode()).hexdigest(),
+                             "consensus_lines": [ln for ln in res.stdout.splitlines() if ln.startswith(("Consensus length", "Final consensus"))]})
+        # grouping with parameters that force several windows / groups (independent of the walk parameters)
+        groups = {}
+        for gp in (("2000", "500", "0.9"), ("500", "200", "0.5"), ("100", "50", "0.99")):
+            gd = os.path.join(tmp, name + "_g.dump")
+            subprocess.run([po.REF_DUMP] + args + ["--no-graph", "--groups", *gp, rr, cr, gd], check=True, stdout=subprocess.DEVNULL)
+            txt = open(gd).read()
+            groups[" ".join(gp)] = txt[txt.index("\nG ") + 1:]
         gz_write(rr, os.path.join(HERE, name + "_rr.paf.gz"))
         gz_write(cr, os.path.join(HERE, name + "_cr.paf.gz"))
         gz_write(dump, os.path.join(HERE, name + ".dump.gz"))
         json.dump({"args": args, "paths": {str(b): len(p) for b, p in d.builders.items()},
-                   "nodes": len(d.node_name), "adj": int(d.adj.shape[0])},
+                   "nodes": len(d.node_name), "adj": int(d.adj.shape[0]), "scaffold": scaffold, "groups": groups},
                   open(os.path.join(HERE, name + ".json"), "w"), indent=1, sort_keys=True)
         print(name, len(d.node_name), d.adj.shape[0], {b: len(p) for b, p in d.builders.items()})
 

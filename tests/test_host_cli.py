@@ -37,8 +37,8 @@ def test_cli_against_reference_dump(binary, name):
         rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
         ref = po.parse_ref_dump(G.gunzip_to(tmp, name + ".dump.gz"))
         out = os.path.join(tmp, "host.dump")
-        res = subprocess.run([binary] + _flags(meta["args"]) + ["--dump", out, rr, cr, "reads.fa", "contigs.fa", "out.fa"],
-                             capture_output=True, text=True, timeout=300)
+        res = subprocess.run([binary] + _flags(meta["args"]) + ["--no-scaffold", "--dump", out, rr, cr, "reads.fa", "contigs.fa",
+                                                                "out.fa"], capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr
         got = po.parse_ref_dump(out)
         g = po.Graph()
@@ -82,6 +82,54 @@ def test_cli_against_reference_dump(binary, name):
             np.testing.assert_array_equal(s1, s2)
 
 
+def _write_dump(path, g, csr, paths):
+    """A ref_dump-format file (graph + `U` paths) from the oracle's objects: the input of telomeri_post."""
+    with open(path, "w") as fh:
+        fh.write("TLMDUMP 1\nN %d\n" % csr.n_nodes)
+        deg = np.diff(csr.row_ptr.astype(np.int64))
+        for i in range(csr.n_nodes):
+            fh.write("n %d %d %d %d %s\n" % (i, csr.node_anchor[i], csr.node_len[i], deg[i], g.node_name(i)))
+        fh.write("A %d\n" % csr.n_adj)
+        for row in G.csr_as_dump_rows(csr):
+            fh.write("a " + " ".join(str(int(x)) for x in row) + "\n")
+        fh.write("U %d\n" % len(paths))
+        for i in range(len(paths)):
+            length, nodes, slots = paths.path(i)
+            fh.write("p %d %d %s %s\n" % (length, len(nodes), " ".join(map(str, nodes)), " ".join(map(str, slots))))
+
+
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+def test_cli_scaffold_end_to_end(binary, name):
+    """PAF in -> scaffold FASTA out on the GPU host program; expected = the (reference-validated, see
+    test_host_post_stages.py) host stages applied to the oracle's per-walk-seeded paths."""
+    from telomeri_amd import synth
+    import helpers as H
+    meta = G.load_json(name + ".json")
+    fp, wp = G.args_to_params(meta["args"])
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    post = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_post")
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
+        reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
+        synth.write_fasta(ds, reads, contigs)
+        out = os.path.join(tmp, "gpu.fa")
+        res = subprocess.run([binary] + _flags(meta["args"]) + [rr, cr, reads, contigs, out], capture_output=True, text=True,
+                             timeout=300)
+        g = po.Graph()
+        assert g.load_paf(rr, False, fp) and g.load_paf(cr, True, fp)
+        osets = [g.walk_mc(m, wp, po.SEED_PER_WALK)[0] for m in (po.METRIC_ES, po.METRIC_OS)] + [g.walk_det(m)[0] for m in (0, 1)]
+        ouniq = po.filter_unique(po.concat_paths(osets))
+        dump = os.path.join(tmp, "oracle.dump")
+        _write_dump(dump, g, g.csr(), ouniq)
+        want = os.path.join(tmp, "want.fa")
+        exp = subprocess.run([post, dump, reads, contigs, want], capture_output=True, text=True, timeout=120)
+        assert res.returncode == exp.returncode, res.stderr + exp.stderr
+        if exp.returncode == 0:
+            assert open(out, "rb").read() == open(want, "rb").read()
+            pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Consensus length", "Final consensus", "ctg", "read"))]
+            assert pick(res.stdout) == pick(exp.stdout)
+
+
 def test_cli_error_conventions(binary):
     res = subprocess.run([binary, "/nonexistent/rr.paf", "/nonexistent/cr.paf", "a", "b", "c"], capture_output=True, text=True)
     assert res.returncode == 1 and "Cannot open file: /nonexistent/rr.paf" in res.stderr
@@ -97,8 +145,8 @@ def test_bundled_fixture_through_cli(binary):
         empty = os.path.join(tmp, "empty.paf")
         open(empty, "w").close()
         for key, flags in (("avg", []), ("min", ["--filter-min"]), ("max", ["--filter-max"])):
-            res = subprocess.run([binary] + flags + ["--rb-att", "20", empty, paf, "r", "c", "o"], capture_output=True,
-                                 text=True, timeout=300)
+            res = subprocess.run([binary] + flags + ["--no-scaffold", "--rb-att", "20", empty, paf, "r", "c", "o"],
+                                 capture_output=True, text=True, timeout=300)
             assert res.returncode == 0, res.stderr
             assert "Loaded %d/24127 edges" % known[key]["kept"] in res.stdout
             assert "-  anchor: 3" in res.stdout

@@ -1,0 +1,112 @@
+"""SURVEY.md §8f rows 3-4 (host logic, no GPU): grouping, consensus, scaffold-path chaining and the Scaffolder of the
+C++ host (telomeri_amd/host: consensus.cpp, scaffolder.cpp, pipeline.cpp), run by `telomeri_post` on the reference's
+own filtered path list (the `U` section of a ref_dump file), must write the reference's scaffold FASTA byte for byte
+and report the reference's groups.
+  * golden: tests/golden/<set>.json holds what the unmodified reference program wrote for the committed inputs;
+  * live (only where oracle/_ref exists): fresh datasets and grouping parameters."""
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import golden_util as G
+import helpers as H
+from oracle import pyoracle as po
+from telomeri_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POST = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_post")
+
+
+@pytest.fixture(scope="module")
+def post():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "telomeri_amd", "host")], check=True)
+    return POST
+
+
+def _dataset(name):
+    return H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+
+
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+def test_scaffold_and_groups_against_golden(post, name):
+    meta = G.load_json(name + ".json")
+    ds = _dataset(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        dump = G.gunzip_to(tmp, name + ".dump.gz")
+        reads, contigs, out = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "out.fa")
+        synth.write_fasta(ds, reads, contigs)
+        res = subprocess.run([post, dump, reads, contigs, out], capture_output=True, text=True, timeout=120)
+        want = meta["scaffold"]
+        assert res.returncode == want["exit"], res.stderr
+        body = open(out, "rb").read()
+        assert len(body) == want["bytes"] and hashlib.md5(body).hexdigest() == want["md5"]
+        chain = [ln for ln in res.stdout.splitlines() if ln.startswith(("ctg", "read")) and "-" in ln]
+        assert hashlib.md5(chain[-1].encode()).hexdigest() == want["chain_md5"]
+        got_lines = [ln for ln in res.stdout.splitlines() if ln.startswith(("Consensus length", "Final consensus"))]
+        assert got_lines == want["consensus_lines"]
+        for params, report in meta["groups"].items():
+            g_out = os.path.join(tmp, "groups.txt")
+            subprocess.run([post, "--groups", g_out] + params.split() + [dump, "x", "y", "z"], check=True, capture_output=True)
+            assert open(g_out).read() == report, params
+
+
+live = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+@live
+@pytest.mark.parametrize("seed,args", [(41, ["--rb-att", "50"]), (42, ["--filter-min", "--rb-att", "40", "--bt-att", "4"]),
+                                       (43, ["--rb-att", "70", "--w-size", "300"])])
+def test_scaffold_against_live_reference(post, seed, args):
+    ds = synth.make_dataset("fresh", seed=seed, genome_len=220_000, n_contigs=3, contig_len=32_000, n_reads=300,
+                            read_len_lo=4_000, read_len_hi=12_000)
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = os.path.join(tmp, "rr.paf"), os.path.join(tmp, "cr.paf")
+        reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
+        synth.write_paf(ds, ds.rr, rr)
+        synth.write_paf(ds, ds.cr, cr)
+        synth.write_fasta(ds, reads, contigs, seed=seed)
+        ref_out, my_out, dump = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "mine.fa"), os.path.join(tmp, "d.dump")
+        ref = subprocess.run([po.REF_MAIN] + args + [rr, cr, reads, contigs, ref_out], capture_output=True, text=True)
+        walk_args = list(args)
+        if "--w-size" in walk_args:         # a grouping parameter only: the dump driver takes it with --groups
+            k = walk_args.index("--w-size")
+            del walk_args[k:k + 2]
+        subprocess.run([po.REF_DUMP] + walk_args + [rr, cr, dump], check=True, stdout=subprocess.DEVNULL)
+        post_args = []
+        if "--w-size" in args:
+            post_args = ["--w-size", args[args.index("--w-size") + 1]]
+        mine = subprocess.run([post] + post_args + [dump, reads, contigs, my_out], capture_output=True, text=True)
+        assert mine.returncode == ref.returncode
+        if ref.returncode == 0:
+            assert open(my_out, "rb").read() == open(ref_out, "rb").read()
+            pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Consensus length", "Final consensus", "ctg", "read", "===="))]
+            assert pick(mine.stdout) == pick(ref.stdout)
+        for gp in (("1500", "400", "0.9"), ("300", "100", "0.6")):
+            gd, mg = os.path.join(tmp, "g.dump"), os.path.join(tmp, "g.mine")
+            subprocess.run([po.REF_DUMP] + walk_args + ["--no-graph", "--groups", *gp, rr, cr, gd], check=True, stdout=subprocess.DEVNULL)
+            subprocess.run([post, "--groups", mg, *gp, dump, "x", "y", "z"], check=True, capture_output=True)
+            txt = open(gd).read()
+            assert open(mg).read() == txt[txt.index("\nG ") + 1:]
+
+
+def test_scaffolder_fastq_and_single_node(post):
+    """FASTQ input (two skipped lines per record, Scaffolder.cpp:13,33-36) gives the same scaffold as FASTA."""
+    meta = G.load_json("tiny.json")
+    ds = synth.make_config("tiny")
+    with tempfile.TemporaryDirectory() as tmp:
+        dump = G.gunzip_to(tmp, "tiny.dump.gz")
+        reads, contigs, out = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "out.fa")
+        synth.write_fasta(ds, reads, contigs)
+        fq = os.path.join(tmp, "reads.fastq")
+        with open(reads) as fi, open(fq, "w") as fo:
+            lines = fi.read().splitlines()
+            for i in range(0, len(lines), 2):
+                fo.write("@%s some comment\n%s\n+\n%s\n" % (lines[i][1:], lines[i + 1], "I" * len(lines[i + 1])))
+        res = subprocess.run([post, dump, fq, contigs, out], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["scaffold"]["md5"]
+        res = subprocess.run([post, dump, os.path.join(tmp, "missing.fa"), contigs, out], capture_output=True, text=True)
+        assert res.returncode == 1 and "Cannot open file" in res.stderr
