@@ -322,7 +322,7 @@ __global__ void padded_degree_kernel(uint32_t n_nodes, const uint32_t *__restric
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_nodes) {
         const uint32_t o = old_of_new[i];
-        pd[i] = (row_ptr[o + 1] - row_ptr[o] + 3u) & ~3u;
+        pd[i] = (row_ptr[o + 1] - row_ptr[o] + 7u) & ~7u;      // rows start on 64-byte boundaries
     }
 }
 
@@ -343,14 +343,16 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
     for (uint32_t node = wave; node < n_nodes; node += n_waves) {     // node = index in walk order
         const uint32_t o = old_of_new[node];
         const uint32_t r0 = row_ptr[o], deg = row_ptr[o + 1] - r0, w0 = w_start[node];
-        const uint32_t pdeg = (deg + 3u) & ~3u;
+        const uint32_t pdeg = (deg + 7u) & ~7u;
         bool anchor_nbr = false;        // does the list hold an anchor?  (bit 28: the forced-anchor test can be skipped)
         for (uint32_t j = lane; j < deg; j += 64) anchor_nbr |= (ent_es[r0 + j].x >> 31) != 0;
         const uint32_t fl = (uint32_t) node_flags[o] | (__ballot(anchor_nbr) ? 16u : 0u);
         if (lane == 0) w_row[node] = make_uint2(w0, deg | (fl << 24));
         for (uint32_t j = lane; j < pdeg; j += 64) {
             const bool real = j < deg;
-            uint2 es = make_uint2(0u, 0u), os = make_uint2(0u, 0u);
+            // padding names the row's own node: visited whenever a Monte-Carlo walk stands on it, so the walk kernel
+            // needs no validity test per entry (no anchor bit, metric 0)
+            uint2 es = make_uint2(node, 0u), os = make_uint2(node, 0u);
             if (real) {
                 es = ent_es[r0 + j];
                 os = ent_os[r0 + j];
@@ -467,7 +469,7 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
         uint64_t apad = 0;
         if (N) {
-            TLM_CHECK(g->n_adj + 3ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
+            TLM_CHECK(g->n_adj + 7ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
             hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, g->w_old_of_new,
                                pd.as<uint32_t>());
             size_t tb = 0;
@@ -488,7 +490,7 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         TLM_HIP(hipMalloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2)));
         TLM_HIP(hipMalloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2)));
         TLM_HIP(hipMalloc((void **) &g->w_qt, (apad + 256) * sizeof(uint2)));
-        // 256 zero entries of slack after the last row: a lane's 4-entry read never leaves the buffer
+        // 256 zero entries of slack after the last row: a lane's 8-entry read never leaves the buffer
         TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
         TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
         if (N) {

@@ -5,6 +5,28 @@ namespace {
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
 
+// Kernel arguments that only the start and the end of a walk need (work cursor, anchor tables, unit records, arena ...)
+// are read from the kernarg segment where they are used, through a pointer the optimiser cannot see through: loads
+// from it cannot be hoisted above the walk loop, so they do not occupy scalar registers while a walk is stepping.
+// WalkArgs is the only kernel parameter (offset 0 of the segment).
+typedef __attribute__((address_space(4))) const WalkArgs ColdArgs;
+__device__ __forceinline__ ColdArgs *cold_args() {
+    uint64_t p = (uint64_t) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (ColdArgs *) p;
+}
+
+// What the step loop itself reads (stays in scalar registers for the whole walk).
+struct HotArgs {
+    const uint2 *rows;
+    const uint2 *ents;
+    const uint2 *qt;
+    uint32_t cap;
+    uint32_t flag_bit;
+    int32_t backtrack_attempts;
+    int64_t len_threshold;
+};
+
 // Orders a wave's own LDS / global traffic between its lanes (lane 0 writes, all lanes read):
 // the wave executes in lockstep and its memory instructions issue in order, so this only has to
 // stop the compiler from moving accesses across it.
@@ -36,7 +58,11 @@ __device__ inline void mt_seed(uint32_t *mt, int lane, uint32_t seed) {
     wave_sync();    // LDS is ordered per wave; this only keeps the compiler from caching or moving the accesses
 }
 
-__device__ inline void mt_twist(uint32_t *mt, int lane) {
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// A real call (every 312 draws): its registers and address arithmetic stay out of the step loop.  Arguments by value,
+// the state pointer typed as LDS so that the body keeps ds_* instructions.
+__device__ __noinline__ void mt_twist(lds_u32 *mt, int lane) {
     // In-place regeneration in chunks of 64 words.  Word i needs old mt[i], old mt[i+1] and
     // mt[(i+397)%624], which is an OLD word for i < 227 (it lies >= 6 chunks ahead) and a NEW word
     // for i >= 227 (it lies >= 3 chunks behind); word 623 needs the new mt[0].  Within a chunk all
@@ -66,7 +92,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // clamped below 1.  The index is always even, so a pair never straddles a twist.
 __device__ inline double mt_canonical(uint32_t *mt, int &idx, int lane) {
     if (idx >= 624) {
-        mt_twist(mt, lane);
+        mt_twist((lds_u32 *) mt, lane);
         idx = 0;
     }
     const uint32_t y0 = mt_temper(mt[idx]), y1 = mt_temper(mt[idx + 1]);
@@ -100,8 +126,8 @@ __device__ __forceinline__ bool visited_test(const Visited &v, uint32_t n) {    
     return d < WIN_BITS ? ((v.win[d >> 5] >> (d & 31u)) & 1u) != 0 : bm_test(v.bm, n);
 }
 
-__device__ __forceinline__ int64_t edge_delta(const WalkArgs &a, uint32_t e) {
-    const uint2 qt = a.qt[e];
+__device__ __forceinline__ int64_t edge_delta(const uint2 *qt_tab, uint32_t e) {
+    const uint2 qt = qt_tab[e];
     return (int64_t) qt.x - (int64_t) qt.y;                    // Path.cpp:14
 }
 
@@ -120,6 +146,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double v) {   // lanes without a source read 0.0
+    if (ROW_MASK == 0xf) {      // every row written: bound_ctrl supplies the zeros, no `old` register to initialise
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
@@ -179,22 +210,25 @@ struct WaveScratch {
 };
 
 // End of a walk: publish the unit's outcome, copy an accepted path into the arena, clear the bitmap.
-__device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int lane, uint32_t ui, uint8_t status,
-                                   uint32_t m, uint32_t nlog, int64_t len_final, uint32_t steps, uint64_t evals,
-                                   uint32_t draws) {
+__device__ inline void finish_unit(const WaveScratch &ws, int lane, uint32_t ui, uint8_t status, uint32_t m,
+                                   uint32_t nlog, int64_t len_final, uint32_t steps, uint64_t evals, uint32_t draws) {
+    ColdArgs *ca = cold_args();
     const uint32_t n_out = m + 1;
     uint64_t off = 0;
     if (status == ST_ACCEPTED) {
         unsigned long long o = 0;
-        if (lane == 0) o = atomicAdd(reinterpret_cast<unsigned long long *>(a.cursor + 2), (unsigned long long) n_out);
+        if (lane == 0) o = atomicAdd(reinterpret_cast<unsigned long long *>(ca->cursor + 2), (unsigned long long) n_out);
         off = __shfl(o, 0);
-        if (off + n_out > a.ar_cap) {
+        if (off + n_out > ca->ar_cap) {
             status = ST_ARENA_OVF;
         } else {
+            uint2 *arena = ca->arena;
+            const uint32_t *old_of_new = ca->old_of_new;
+            const uint2 *rows = ca->rows;
             for (uint32_t i = lane; i < n_out; i += 64) {
                 const uint32_t node = ws.pn[i];
-                a.arena[off + i] = make_uint2(a.old_of_new[node],                     // reference index
-                                              (i < m) ? (ws.pe[i] - a.rows[node].x) : 0xFFFFFFFFu);
+                arena[off + i] = make_uint2(old_of_new[node],                         // reference index
+                                            (i < m) ? (ws.pe[i] - rows[node].x) : 0xFFFFFFFFu);
             }
         }
     }
@@ -207,7 +241,7 @@ __device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int
         u.steps = steps;
         u.draws = draws;
         u.status = status;
-        a.units[ui] = u;
+        ca->units[ui] = u;
     }
     for (uint32_t i = lane; i < nlog; i += 64) ws.bm[ws.lg[i] >> 5] = 0u;
     wave_sync();
@@ -216,15 +250,20 @@ __device__ inline void finish_unit(const WalkArgs &a, const WaveScratch &ws, int
 // ---------------------------------------------------------------------------------------------
 // One Monte-Carlo trial: PathManager.cpp:30-160.
 //
-// The selection scan of one step (:53-115) on a wave, BLOCKED layout: a chunk is 256 consecutive
-// entries and lane l owns entries 4l..4l+3 of it (two aligned 16-byte loads: rows are padded to 4
-// entries).  List order is lane-major, so the prefix of entry (l, k) is
-//     [sum of earlier chunks] + [exclusive wave scan of the lane totals](l) + [running sum inside lane l],
-// i.e. ONE 64-lane scan per 256 entries, the rest is lane-local.  On a safe node (all metrics >= 0,
-// every partial sum exact in a double -- node flag from the graph build) any association of the
-// additions gives the reference's bits, and the non-decreasing prefix lets the second pass
-// (:107-114) look only at the one lane whose range contains `random`.  Unsafe nodes take
+// The selection scan of one step (:53-115) on a wave, BLOCKED layout: lane l owns K consecutive
+// entries K*l .. K*l+K-1 of the list (K/2 aligned 16-byte loads: rows start on 64-byte boundaries and
+// are padded to 8 entries), K = 4 for lists up to 256 entries, K = 8 up to 512.  List order is
+// lane-major, so the prefix of entry (l, k) is
+//     [exclusive wave scan of the lane totals](l) + [running sum inside lane l],
+// i.e. ONE 64-lane scan per step, everything else is lane-local and the list is read once.  On a safe
+// node (all metrics >= 0, every partial sum exact in a double -- node flag from the graph build) any
+// association of the additions gives the reference's bits, and the non-decreasing prefix lets the
+// second pass (:107-114) look only at the one lane whose range contains `random`.  Unsafe nodes take
 // select_serial, which adds one candidate after the other in list order.
+//
+// No per-entry validity tests: row padding entries name the row's own node (visited while the walk
+// stands on it, so never a candidate; anchor bit clear, metric 0), and lanes past the end of the list
+// re-read the list's first entries and have their sum forced to zero.
 
 struct Selection {
     int pick;            // position in the list, -1 = none
@@ -242,13 +281,13 @@ __device__ __forceinline__ double metric_f64(uint32_t bits) {
     return (double) mf;
 }
 
-struct Chunk {           // one lane's 4 entries of a 256-entry chunk
+struct Chunk {           // one lane's 4 entries of a 256-entry chunk (deterministic kernel, backtracking)
     uint32_t nb[4];      // neighbour | anchor << 31
     uint32_t mb[4];      // fp32 bits of the metric
 };
 
 __device__ __forceinline__ Chunk load_chunk(const uint2 *ents, uint32_t row, uint32_t base, uint32_t deg, int lane) {
-    // row is a multiple of 4 entries and so is base + 4*lane: 32-byte aligned, two dwordx4 loads.  Lanes whose four
+    // row is a multiple of 8 entries and base + 4*lane of 4: 32-byte aligned, two dwordx4 loads.  Lanes whose four
     // entries all lie past the degree load nothing; inside a lane, entries past the degree are row padding, masked
     // by position and never used.
     Chunk c;
@@ -264,98 +303,146 @@ __device__ __forceinline__ Chunk load_chunk(const uint2 *ents, uint32_t row, uin
     return c;
 }
 
-// forced anchor edge inside one chunk: the first entry, in list order, whose neighbour is an anchor other than
-// `start` (:57-60).  Returns its position inside the chunk (lane*4+k) or -1.
-__device__ __forceinline__ int forced_in_chunk(const Chunk &c, uint32_t base, uint32_t deg, uint32_t start, int lane,
-                                               uint32_t &nbr_out) {
+// K consecutive entries per lane starting at list position base + K*lane; lanes past the end of the list (`act`
+// false) re-read the chunk's first entries (same cache line as lane 0) -- their sums are forced to zero below.
+template <int K>
+__device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint32_t base, uint32_t deg, int lane,
+                                          uint32_t (&nb)[K], uint32_t (&mb)[K]) {
+    const uint32_t first = base + (uint32_t) K * (uint32_t) lane;
+    const bool act = first < deg;
+    const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + (act ? first : base));
+#pragma unroll
+    for (int j = 0; j < K / 2; j++) {
+        const uint4 v = p[j];
+        nb[2 * j] = v.x; mb[2 * j] = v.y; nb[2 * j + 1] = v.z; mb[2 * j + 1] = v.w;
+    }
+    return act;
+}
+
+// forced anchor edge: the first entry, in list order, whose neighbour is an anchor other than `start` (:57-60).
+// Returns its position relative to the chunk (lane*K+k) or -1.  Padding entries carry no anchor bit; an inactive
+// lane repeats lane 0's entries, and lane 0 wins the find-first.
+template <int K>
+__device__ __forceinline__ int forced_in_lanes(const uint32_t (&nb)[K], uint32_t start, uint32_t &nbr_out) {
     int best = -1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
-        const uint64_t fm = __ballot(i < deg && (c.nb[k] >> 31) && (c.nb[k] & 0x7FFFFFFFu) != start);
+    for (int k = 0; k < K; k++) {
+        const uint64_t fm = __ballot((nb[k] >> 31) && (nb[k] & 0x7FFFFFFFu) != start);
         if (fm) {
             const int fl = __ffsll((unsigned long long) fm) - 1;
-            const int pos = fl * 4 + k;
+            const int pos = fl * K + k;
             if (best < 0 || pos < best) {
                 best = pos;
-                nbr_out = readlane_u32(c.nb[k], fl) & 0x7FFFFFFFu;
+                nbr_out = readlane_u32(nb[k], fl) & 0x7FFFFFFFu;
             }
         }
     }
     return best;
 }
 
-// One lane's view of a chunk after the visited test: metric of each candidate, -1 for "not a candidate"
-// (safe nodes have no negative metrics), and the lane's sum.
-template <bool SQRT>
-__device__ __forceinline__ bool lane_candidates(const Chunk &c, const Visited &vs, uint32_t base, uint32_t deg, int lane,
-                                                double (&mv)[4], double &lane_sum) {
-    bool has = false;
-    lane_sum = 0.0;
-    uint32_t w[4];
-    bool far = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {       // probes inside the LDS band
-        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
-        const uint32_t d = (c.nb[k] & 0x7FFFFFFFu) - vs.lo;
-        const bool in = i < deg;
+// visited masks of a lane's K entries (all ones = visited): K LDS reads in flight at once, no branches.  The anchor
+// bit is left in the id on purpose: such an entry lands outside the band and takes the exact path below, as does
+// every id that really lies outside the band.
+template <int K>
+__device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&nb)[K], uint32_t (&vis)[K]) {
+    uint32_t any = 0u;
 #ifdef TLM_ABLATE_NOBM      /* timing-only build: no visited probes (results are wrong) */
-        w[k] = in ? 0u : 1u;
+#pragma unroll
+    for (int k = 0; k < K; k++) vis[k] = 0u;
+    (void) any;
 #else
-        w[k] = !in ? 1u : d < WIN_BITS ? (vs.win[d >> 5] >> (d & 31u)) & 1u : 2u;      // 2 = look in HBM
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t d = nb[k] - vs.lo;
+        any |= d;
+        vis[k] = vs.win[(d >> 5) & (WIN_WORDS - 1u)];                 // always inside the band's words
+    }
+    // bit (id - lo) & 31 == id & 31 (lo is a multiple of 32; v_bfe_i32 reads 5 bits of the offset): 0 or all ones
+#pragma unroll
+    for (int k = 0; k < K; k++) vis[k] = (uint32_t) __builtin_amdgcn_sbfe((int) vis[k], nb[k], 1u);
+    if (__ballot(any >= WIN_BITS)) {    // rare: an anchor neighbour, or a neighbour outside the band
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (nb[k] - vs.lo >= WIN_BITS) vis[k] = visited_test(vs, nb[k] & 0x7FFFFFFFu) ? ~0u : 0u;
+    }
 #endif
-        far |= w[k] == 2u;
-    }
-    if (__ballot(far)) {                // rare: a neighbour outside the band
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (w[k] == 2u) w[k] = bm_test(vs.bm, c.nb[k] & 0x7FFFFFFFu) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool cand = w[k] == 0u;                                                // :63
-        mv[k] = cand ? metric_f64<SQRT>(c.mb[k]) : -1.0;
-        if (cand) {
-            lane_sum += mv[k];                                                       // :64
-            has = true;
-        }
-    }
-    return has;
 }
 
-// The hit lies in lane `hl` (its inclusive prefix reached `random`, the one before did not): find the first
-// candidate k of that lane whose prefix reaches `random` (:108-113) and report it.
-__device__ __forceinline__ void resolve_in_lane(Selection &s, const Chunk &c, const double (&mv)[4], double excl,
-                                                double random, uint32_t base, int hl) {
-    // running prefix inside the lane (every sum is exact on a safe node)
-    const double p0 = excl + (mv[0] >= 0.0 ? mv[0] : 0.0);
-    const double p1 = p0 + (mv[1] >= 0.0 ? mv[1] : 0.0);
-    const double p2 = p1 + (mv[2] >= 0.0 ? mv[2] : 0.0);
-    const double p3 = p2 + (mv[3] >= 0.0 ? mv[3] : 0.0);
-    const int myk = (mv[0] >= 0.0 && p0 >= random) ? 0                              // :110, first k wins
-                    : (mv[1] >= 0.0 && p1 >= random) ? 1
-                    : (mv[2] >= 0.0 && p2 >= random) ? 2
-                    : (mv[3] >= 0.0 && p3 >= random) ? 3 : -1;
+// Selection among the K*64 entries held in registers.  `mb` arrives masked (0 where the entry is not a candidate),
+// `va` is the AND of the lane's visited masks (all ones = no candidate in this lane).
+template <int K, bool SQRT>
+__device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, uint32_t *mt, int &mti, int lane,
+                                               uint32_t base, bool act, const uint32_t (&nb)[K], const uint32_t (&mb)[K],
+                                               uint32_t va, uint32_t &draws) {
+    double ls = metric_f64<SQRT>(mb[0]);
+#pragma unroll
+    for (int k = 1; k < K; k++) ls += metric_f64<SQRT>(mb[k]);                     // :64
+    if (!act) ls = 0.0;
+#ifdef TLM_ABLATE_NOSCAN    /* timing-only build: no prefix scan (results are wrong) */
+    const double incl = ls * (double) (lane + 1);
+#else
+    const double incl = wave_incl_scan_f64(ls);
+#endif
+    const double total = readlane_f64(incl, 63);
+    const bool has = act && va != ~0u;
+    if (total == 0.0) {                                                            // dead end, or candidates of metric 0
+        if (!__ballot(has)) return;                                                // :72
+    }
+    s.ncand = 1;
+    const double random = mt_canonical(mt, mti, lane) * total;                     // :104
+    draws++;
+    int hl, myk = K - 1;
+    uint32_t mynb = nb[K - 1];
+    if (random == 0.0) {
+        // `sum >= 0` holds at the first candidate of the list (:110); rare enough to probe again
+        hl = __ffsll((unsigned long long) __ballot(has)) - 1;
+        uint32_t vis[K];
+        lane_probe<K>(vs, nb, vis);
+#pragma unroll
+        for (int k = K - 2; k >= 0; k--)
+            if (vis[k] == 0u) {
+                myk = k;
+                mynb = nb[k];
+            }
+    } else {
+        // the first lane whose inclusive prefix reaches `random` holds the hit; inside it the first entry whose
+        // running prefix reaches it.  Entries that are not candidates add +0 and so never are the first to reach it.
+        const uint64_t hm = __ballot(incl >= random);
+        if (!hm) return;                               // not reachable for finite sums (u < 1)
+        hl = __ffsll((unsigned long long) hm) - 1;
+        double pk[K - 1];
+        double p = incl - ls;                           // exclusive prefix of the lane (exact)
+#pragma unroll
+        for (int k = 0; k < K - 1; k++) {
+            p += metric_f64<SQRT>(mb[k]);               // :109
+            pk[k] = p;
+        }
+#pragma unroll
+        for (int k = K - 2; k >= 0; k--)
+            if (pk[k] >= random) {                      // :110, first k wins
+                myk = k;
+                mynb = nb[k];
+            }
+    }
     const int k = __builtin_amdgcn_readlane(myk, hl);
-    const uint32_t e0 = readlane_u32(c.nb[0], hl), e1 = readlane_u32(c.nb[1], hl);
-    const uint32_t e2 = readlane_u32(c.nb[2], hl), e3 = readlane_u32(c.nb[3], hl);
-    const uint32_t e = k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
-    s.pick = (int) base + hl * 4 + k;
+    const uint32_t e = readlane_u32(mynb, hl);
+    s.pick = (int) base + hl * K + k;
     s.nbr = e & 0x7FFFFFFFu;
     s.anchor = (e >> 31) != 0;
 }
 
-template <bool SQRT>
-__device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Visited &vs, uint32_t *mt, int &mti,
-                                                    double *after, int lane, uint32_t row, uint32_t deg, uint32_t start,
-                                                    bool anchor_nbr, uint32_t &draws) {
+// A list of at most 64*K entries: one load, one visited probe, ONE scan (it yields the total and every lane's
+// prefix), no second pass over memory.
+template <int K, bool SQRT>
+__device__ __forceinline__ Selection select_short(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, int lane,
+                                                  uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
+                                                  uint32_t &draws) {
     Selection s{-1, 0u, false, false, 0u, deg};
-    if (deg <= 256u) {
-        // the whole list in one chunk: one load, one visited probe, ONE scan (it yields the total and every
-        // lane's prefix), no second pass over memory
-        const Chunk c = load_chunk(a.ents, row, 0u, deg, lane);
+    uint32_t nb[K], mb[K], vis[K];
+    const bool act = lane_load<K>(a.ents, row, 0u, deg, lane, nb, mb);
+    if (anchor_nbr) {
         uint32_t fn = 0;
-        const int fpos = anchor_nbr ? forced_in_chunk(c, 0u, deg, start, lane, fn) : -1;
+        const int fpos = forced_in_lanes<K>(nb, start, fn);
         if (fpos >= 0) {
             s.pick = fpos;
             s.nbr = fn;
@@ -363,53 +450,72 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Vis
             s.evals = (uint32_t) fpos + 1u;
             return s;
         }
-        double mv[4], lane_sum;
-        const bool has = lane_candidates<SQRT>(c, vs, 0u, deg, lane, mv, lane_sum);
-        if (!__ballot(has)) return s;                                               // :72 dead end
-        s.ncand = 1;
-#ifdef TLM_ABLATE_NOSCAN    /* timing-only build: no prefix scan (results are wrong) */
-        const double incl = lane_sum * (double) (lane + 1);
-#else
-        const double incl = wave_incl_scan_f64(lane_sum);
-#endif
-        const double random = mt_canonical(mt, mti, lane) * readlane_f64(incl, 63);  // :104
-        draws++;
-        const uint64_t hm = __ballot(has && incl >= random);
-        if (hm) resolve_in_lane(s, c, mv, incl - lane_sum, random, 0u, __ffsll((unsigned long long) hm) - 1);
-        return s;
     }
-    // ---- longer lists, pass 1 (:53-67): total over the unvisited neighbours, chunk after chunk.  The running sum
-    // after each of the first AFTER_SLOTS chunks is parked in LDS: the prefix is non-decreasing, so pass 2 only
-    // has to look into the one chunk where it crosses `random`.
+    lane_probe<K>(vs, nb, vis);
+    uint32_t va = ~0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        mb[k] &= ~vis[k];
+        va &= vis[k];
+    }
+    select_in_regs<K, SQRT>(s, vs, mt, mti, lane, 0u, act, nb, mb, va, draws);
+    return s;
+}
+
+template <bool SQRT>
+__device__ Selection select_serial(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, int lane, uint32_t row,
+                                   uint32_t deg, uint32_t start, uint32_t &draws, bool have_u, double u_given);
+
+// Lists longer than 512 entries, chunks of 512.  Pass 1 (:53-67): total over the unvisited neighbours; the running
+// sum after each of the first AFTER_SLOTS chunks is parked in LDS: the prefix is non-decreasing, so pass 2
+// (:107-114) only has to look into the one chunk where it crosses `random`.
+template <bool SQRT>
+__device__ Selection select_long(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, double *after,
+                                              int lane, uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
+                                              uint32_t &draws) {
+    constexpr int K = 8;
+    constexpr uint32_t C = 64u * K;
+    Selection s{-1, 0u, false, false, 0u, deg};
     double total = 0.0;
     uint32_t ci = 0;
-    for (uint32_t base = 0; base < deg; base += 256, ci++) {
-        const Chunk c = load_chunk(a.ents, row, base, deg, lane);
-        uint32_t fn = 0;
-        const int fpos = anchor_nbr ? forced_in_chunk(c, base, deg, start, lane, fn) : -1;
-        if (fpos >= 0) {
-            s.pick = (int) base + fpos;
-            s.nbr = fn;
-            s.anchor = s.forced = true;
-            s.evals = (uint32_t) s.pick + 1u;
-            return s;
+    bool any_cand = false;
+    for (uint32_t base = 0; base < deg; base += C, ci++) {
+        uint32_t nb[K], mb[K], vis[K];
+        const bool act = lane_load<K>(a.ents, row, base, deg, lane, nb, mb);
+        if (anchor_nbr) {
+            uint32_t fn = 0;
+            const int fpos = forced_in_lanes<K>(nb, start, fn);
+            if (fpos >= 0) {
+                s.pick = (int) base + fpos;
+                s.nbr = fn;
+                s.anchor = s.forced = true;
+                s.evals = (uint32_t) s.pick + 1u;
+                return s;
+            }
         }
-        double mv[4], lane_sum;
-        const bool has = lane_candidates<SQRT>(c, vs, base, deg, lane, mv, lane_sum);
-        if (__ballot(has)) {
-            total += readlane_f64(wave_incl_scan_f64(lane_sum), 63);
-            s.ncand = 1;
+        lane_probe<K>(vs, nb, vis);
+        double ls = 0.0;
+        uint32_t va = ~0u;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            ls += metric_f64<SQRT>(mb[k] & ~vis[k]);
+            va &= vis[k];
         }
+        if (!act) ls = 0.0;
+        if (__ballot(act && va != ~0u)) any_cand = true;
+        total += readlane_f64(wave_incl_scan_f64(ls), 63);
         if (ci < AFTER_SLOTS && lane == 0) after[ci] = total;
     }
-    if (s.ncand == 0) return s;
+    if (!any_cand) return s;                                                        // :72 dead end
+    s.ncand = 1;
     wave_sync();                                                                    // `after` is read by every lane below
-    const double random = mt_canonical(mt, mti, lane) * total;                      // :104
+    const double u = mt_canonical(mt, mti, lane);
     draws++;
-    // ---- pass 2 (:107-114): the first candidate whose inclusive prefix reaches `random`
+    const double random = u * total;                                                // :104
+    if (random == 0.0) return select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws, true, u);
     double carry = 0.0;
     ci = 0;
-    for (uint32_t base = 0; base < deg; base += 256, ci++) {
+    for (uint32_t base = 0; base < deg; base += C, ci++) {
         if (ci < AFTER_SLOTS) {
             const double closing = after[ci];
             if (closing < random) {          // the hit is further down the list
@@ -417,26 +523,53 @@ __device__ __forceinline__ Selection select_blocked(const WalkArgs &a, const Vis
                 continue;
             }
         }
-        const Chunk c = load_chunk(a.ents, row, base, deg, lane);
-        double mv[4], lane_sum;
-        const bool has = lane_candidates<SQRT>(c, vs, base, deg, lane, mv, lane_sum);
-        if (!__ballot(has)) continue;
-        const double incl = wave_incl_scan_f64(lane_sum) + carry;
-        carry = readlane_f64(incl, 63);
-        const uint64_t hm = __ballot(has && incl >= random);
-        if (hm) {
-            resolve_in_lane(s, c, mv, incl - lane_sum, random, base, __ffsll((unsigned long long) hm) - 1);
-            return s;
+        uint32_t nb[K], mb[K], vis[K];
+        const bool act = lane_load<K>(a.ents, row, base, deg, lane, nb, mb);
+        lane_probe<K>(vs, nb, vis);
+        double ls = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            mb[k] &= ~vis[k];
+            ls += metric_f64<SQRT>(mb[k]);
         }
+        if (!act) ls = 0.0;
+        const double incl = wave_incl_scan_f64(ls) + carry;
+        carry = readlane_f64(incl, 63);
+        const uint64_t hm = __ballot(incl >= random);
+        if (!hm) continue;
+        const int hl = __ffsll((unsigned long long) hm) - 1;
+        int myk = K - 1;
+        uint32_t mynb = nb[K - 1];
+        double pk[K - 1];
+        double p = incl - ls;
+#pragma unroll
+        for (int k = 0; k < K - 1; k++) {
+            p += metric_f64<SQRT>(mb[k]);
+            pk[k] = p;
+        }
+#pragma unroll
+        for (int k = K - 2; k >= 0; k--)
+            if (pk[k] >= random) {
+                myk = k;
+                mynb = nb[k];
+            }
+        const int k = __builtin_amdgcn_readlane(myk, hl);
+        const uint32_t e = readlane_u32(mynb, hl);
+        s.pick = (int) base + hl * K + k;
+        s.nbr = e & 0x7FFFFFFFu;
+        s.anchor = (e >> 31) != 0;
+        return s;
     }
     return s;
 }
 
 // Unsafe node (a metric is negative / not finite, or the sums are not exact in a double): the additions are made
 // one candidate after the other in list order, as PathManager.cpp:64,109 makes them.  Rare; never on real overlaps.
+// `have_u`: the step's draw was already made by the caller (select_long, when u * total came out as 0).
 template <bool SQRT>
-__device__ Selection select_serial(const WalkArgs &a, const Visited &vs, uint32_t *mt, int &mti,
-                                                int lane, uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws) {
+__device__ Selection select_serial(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, int lane,
+                                                uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws, bool have_u,
+                                                double u_given) {
     Selection s{-1, 0u, false, false, 0u, deg};
     double total = 0.0;
     for (int pass = 0; pass < 2; pass++) {
@@ -444,8 +577,12 @@ __device__ Selection select_serial(const WalkArgs &a, const Visited &vs, uint32_
         double random = 0.0;
         if (pass == 1) {
             if (s.ncand == 0) return s;
-            random = mt_canonical(mt, mti, lane) * total;                            // :104
-            draws++;
+            if (have_u) {
+                random = u_given * total;
+            } else {
+                random = mt_canonical(mt, mti, lane) * total;                        // :104
+                draws++;
+            }
         }
         for (uint32_t base = 0; base < deg; base += 64) {
             const uint32_t i = base + lane;
@@ -485,11 +622,11 @@ __device__ Selection select_serial(const WalkArgs &a, const Visited &vs, uint32_
 }
 
 template <bool SQRT>
-__device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after, int lane,
-                        uint32_t ui, uint32_t start, uint32_t start_ref, uint32_t r) {
-    // `start` and every node id below are walk-order indices; start_ref is the anchor's reference index
+__device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after, int lane,
+                        uint32_t ui, uint32_t start, uint32_t seed, int64_t len0) {
+    // `start` and every node id below are walk-order indices
     int mti = 624;
-    mt_seed(mt, lane, walk_seed_dev(a.metric, start_ref, r));
+    mt_seed(mt, lane, seed);
     Visited vs;
     vs.win = win;
     vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
@@ -501,7 +638,6 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
     int64_t acc = 0;         // sum of the increments of edges 0..m-2 (all but the last pushed one)
     uint32_t pend_qs = 0, pend_ts = 0;   // q_start / t_start of the last pushed edge, in flight
     bool have_pend = false;
-    const int64_t len0 = (int64_t) a.node_len[start_ref];
     int backtracks = 0;
     uint32_t steps = 0, draws = 0;
     uint64_t evals = 0;
@@ -523,8 +659,10 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
         const bool anchor_nbr = ((rfl(rec.y) >> 28) & 1u) != 0;
         // ---- selection scan (:53-115)
-        const Selection s = safe ? select_blocked<SQRT>(a, vs, mt, mti, after, lane, row, deg, start, anchor_nbr, draws)
-                                 : select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws);
+        const Selection s = !safe        ? select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws, false, 0.0)
+                            : deg <= 256u ? select_short<4, SQRT>(a, vs, mt, mti, lane, row, deg, start, anchor_nbr, draws)
+                            : deg <= 512u ? select_short<8, SQRT>(a, vs, mt, mti, lane, row, deg, start, anchor_nbr, draws)
+                                          : select_long<SQRT>(a, vs, mt, mti, after, lane, row, deg, start, anchor_nbr, draws);
         evals += s.evals;
         steps++;
         if (s.pick < 0) {
@@ -537,7 +675,7 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
                     // pop edge m-1: it was the pending one (never added); the new last edge m-2 leaves the sum
                     m--;
                     have_pend = false;
-                    if (m >= 1) acc -= edge_delta(a, rfl(ws.pe[m - 1]));
+                    if (m >= 1) acc -= edge_delta(a.qt, rfl(ws.pe[m - 1]));
                     const uint32_t back = rfl(ws.pn[m]);
                     const uint2 brec = a.rows[back];
                     const uint32_t brow = rfl(brec.x);
@@ -584,7 +722,9 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
         // :125 -- Path::length() after this push excludes the new last edge (Path.cpp:12-15): it is len0 plus the
         // increments of all EARLIER edges.  The increment of the edge pushed in the previous step was requested
         // then (pend_*) and is only consumed here, a whole step later, so its latency is never waited for.
-        if (have_pend) acc += (int64_t) pend_qs - (int64_t) pend_ts;
+        // (readfirstlane: the compiler takes the loaded words for per-lane values, and a loop whose exit depends on
+        // them for a divergent loop -- every loop-carried scalar would then live in a vector register)
+        if (have_pend) acc += (int64_t) rfl(pend_qs) - (int64_t) rfl(pend_ts);
         const int64_t len = len0 + acc;
         {
             const uint2 qt = a.qt[eidx];
@@ -605,7 +745,7 @@ __device__ void mc_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *mt, 
     // acc holds the increments of edges 0..m-2 (the last pushed edge is still pending): exactly Path::length()
     const int64_t len_final = len0 + acc;
     if (acceptable && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :146-155
-    finish_unit(a, ws, lane, ui, status, m, nlog, len_final, steps, evals, draws);
+    finish_unit(ws, lane, ui, status, m, nlog, len_final, steps, evals, draws);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,7 +818,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     const bool second_anchor = rfl(ent0.x >> 31) != 0;
     const int64_t len0 = (int64_t) a.node_len[start_ref];
     uint32_t m = 1, nlog = 0;           // nlog: marks that went to the HBM map
-    int64_t acc = edge_delta(a, first);
+    int64_t acc = edge_delta(a.qt, first);
     uint32_t steps = 0;
     uint64_t evals = 0;
     uint8_t status = ST_ABANDONED;
@@ -760,7 +900,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 step_index -= 1;
                 skip_n_best += 1;
                 m--;                                        // pop node + edge
-                acc -= edge_delta(a, rfl(ws.pe[m]));
+                acc -= edge_delta(a.qt, rfl(ws.pe[m]));
                 node = rfl(ws.pn[m]);
                 if (lane == 0) visited_clear(vs, node);     // :262,284,335
                 wave_sync();
@@ -801,7 +941,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 if (far_mark) ws.lg[nlog] = node;
             }
             if (far_mark) nlog++;
-            acc += edge_delta(a, eidx);
+            acc += edge_delta(a.qt, eidx);
             m++;
             node = chosen_nbr;                              // :356
             wave_sync();
@@ -812,9 +952,9 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
             step_index += 1;
         }
     }
-    const int64_t len_final = len0 + acc - edge_delta(a, rfl(ws.pe[m - 1]));
+    const int64_t len_final = len0 + acc - edge_delta(a.qt, rfl(ws.pe[m - 1]));
     if (all_ok && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :372-384
-    finish_unit(a, ws, lane, ui, status, m, nlog, len_final, steps, evals, 0);
+    finish_unit(ws, lane, ui, status, m, nlog, len_final, steps, evals, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -830,16 +970,18 @@ __device__ __forceinline__ WaveScratch wave_scratch(const WalkArgs &a, uint32_t 
 
 // Persistent waves: every wave pulls the next work item until the cursor passes n_work; the cursor
 // only grows, so every wave reaches its exit and the grid drains.
-__device__ __forceinline__ bool next_work(const WalkArgs &a, int lane, uint32_t &ui) {
+__device__ __forceinline__ bool next_work(int lane, uint32_t &ui) {
+    ColdArgs *ca = cold_args();
     uint32_t w = 0;
-    if (lane == 0) w = atomicAdd(a.cursor, 1u);
+    if (lane == 0) w = atomicAdd(ca->cursor, 1u);
     w = rfl(w);
-    if (w >= a.n_work) return false;
-    ui = a.work_list ? rfl(a.work_list[w]) : w;
+    if (w >= ca->n_work) return false;
+    const uint32_t *wl = ca->work_list;
+    ui = wl ? rfl(wl[w]) : w;
     return true;
 }
 
-// work item -> (metric slot, unit); returns the arguments specialised for the slot
+// work item -> (metric slot, unit); returns the arguments specialised for the slot (deterministic kernel)
 __device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, uint32_t &ui) {
     WalkArgs b = a;
     const uint32_t slot = cu >= a.n_units ? 1u : 0u;      // at most two slots
@@ -861,14 +1003,30 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
     uint32_t cu;
-    while (next_work(a, lane, cu)) {
-        uint32_t ui;
-        const WalkArgs b = slot_args(a, cu, ui);
-        const uint64_t unit = a.unit_begin + ui;
-        const uint32_t a_rank = (uint32_t) (unit / (uint64_t) a.rebuild_attempts);
-        const uint32_t r = (uint32_t) (unit % (uint64_t) a.rebuild_attempts);
-        mc_walk<SQRT>(b, ws, mt_s[wib], win_s[wib], after_s[wib], lane, cu, rfl(a.w_anchors[a_rank]),
-                      rfl(a.anchors[a_rank]), r);
+    while (next_work(lane, cu)) {
+        // work item -> (metric slot, unit) -> (anchor, trial); everything but the step loop's own arguments is read
+        // from the kernarg segment here and dropped again
+        ColdArgs *ca = cold_args();
+        const uint32_t n_units = ca->n_units;
+        const bool slot1 = cu >= n_units;                  // at most two slots
+        const uint32_t ui = cu - (slot1 ? n_units : 0u);
+        const uint64_t unit = ca->unit_begin + ui;
+        const uint64_t rb = (uint64_t) ca->rebuild_attempts;
+        const uint32_t a_rank = (uint32_t) (unit / rb);
+        const uint32_t r = (uint32_t) (unit % rb);
+        const uint32_t start = rfl(ca->w_anchors[a_rank]);
+        const uint32_t start_ref = rfl(ca->anchors[a_rank]);        // the anchor's reference index
+        const int metric = slot1 ? ca->metric1 : ca->metric;
+        HotArgs h;
+        h.rows = a.rows;
+        h.ents = slot1 ? ca->ents1 : a.ents;
+        h.qt = a.qt;
+        h.cap = a.cap;
+        h.flag_bit = slot1 ? ca->flag_bit1 : a.flag_bit;
+        h.backtrack_attempts = a.backtrack_attempts;
+        h.len_threshold = a.len_threshold;
+        const int64_t len0 = (int64_t) rfl(ca->node_len[start_ref]);
+        mc_walk<SQRT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], lane, cu, start, walk_seed_dev(metric, start_ref, r), len0);
     }
 }
 
@@ -879,7 +1037,7 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
     uint32_t cu;
-    while (next_work(a, lane, cu)) {
+    while (next_work(lane, cu)) {
         uint32_t ui;
         const WalkArgs b = slot_args(a, cu, ui);
         const uint64_t unit = a.unit_begin + ui;
