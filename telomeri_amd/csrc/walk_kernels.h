@@ -48,6 +48,7 @@ struct WalkArgs {
     const uint64_t *det_off;
     uint64_t unit_begin;
     uint32_t n_work;
+    uint32_t chunk;                 // consecutive work items that share a start anchor: dealt to one XCD's queue
     const uint32_t *work_list;      // unit - unit_begin per work item, or null = identity
     int32_t rebuild_attempts, backtrack_attempts;
     int64_t len_threshold;
@@ -56,13 +57,17 @@ struct WalkArgs {
     uint32_t cap;
     uint32_t *bitmaps;
     uint32_t bm_words;              // 32-bit words per wave
-    // work cursor at cursor[0], arena cursor (u64) at cursor[2..3]
+    // arena cursor (u64) at cursor[2..3]; one work cursor per XCD at cursor[WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * x]
     uint32_t *cursor;
     UnitOut *units;
     uint2 *arena;                   // accepted paths: {reference node, edge slot}
     uint64_t ar_cap;
 };
 
+constexpr int WALK_XCDS = 8;                    // MI355X: 8 accelerator dies, each with its own L2
+constexpr int WALK_QUEUE_BASE = 32;             // u32 index of XCD 0's work cursor; one 64-byte line per cursor
+constexpr int WALK_QUEUE_STRIDE = 16;
+constexpr int WALK_CURSOR_WORDS = WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * WALK_XCDS;
 constexpr int WALK_BLOCK = 256;                 // 4 independent waves per workgroup
 constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
 

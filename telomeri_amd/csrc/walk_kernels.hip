@@ -103,6 +103,23 @@ __device__ inline double mt_canonical(uint32_t *mt, int &idx, int lane) {
     return ret;
 }
 
+// `mt_canonical(...) * total` for a finite total >= 0 that is zero or at least 2^-900 (sums of fp32 metrics are), in
+// fewer vector instructions: y1 * 2^32 is exact, so fma(y1, 2^32, y0) rounds y0 + y1 * 2^32 once, exactly as the
+// addition above does; scaling by 2^-64 is exact and commutes with the rounding of the product, so
+// RN(sum * 2^-64 * total) == RN(sum * (total * 2^-64)).  The clamp can only bite when y1 is all ones: that case takes
+// the general function.
+__device__ __forceinline__ double mt_canonical_times(uint32_t *mt, int &idx, int lane, double total) {
+    if (idx >= 624) {
+        mt_twist((lds_u32 *) mt, lane);
+        idx = 0;
+    }
+    const uint32_t y1 = rfl(mt_temper(mt[idx + 1]));
+    if (y1 == 0xFFFFFFFFu) return mt_canonical(mt, idx, lane) * total;
+    const uint32_t y0 = mt_temper(mt[idx]);
+    idx += 2;
+    return __builtin_fma((double) y1, 4294967296.0, (double) y0) * (total * 0x1p-64);
+}
+
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
@@ -116,10 +133,15 @@ constexpr uint32_t WIN_BITS = 1u << 14;                 // 2 KB of LDS per wave
 constexpr uint32_t WIN_WORDS = WIN_BITS / 32;
 constexpr uint32_t AFTER_SLOTS = 8;                     // closing sums of the first 8 chunks (2048 entries) of a long list
 struct Visited {
-    uint32_t *win;
+    uint32_t *win;      // 2 KB-aligned in LDS
     uint32_t lo;
     uint32_t *bm;
 };
+
+// LDS byte address of the band (the low 32 bits of a generic pointer into LDS are its LDS offset)
+__device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
+    return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const uint32_t *) p;
+}
 
 __device__ __forceinline__ bool visited_test(const Visited &v, uint32_t n) {      // slow paths only
     const uint32_t d = n - v.lo;
@@ -351,11 +373,17 @@ __device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&n
     for (int k = 0; k < K; k++) vis[k] = 0u;
     (void) any;
 #else
+    const uint32_t wb = lds_addr(vs.win);                             // multiple of 2048: `|` instead of `+` (v_and_or_b32)
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const uint32_t d = nb[k] - vs.lo;
         any |= d;
-        vis[k] = vs.win[(d >> 5) & (WIN_WORDS - 1u)];                 // always inside the band's words
+        // word (d >> 5) mod 512 of the band: always inside it, whatever d is
+        // two instructions (the compiler's own form, shift + mask + or, takes three: a VOP3 cannot carry the literal)
+        static_assert(WIN_WORDS == 512u, "the bit-field width below is log2(WIN_WORDS)");
+        uint32_t addr;
+        asm("v_bfe_u32 %0, %1, 5, 9\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=v"(addr) : "v"(d), "s"(wb));
+        vis[k] = *(__attribute__((address_space(3))) const uint32_t *) (uintptr_t) addr;
     }
     // bit (id - lo) & 31 == id & 31 (lo is a multiple of 32; v_bfe_i32 reads 5 bits of the offset): 0 or all ones
 #pragma unroll
@@ -389,15 +417,20 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
         if (!__ballot(has)) return;                                                // :72
     }
     s.ncand = 1;
-    const double random = mt_canonical(mt, mti, lane) * total;                     // :104
+    const double random = mt_canonical_times(mt, mti, lane, total);                // :104
     draws++;
     int hl, myk = K - 1;
     uint32_t mynb = nb[K - 1];
     if (random == 0.0) {
         // `sum >= 0` holds at the first candidate of the list (:110); rare enough to probe again
         hl = __ffsll((unsigned long long) __ballot(has)) - 1;
-        uint32_t vis[K];
-        lane_probe<K>(vs, nb, vis);
+        uint32_t vis[K], nb2[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {       // opaque copy: nothing of the first probe is kept alive for this path
+            nb2[k] = nb[k];
+            asm volatile("" : "+v"(nb2[k]));
+        }
+        lane_probe<K>(vs, nb2, vis);
 #pragma unroll
         for (int k = K - 2; k >= 0; k--)
             if (vis[k] == 0u) {
@@ -652,8 +685,8 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         win[d >> 5] |= 1u << (d & 31u);
     }
     wave_sync();
+    uint2 rec = a.rows[n];
     for (;;) {                                          // :48
-        const uint2 rec = a.rows[n];
         const uint32_t row = rfl(rec.x);
         const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
@@ -697,11 +730,13 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                     pend_ts = qt.y;
                     have_pend = true;
                 }
+                rec = a.rows[n];
                 continue;
             }
             break;                                      // :101
         }
         // ---- advance (:118-123)
+        rec = a.rows[s.nbr];        // the next step's row record: requested before this step's bookkeeping
         if (m + 2 > a.cap || nlog + 1 > a.cap) {
             status = ST_SCRATCH_OVF;
             break;
@@ -968,17 +1003,43 @@ __device__ __forceinline__ WaveScratch wave_scratch(const WalkArgs &a, uint32_t 
     return ws;
 }
 
-// Persistent waves: every wave pulls the next work item until the cursor passes n_work; the cursor
-// only grows, so every wave reaches its exit and the grid drains.
-__device__ __forceinline__ bool next_work(int lane, uint32_t &ui) {
+// Persistent waves with one work queue per XCD.  The work items are cut into chunks of `chunk` consecutive items (the
+// trials of one start anchor under one metric) and chunk j belongs to XCD j % 8: the waves of an XCD walk the same
+// neighbourhood at the same time, so its L2 (4 MB, private to the XCD) holds the rows they share.  A wave pulls from
+// its own XCD's cursor; when that queue is dry it moves on to the next XCD's and never comes back.  Cursors only
+// grow, so every wave passes all eight queues and leaves: the grid drains.  Which XCD runs a unit has no influence
+// on its result.
+struct QueueState {
+    uint32_t home;      // XCC_ID of this wave
+    uint32_t passed;    // queues found dry so far
+};
+
+__device__ __forceinline__ QueueState queue_init() {
+    QueueState q;
+    // HW_REG_XCC_ID (id 20), bits [3:0]: s_getreg_b32 operand = id | offset << 6 | (size - 1) << 11
+    q.home = (uint32_t) __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (WALK_XCDS - 1);
+    q.passed = 0;
+    return q;
+}
+
+__device__ __forceinline__ bool next_work(int lane, QueueState &q, uint32_t &ui) {
     ColdArgs *ca = cold_args();
-    uint32_t w = 0;
-    if (lane == 0) w = atomicAdd(ca->cursor, 1u);
-    w = rfl(w);
-    if (w >= ca->n_work) return false;
-    const uint32_t *wl = ca->work_list;
-    ui = wl ? rfl(wl[w]) : w;
-    return true;
+    const uint32_t n_work = ca->n_work, chunk = ca->chunk;
+    uint32_t *cur = ca->cursor;
+    while (q.passed < WALK_XCDS) {
+        const uint32_t x = (q.home + q.passed) & (WALK_XCDS - 1);
+        uint32_t p = 0;
+        if (lane == 0) p = atomicAdd(cur + WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * x, 1u);
+        p = rfl(p);
+        const uint64_t w = ((uint64_t) (p / chunk) * WALK_XCDS + x) * chunk + p % chunk;
+        if (w < n_work) {
+            const uint32_t *wl = ca->work_list;
+            ui = wl ? rfl(wl[w]) : (uint32_t) w;
+            return true;
+        }
+        q.passed++;
+    }
+    return false;
 }
 
 // work item -> (metric slot, unit); returns the arguments specialised for the slot (deterministic kernel)
@@ -996,14 +1057,15 @@ __device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, ui
 
 template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
+    __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
-    __shared__ uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ double after_s[WALK_WAVES_PER_BLOCK][AFTER_SLOTS];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
     uint32_t cu;
-    while (next_work(lane, cu)) {
+    QueueState q = queue_init();
+    while (next_work(lane, q, cu)) {
         // work item -> (metric slot, unit) -> (anchor, trial); everything but the step loop's own arguments is read
         // from the kernarg segment here and dropped again
         ColdArgs *ca = cold_args();
@@ -1037,7 +1099,8 @@ __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
     uint32_t cu;
-    while (next_work(lane, cu)) {
+    QueueState q = queue_init();
+    while (next_work(lane, q, cu)) {
         uint32_t ui;
         const WalkArgs b = slot_args(a, cu, ui);
         const uint64_t unit = a.unit_begin + ui;
