@@ -420,7 +420,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         const uint32_t full_cap = N + 2;
         uint32_t cap = ctx->path_capacity ? ctx->path_capacity : 16384u;
         cap = std::max<uint32_t>(8u, std::min(cap, full_cap));
-        const uint32_t bm_words = (N + 31) / 32 + 1;
+        const uint32_t bm_words = (N + 31) / 32 + 1 + WALK_RNG_WORDS;
         // persistent grid = what is resident at once: blocks/CU from the occupancy query (a block is 4
         // waves), optionally capped by the tuning knob; never more than 8 blocks (32 waves) per CU
         const bool sq = metrics[0] >= 2;

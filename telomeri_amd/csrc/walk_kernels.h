@@ -56,7 +56,7 @@ struct WalkArgs {
     uint32_t *scratch;
     uint32_t cap;
     uint32_t *bitmaps;
-    uint32_t bm_words;              // 32-bit words per wave
+    uint32_t bm_words;              // 32-bit words per wave: the N-bit visited map, then WALK_RNG_WORDS of generator state
     // arena cursor (u64) at cursor[2..3]; one work cursor per XCD at cursor[WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * x]
     uint32_t *cursor;
     UnitOut *units;
@@ -64,6 +64,7 @@ struct WalkArgs {
     uint64_t ar_cap;
 };
 
+constexpr int WALK_RNG_WORDS = 640;             // raw std::mt19937 state of a wave (624 words), kept in HBM between twists
 constexpr int WALK_XCDS = 8;                    // MI355X: 8 accelerator dies, each with its own L2
 constexpr int WALK_QUEUE_BASE = 32;             // u32 index of XCD 0's work cursor; one 64-byte line per cursor
 constexpr int WALK_QUEUE_STRIDE = 16;

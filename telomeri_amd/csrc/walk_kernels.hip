@@ -36,14 +36,63 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---------------------------------------------------------------------------------------------
-// std::mt19937, one generator per wave, state in LDS (624 words), all lanes hold the same index.
+// std::mt19937 + uniform_real_distribution<double>(0,1), one generator per wave.
+//
+// A walk consumes one double per step, and a double is two raw words, tempered, combined and scaled.  That work is
+// done once per twist for all 312 doubles of a generator period, by all 64 lanes: the wave's LDS block (2496 bytes)
+// holds the 312 ready doubles, a draw is one 8-byte LDS read.  The raw state is only needed by the next twist (every
+// 312 draws) and sits in the wave's HBM scratch in between.
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
 
 __device__ __forceinline__ uint32_t walk_seed_dev(int metric, uint32_t anchor_node, uint32_t r) {
     // == tlm_walk_seed() / tlo_walk_seed()
     return 5489u + 0x9E3779B9u * (anchor_node + 1u) + 0x85EBCA6Bu * r + 0xC2B2AE35u * (uint32_t) metric;
 }
 
-__device__ inline void mt_seed(uint32_t *mt, int lane, uint32_t seed) {
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// In-place regeneration of the raw state in LDS, in chunks of 64 words.  Word i needs old mt[i], old mt[i+1] and
+// mt[(i+397)%624], which is an OLD word for i < 227 (it lies >= 6 chunks ahead) and a NEW word for i >= 227 (it
+// lies >= 3 chunks behind); word 623 needs the new mt[0].  Within a chunk all reads are issued before the chunk's
+// writes.  Then: the new raw state goes to HBM, and every pair of words becomes its double, in place --
+// uniform_real_distribution<double>(0,1)(gen): two draws, low word first, RN(x0 + x1 * 2^32) / 2^64, clamped
+// below 1 (libstdc++ generate_canonical<double, 53>).
+__device__ __forceinline__ void mt_twist_lds(lds_u32 *mt, glb_u32 *raw, int lane) {
+    for (int base = 0; base < 624; base += 64) {
+        const int i = base + lane;
+        uint32_t v = 0;
+        if (i < 624) {
+            const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+            v = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        wave_sync();
+        if (i < 624) mt[i] = v;
+        wave_sync();
+    }
+    for (int j = lane; j < 312; j += 64) {
+        const uint32_t r0 = mt[2 * j], r1 = mt[2 * j + 1];
+        raw[2 * j] = r0;
+        raw[2 * j + 1] = r1;
+        const double sum = (double) mt_temper(r0) + (double) mt_temper(r1) * 4294967296.0;
+        double ret = sum * 0x1p-64;                   // exact scaling
+        if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;   // nextafter(1, 0)
+        mt[2 * j] = (uint32_t) __double2loint(ret);
+        mt[2 * j + 1] = (uint32_t) __double2hiint(ret);
+    }
+    wave_sync();
+}
+
+// Real calls (once per walk / every 312 draws): their registers and address arithmetic stay out of the step loop.
+// Arguments by value, pointers typed by address space so that the bodies keep ds_* / global_* instructions.
+__device__ __noinline__ void mt_seed(lds_u32 *mt, glb_u32 *raw, int lane, uint32_t seed) {
     // mt[i] = 1812433253 * (mt[i-1] ^ (mt[i-1] >> 30)) + i : a serial chain, computed redundantly
     // by every lane (wave-uniform); lane i&63 keeps word i and the wave stores 64 words at a time.
     uint32_t x = seed, mine = 0;
@@ -56,68 +105,30 @@ __device__ inline void mt_seed(uint32_t *mt, int lane, uint32_t seed) {
         x = 1812433253u * (x ^ (x >> 30)) + (uint32_t) (i + 1);
     }
     wave_sync();    // LDS is ordered per wave; this only keeps the compiler from caching or moving the accesses
+    mt_twist_lds(mt, raw, lane);    // std::mt19937 twists before its first output
 }
 
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __noinline__ void mt_twist(lds_u32 *mt, glb_u32 *raw, int lane) {
+    for (int i = lane; i < 624; i += 64) mt[i] = raw[i];
+    wave_sync();
+    mt_twist_lds(mt, raw, lane);
+}
 
-// A real call (every 312 draws): its registers and address arithmetic stay out of the step loop.  Arguments by value,
-// the state pointer typed as LDS so that the body keeps ds_* instructions.
-__device__ __noinline__ void mt_twist(lds_u32 *mt, int lane) {
-    // In-place regeneration in chunks of 64 words.  Word i needs old mt[i], old mt[i+1] and
-    // mt[(i+397)%624], which is an OLD word for i < 227 (it lies >= 6 chunks ahead) and a NEW word
-    // for i >= 227 (it lies >= 3 chunks behind); word 623 needs the new mt[0].  Within a chunk all
-    // reads are issued before the chunk's writes.
-    for (int base = 0; base < 624; base += 64) {
-        const int i = base + lane;
-        uint32_t v = 0;
-        if (i < 624) {
-            const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
-            v = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        wave_sync();
-        if (i < 624) mt[i] = v;
-        wave_sync();
+// the generator of a walk: the LDS block of ready doubles, the raw state in HBM, the index of the next double
+struct Rng {
+    uint32_t *mt;
+    uint32_t *raw;
+    int idx;
+};
+
+__device__ __forceinline__ double mt_canonical(Rng &g, int lane) {
+    if (g.idx >= 312) {
+        mt_twist((lds_u32 *) g.mt, (glb_u32 *) g.raw, lane);
+        g.idx = 0;
     }
-}
-
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-
-// uniform_real_distribution<double>(0,1)(gen): two draws, low word first, RN(x0 + x1*2^32) / 2^64,
-// clamped below 1.  The index is always even, so a pair never straddles a twist.
-__device__ inline double mt_canonical(uint32_t *mt, int &idx, int lane) {
-    if (idx >= 624) {
-        mt_twist((lds_u32 *) mt, lane);
-        idx = 0;
-    }
-    const uint32_t y0 = mt_temper(mt[idx]), y1 = mt_temper(mt[idx + 1]);
-    idx += 2;
-    const double sum = (double) y0 + (double) y1 * 4294967296.0;
-    double ret = sum * 0x1p-64;                   // exact scaling
-    if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;   // nextafter(1, 0)
-    return ret;
-}
-
-// `mt_canonical(...) * total` for a finite total >= 0 that is zero or at least 2^-900 (sums of fp32 metrics are), in
-// fewer vector instructions: y1 * 2^32 is exact, so fma(y1, 2^32, y0) rounds y0 + y1 * 2^32 once, exactly as the
-// addition above does; scaling by 2^-64 is exact and commutes with the rounding of the product, so
-// RN(sum * 2^-64 * total) == RN(sum * (total * 2^-64)).  The clamp can only bite when y1 is all ones: that case takes
-// the general function.
-__device__ __forceinline__ double mt_canonical_times(uint32_t *mt, int &idx, int lane, double total) {
-    if (idx >= 624) {
-        mt_twist((lds_u32 *) mt, lane);
-        idx = 0;
-    }
-    const uint32_t y1 = rfl(mt_temper(mt[idx + 1]));
-    if (y1 == 0xFFFFFFFFu) return mt_canonical(mt, idx, lane) * total;
-    const uint32_t y0 = mt_temper(mt[idx]);
-    idx += 2;
-    return __builtin_fma((double) y1, 4294967296.0, (double) y0) * (total * 0x1p-64);
+    const uint2 w = *reinterpret_cast<const uint2 *>(g.mt + 2 * g.idx);
+    g.idx++;
+    return __hiloint2double((int) w.y, (int) w.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,6 +240,7 @@ struct WaveScratch {
     uint32_t *pe;     // path: global CSR index of each edge
     uint32_t *lg;     // every node whose visited bit was set (to clear the bitmap afterwards)
     uint32_t *bm;     // N-bit visited set, all zero between walks
+    uint32_t *rng;    // raw generator state (Monte-Carlo)
 };
 
 // End of a walk: publish the unit's outcome, copy an accepted path into the arena, clear the bitmap.
@@ -399,7 +411,7 @@ __device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&n
 // Selection among the K*64 entries held in registers.  `mb` arrives masked (0 where the entry is not a candidate),
 // `va` is the AND of the lane's visited masks (all ones = no candidate in this lane).
 template <int K, bool SQRT>
-__device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, uint32_t *mt, int &mti, int lane,
+__device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, Rng &rng, int lane,
                                                uint32_t base, bool act, const uint32_t (&nb)[K], const uint32_t (&mb)[K],
                                                uint32_t va, uint32_t &draws) {
     double ls = metric_f64<SQRT>(mb[0]);
@@ -417,7 +429,7 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
         if (!__ballot(has)) return;                                                // :72
     }
     s.ncand = 1;
-    const double random = mt_canonical_times(mt, mti, lane, total);                // :104
+    const double random = mt_canonical(rng, lane) * total;                // :104
     draws++;
     int hl, myk = K - 1;
     uint32_t mynb = nb[K - 1];
@@ -467,7 +479,7 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
 // A list of at most 64*K entries: one load, one visited probe, ONE scan (it yields the total and every lane's
 // prefix), no second pass over memory.
 template <int K, bool SQRT>
-__device__ __forceinline__ Selection select_short(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, int lane,
+__device__ __forceinline__ Selection select_short(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
                                                   uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
                                                   uint32_t &draws) {
     Selection s{-1, 0u, false, false, 0u, deg};
@@ -491,19 +503,19 @@ __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visite
         mb[k] &= ~vis[k];
         va &= vis[k];
     }
-    select_in_regs<K, SQRT>(s, vs, mt, mti, lane, 0u, act, nb, mb, va, draws);
+    select_in_regs<K, SQRT>(s, vs, rng, lane, 0u, act, nb, mb, va, draws);
     return s;
 }
 
 template <bool SQRT>
-__device__ Selection select_serial(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, int lane, uint32_t row,
+__device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane, uint32_t row,
                                    uint32_t deg, uint32_t start, uint32_t &draws, bool have_u, double u_given);
 
 // Lists longer than 512 entries, chunks of 512.  Pass 1 (:53-67): total over the unvisited neighbours; the running
 // sum after each of the first AFTER_SLOTS chunks is parked in LDS: the prefix is non-decreasing, so pass 2
 // (:107-114) only has to look into the one chunk where it crosses `random`.
 template <bool SQRT>
-__device__ Selection select_long(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, double *after,
+__device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, double *after,
                                               int lane, uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
                                               uint32_t &draws) {
     constexpr int K = 8;
@@ -542,10 +554,10 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, uint32_t *
     if (!any_cand) return s;                                                        // :72 dead end
     s.ncand = 1;
     wave_sync();                                                                    // `after` is read by every lane below
-    const double u = mt_canonical(mt, mti, lane);
+    const double u = mt_canonical(rng, lane);
     draws++;
     const double random = u * total;                                                // :104
-    if (random == 0.0) return select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws, true, u);
+    if (random == 0.0) return select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, true, u);
     double carry = 0.0;
     ci = 0;
     for (uint32_t base = 0; base < deg; base += C, ci++) {
@@ -600,7 +612,7 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, uint32_t *
 // one candidate after the other in list order, as PathManager.cpp:64,109 makes them.  Rare; never on real overlaps.
 // `have_u`: the step's draw was already made by the caller (select_long, when u * total came out as 0).
 template <bool SQRT>
-__device__ Selection select_serial(const HotArgs &a, const Visited &vs, uint32_t *mt, int &mti, int lane,
+__device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
                                                 uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws, bool have_u,
                                                 double u_given) {
     Selection s{-1, 0u, false, false, 0u, deg};
@@ -613,7 +625,7 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, uint32_t
             if (have_u) {
                 random = u_given * total;
             } else {
-                random = mt_canonical(mt, mti, lane) * total;                        // :104
+                random = mt_canonical(rng, lane) * total;                        // :104
                 draws++;
             }
         }
@@ -658,8 +670,8 @@ template <bool SQRT>
 __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after, int lane,
                         uint32_t ui, uint32_t start, uint32_t seed, int64_t len0) {
     // `start` and every node id below are walk-order indices
-    int mti = 624;
-    mt_seed(mt, lane, seed);
+    Rng rng{mt, ws.rng, 0};
+    mt_seed((lds_u32 *) mt, (glb_u32 *) ws.rng, lane, seed);
     Visited vs;
     vs.win = win;
     vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
@@ -692,10 +704,10 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
         const bool anchor_nbr = ((rfl(rec.y) >> 28) & 1u) != 0;
         // ---- selection scan (:53-115)
-        const Selection s = !safe        ? select_serial<SQRT>(a, vs, mt, mti, lane, row, deg, start, draws, false, 0.0)
-                            : deg <= 256u ? select_short<4, SQRT>(a, vs, mt, mti, lane, row, deg, start, anchor_nbr, draws)
-                            : deg <= 512u ? select_short<8, SQRT>(a, vs, mt, mti, lane, row, deg, start, anchor_nbr, draws)
-                                          : select_long<SQRT>(a, vs, mt, mti, after, lane, row, deg, start, anchor_nbr, draws);
+        const Selection s = !safe        ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
+                            : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
+                            : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
+                                          : select_long<SQRT>(a, vs, rng, after, lane, row, deg, start, anchor_nbr, draws);
         evals += s.evals;
         steps++;
         if (s.pick < 0) {
@@ -1000,6 +1012,7 @@ __device__ __forceinline__ WaveScratch wave_scratch(const WalkArgs &a, uint32_t 
     ws.pe = ws.pn + a.cap;
     ws.lg = ws.pe + a.cap;
     ws.bm = a.bitmaps + (size_t) wave * a.bm_words;
+    ws.rng = ws.bm + (a.bm_words - WALK_RNG_WORDS);
     return ws;
 }
 
