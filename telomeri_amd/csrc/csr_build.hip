@@ -316,13 +316,20 @@ __global__ void invert_perm_kernel(uint32_t n_nodes, const uint32_t *__restrict_
     if (i < n_nodes) new_of_old[old_of_new[i]] = i;
 }
 
+// Padded length of a row of the walk layout: a multiple of 8 entries (rows start on 64-byte boundaries, a lane of the
+// walk kernel owns 4 or 8 consecutive entries), and of 24 for the degrees the kernel reads with 6 entries per lane
+// (257..384): whatever the lane width, the last lane's entries end inside the row's own padding.
+__host__ __device__ inline uint32_t tlm_padded_degree(uint32_t deg) {
+    return (deg > 256u && deg <= 384u) ? ((deg + 23u) / 24u) * 24u : (deg + 7u) & ~7u;
+}
+
 // walk layout: padded degrees in walk order, then (after an exclusive scan) the per-node record and the row copies
 __global__ void padded_degree_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
                                      const uint32_t *__restrict__ old_of_new, uint32_t *__restrict__ pd) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_nodes) {
         const uint32_t o = old_of_new[i];
-        pd[i] = (row_ptr[o + 1] - row_ptr[o] + 7u) & ~7u;      // rows start on 64-byte boundaries
+        pd[i] = tlm_padded_degree(row_ptr[o + 1] - row_ptr[o]);
     }
 }
 
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
     for (uint32_t node = wave; node < n_nodes; node += n_waves) {     // node = index in walk order
         const uint32_t o = old_of_new[node];
         const uint32_t r0 = row_ptr[o], deg = row_ptr[o + 1] - r0, w0 = w_start[node];
-        const uint32_t pdeg = (deg + 7u) & ~7u;
+        const uint32_t pdeg = tlm_padded_degree(deg);
         bool anchor_nbr = false;        // does the list hold an anchor?  (bit 28: the forced-anchor test can be skipped)
         for (uint32_t j = lane; j < deg; j += 64) anchor_nbr |= (ent_es[r0 + j].x >> 31) != 0;
         const uint32_t fl = (uint32_t) node_flags[o] | (__ballot(anchor_nbr) ? 16u : 0u);
@@ -469,7 +476,7 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
         uint64_t apad = 0;
         if (N) {
-            TLM_CHECK(g->n_adj + 7ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
+            TLM_CHECK(g->n_adj + 23ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
             hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, g->w_old_of_new,
                                pd.as<uint32_t>());
             size_t tb = 0;

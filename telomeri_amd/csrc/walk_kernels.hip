@@ -706,6 +706,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         // ---- selection scan (:53-115)
         const Selection s = !safe        ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
                             : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
+                            : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
                             : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
                                           : select_long<SQRT>(a, vs, rng, after, lane, row, deg, start, anchor_nbr, draws);
         evals += s.evals;
