@@ -301,6 +301,56 @@ def test_walks_on_adopted_csr(ctx, wild):
         _walk_both(ctx, dg, og, metric, None, mc=False)
 
 
+def _csr_with_degrees(degrees, seed=0, zero_rows=()):
+    """Node i has exactly degrees[i] list entries (multi-edges allowed); rows in `zero_rows` carry metric 0 only."""
+    rng = np.random.default_rng(seed)
+    n = len(degrees)
+    anchors = np.zeros(n, np.uint8)
+    anchors[[1, n // 3, (2 * n) // 3]] = 1
+    row_ptr = np.zeros(n + 1, np.uint64)
+    row_ptr[1:] = np.cumsum(degrees)
+    a = int(row_ptr[-1])
+    # neighbours are reads; only a few lists hold an anchor, so that walks roam instead of being forced home at once
+    reads = np.nonzero(anchors == 0)[0].astype(np.uint32)
+    nbr = reads[rng.integers(0, reads.shape[0], size=a)]
+    owner = np.repeat(np.arange(n, dtype=np.uint32), degrees)
+    clash = nbr == owner
+    nbr[clash] = reads[(np.searchsorted(reads, nbr[clash]) + 1) % reads.shape[0]]
+    for r in rng.choice(n, size=6, replace=False):
+        if degrees[r] > 1:
+            nbr[int(row_ptr[r]) + int(rng.integers(0, degrees[r]))] = np.nonzero(anchors)[0][int(rng.integers(0, 3))]
+    # multiples of 1/8: every sum of a list is exact in a double, whatever its length (no serial fallback)
+    es = (rng.integers(1, 160000, size=a) / 8.0).astype(np.float32)
+    os_ = (rng.integers(1, 72000, size=a) / 8.0).astype(np.float32)
+    for r in zero_rows:
+        es[int(row_ptr[r]):int(row_ptr[r + 1])] = 0.0
+        os_[int(row_ptr[r]):int(row_ptr[r + 1])] = -0.0
+    q_start = rng.integers(0, 9000, size=a).astype(np.uint32)
+    t_start = rng.integers(0, 8990, size=a).astype(np.uint32)
+    node_len = rng.integers(20000, 90000, size=n).astype(np.uint32)
+    return row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors
+
+
+def test_walks_across_lane_widths(ctx):
+    """List lengths on both sides of every switch of the Monte-Carlo kernel: 4 / 6 / 8 entries per lane (256, 384, 512),
+    the chunked two-pass path above 512, more chunks than parked closing sums (> 4096), rows whose padded length ends
+    exactly at the list, and rows whose candidates all have metric 0 (u * total == 0: first candidate wins)."""
+    degrees = list(range(1, 40)) + list(range(120, 136)) + list(range(246, 300)) + list(range(370, 396)) \
+        + list(range(500, 530)) + [640, 1023, 1024, 1025, 1536, 4095, 4097, 5000, 2, 3, 5, 8]
+    degrees = np.array(degrees * 2, np.int64)
+    zero_rows = [0, 7, 60, 80, 100, 130, 150]
+    args = _csr_with_degrees(degrees, seed=11, zero_rows=zero_rows)
+    dg = ctx.graph_from_csr(*args)
+    og = po.Graph.from_csr(*args)
+    gi = dg.info()
+    assert gi.unsafe_nodes[0] == 0 and gi.unsafe_nodes[1] == 0 and gi.max_degree == 5000
+    wp = capi.WalkParams.default(rb_att=150, bt_att=6, len_thr=300_000)
+    for metric in (capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_ES_SQRT):
+        ps, _ = _walk_both(ctx, dg, og, metric, wp, mc=True)
+        assert ps.unit_stats()["steps"].sum() > 2000
+    _walk_both(ctx, dg, og, capi.METRIC_OS, None, mc=False)
+
+
 def test_rng_stream_through_long_walks(ctx):
     """More than 312 draws in one walk crosses an mt19937 twist on the device."""
     row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors = _synthetic_csr(n_reads=3000, deg=40, seed=3)
