@@ -1,7 +1,42 @@
 // telomeri_amd/csrc/walk_kernels.hip -- see walk_kernels.h.
 #include "walk_kernels.h"
 
+// Diagnostic build (make EXTRA=-DTLM_TIMING): shader-clock cycles per phase of a Monte-Carlo step, summed over all
+// waves of a launch and printed on stderr by tlm_launch_walk_mc.  The phases are separated by full vmcnt waits, so
+// the build is slower than the product and its results are for reading, not for shipping.
+#ifdef TLM_TIMING
+__device__ unsigned long long tlm_timing[8];
+#endif
+
 namespace {
+
+struct StepClock {
+#ifdef TLM_TIMING
+    uint64_t t, acc[5], steps;
+    __device__ __forceinline__ void start() {
+        for (int i = 0; i < 5; i++) acc[i] = 0;
+        steps = 0;
+        t = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int phase, bool wait_loads) {     // closes `phase`
+        if (wait_loads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t now = __builtin_amdgcn_s_memtime();
+        acc[phase] += now - t;
+        t = now;
+    }
+    __device__ __forceinline__ void flush(int lane) {
+        if (lane == 0) {
+            for (int i = 0; i < 5; i++) atomicAdd(&tlm_timing[i], (unsigned long long) acc[i]);
+            atomicAdd(&tlm_timing[5], (unsigned long long) steps);
+        }
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int, bool) {}
+    __device__ __forceinline__ void flush(int) {}
+#endif
+};
+enum { CLK_ROW_WAIT = 0, CLK_LIST_WAIT = 1, CLK_SELECT = 2, CLK_ADVANCE = 3, CLK_OTHER = 4 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
 
@@ -481,10 +516,11 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
 template <int K, bool SQRT>
 __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
                                                   uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
-                                                  uint32_t &draws) {
+                                                  uint32_t &draws, StepClock &clk) {
     Selection s{-1, 0u, false, false, 0u, deg};
     uint32_t nb[K], mb[K], vis[K];
     const bool act = lane_load<K>(a.ents, row, 0u, deg, lane, nb, mb);
+    clk.mark(CLK_LIST_WAIT, true);
     if (anchor_nbr) {
         uint32_t fn = 0;
         const int fpos = forced_in_lanes<K>(nb, start, fn);
@@ -698,19 +734,26 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     }
     wave_sync();
     uint2 rec = a.rows[n];
+    StepClock clk;
+    clk.start();
     for (;;) {                                          // :48
+        clk.mark(CLK_ROW_WAIT, true);
         const uint32_t row = rfl(rec.x);
         const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
         const bool anchor_nbr = ((rfl(rec.y) >> 28) & 1u) != 0;
         // ---- selection scan (:53-115)
         const Selection s = !safe        ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
-                            : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
-                            : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
-                            : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws)
+                            : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+                            : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+                            : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
                                           : select_long<SQRT>(a, vs, rng, after, lane, row, deg, start, anchor_nbr, draws);
         evals += s.evals;
         steps++;
+        clk.mark(CLK_SELECT, false);
+#ifdef TLM_TIMING
+        clk.steps++;
+#endif
         if (s.pick < 0) {
             if (s.ncand != 0) break;    // no prefix reached `random` (NaN / negative metrics): the reference
                                         // dereferences a null Edge* there; oracle and kernel abandon the walk
@@ -783,6 +826,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         m++;
         n = s.nbr;
         wave_sync();
+        clk.mark(CLK_ADVANCE, false);
         if (len <= 0) break;                            // :126-128
         if (s.anchor) {                                 // :131-134
             acceptable = true;
@@ -790,6 +834,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         }
         if (len >= a.len_threshold) break;              // :137-142
     }
+    clk.flush(lane);
     // acc holds the increments of edges 0..m-2 (the last pushed edge is still pending): exactly Path::length()
     const int64_t len_final = len0 + acc;
     if (acceptable && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :146-155
@@ -1143,8 +1188,25 @@ int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric) {
 }
 
 void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a) {
+#ifdef TLM_TIMING
+    {
+        unsigned long long z[8] = {0};
+        (void) hipMemcpyToSymbol(HIP_SYMBOL(tlm_timing), z, sizeof(z));
+    }
+#endif
     if (sqrt_metric) hipLaunchKernelGGL(walk_mc_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(walk_mc_kernel<false>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+#ifdef TLM_TIMING
+    {
+        unsigned long long h[8] = {0};
+        (void) hipStreamSynchronize(s);
+        (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(tlm_timing), sizeof(h));
+        if (h[5])
+            fprintf(stderr, "[tlm timing] %llu steps; cycles per step: row-record wait %.0f, list wait %.0f, selection %.0f, "
+                            "bookkeeping %.0f\n", h[5], (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5],
+                    (double) h[3] / h[5]);
+    }
+#endif
 }
 
 void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a) {
