@@ -235,41 +235,6 @@ __device__ __forceinline__ double wave_incl_scan_f64(double v) {
     return v;
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp_u64(uint64_t v, uint64_t identity) {      // lanes without a source read `identity`
-    const int lo = __builtin_amdgcn_update_dpp((int) (uint32_t) identity, (int) (uint32_t) v, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int) (uint32_t) (identity >> 32), (int) (uint32_t) (v >> 32), CTRL, ROW_MASK,
-                                               0xf, false);
-    return ((uint64_t) (uint32_t) hi << 32) | (uint64_t) (uint32_t) lo;
-}
-
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
-    return ((uint64_t) readlane_u32((uint32_t) (v >> 32), l) << 32) | (uint64_t) readlane_u32((uint32_t) v, l);
-}
-
-// maximum / minimum of a 64-bit key over the wave, result wave-uniform (scan shape: lane 63 ends up with it)
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-    uint64_t o;
-    o = dpp_u64<0x111, 0xf>(v, 0); v = o > v ? o : v;
-    o = dpp_u64<0x112, 0xf>(v, 0); v = o > v ? o : v;
-    o = dpp_u64<0x114, 0xf>(v, 0); v = o > v ? o : v;
-    o = dpp_u64<0x118, 0xf>(v, 0); v = o > v ? o : v;
-    o = dpp_u64<0x142, 0xa>(v, 0); v = o > v ? o : v;
-    o = dpp_u64<0x143, 0xc>(v, 0); v = o > v ? o : v;
-    return readlane_u64(v, 63);
-}
-
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-    uint64_t o;
-    o = dpp_u64<0x111, 0xf>(v, ~0ull); v = o < v ? o : v;
-    o = dpp_u64<0x112, 0xf>(v, ~0ull); v = o < v ? o : v;
-    o = dpp_u64<0x114, 0xf>(v, ~0ull); v = o < v ? o : v;
-    o = dpp_u64<0x118, 0xf>(v, ~0ull); v = o < v ? o : v;
-    o = dpp_u64<0x142, 0xa>(v, ~0ull); v = o < v ? o : v;
-    o = dpp_u64<0x143, 0xc>(v, ~0ull); v = o < v ? o : v;
-    return readlane_u64(v, 63);
-}
-
 struct WaveScratch {
     uint32_t *pn;     // path: nodes
     uint32_t *pe;     // path: global CSR index of each edge
@@ -846,42 +811,63 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
 //
 // The reference copies the list and stable_sorts it descending by metric (:289-296), then takes the
 // first rank k in [skip_n_best, deg-2] whose neighbour is unvisited (:299-315).  Rank order is
-// (metric desc, list position asc); so with key = (orderable(metric) << 32) | ~position, rank 0 is
-// the maximum key, rank deg-1 the minimum key, and the wanted entry is the maximum key among the
-// unvisited entries other than rank deg-1 and, after a go-back (skip_n_best == 1), rank 0.
+// (metric desc, list position asc).  With ord = an order-preserving u32 image of the metric:
+//   rank 0      = the largest ord, at its smallest position;
+//   rank deg-1  = the smallest ord, at its largest position (never eligible, :302);
+//   the wanted entry = the largest ord among the unvisited entries other than rank deg-1 and, after a go-back
+//   (skip_n_best == 1), rank 0 -- at its smallest position.
+// A wave finds each with a 32-bit DPP max/min (six v_max_u32_dpp) and a find-first over ballots.
 
-__device__ __forceinline__ uint64_t det_key(uint32_t bits, uint32_t i) {
+__device__ __forceinline__ uint32_t det_ord(uint32_t bits) {
     if (bits == 0x80000000u) bits = 0u;                               // -0 == +0 for operator>
-    const uint32_t ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-    return ((uint64_t) ord << 32) | (uint64_t) (0xFFFFFFFFu - i);
-}
-
-// visited flags of one lane's 4 entries: LDS band first, HBM map for ids outside it (rare)
-__device__ __forceinline__ void lane_visited(const Chunk &c, const Visited &vs, uint32_t base, uint32_t deg, int lane,
-                                             bool (&vis)[4]) {
-    uint32_t w[4];
-    bool far = false;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t i = base + 4u * (uint32_t) lane + (uint32_t) k;
-        const uint32_t d = (c.nb[k] & 0x7FFFFFFFu) - vs.lo;
-        w[k] = i >= deg ? 1u : d < WIN_BITS ? (vs.win[d >> 5] >> (d & 31u)) & 1u : 2u;
-        far |= w[k] == 2u;
-    }
-    if (__ballot(far)) {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (w[k] == 2u) w[k] = bm_test(vs.bm, c.nb[k] & 0x7FFFFFFFu) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) vis[k] = w[k] != 0u;
+    return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
 }
 
 template <bool SQRT>
-__device__ __forceinline__ uint64_t det_key_of(const Chunk &c, int k, uint32_t pos) {
-    float mf = __uint_as_float(c.mb[k]);
+__device__ __forceinline__ uint32_t det_ord_of(uint32_t mb) {
+    float mf = __uint_as_float(mb);
     if (SQRT) mf = sqrtf(mf);
-    return det_key(__float_as_uint(mf), pos);
+    return det_ord(__float_as_uint(mf));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t identity) {       // lanes without a source read `identity`
+    return (uint32_t) __builtin_amdgcn_update_dpp((int) identity, (int) v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // result wave-uniform
+    v = max(v, dpp_u32<0x111, 0xf>(v, 0u));
+    v = max(v, dpp_u32<0x112, 0xf>(v, 0u));
+    v = max(v, dpp_u32<0x114, 0xf>(v, 0u));
+    v = max(v, dpp_u32<0x118, 0xf>(v, 0u));
+    v = max(v, dpp_u32<0x142, 0xa>(v, 0u));
+    v = max(v, dpp_u32<0x143, 0xc>(v, 0u));
+    return readlane_u32(v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u32<0x111, 0xf>(v, ~0u));
+    v = min(v, dpp_u32<0x112, 0xf>(v, ~0u));
+    v = min(v, dpp_u32<0x114, 0xf>(v, ~0u));
+    v = min(v, dpp_u32<0x118, 0xf>(v, ~0u));
+    v = min(v, dpp_u32<0x142, 0xa>(v, ~0u));
+    v = min(v, dpp_u32<0x143, 0xc>(v, ~0u));
+    return readlane_u32(v, 63);
+}
+
+// Which of a lane's 4 entries may be taken (bit k): inside the list, unvisited, not rank deg-1, not the excluded
+// rank 0.  Visited probes as in the Monte-Carlo kernel (LDS band, exact HBM map for ids outside it).
+__device__ __forceinline__ uint32_t det_eligible(const Chunk &c, const Visited &vs, uint32_t base, uint32_t deg, int lane,
+                                                 uint32_t worst_i, uint32_t excluded_i) {
+    uint32_t vis[4];
+    lane_probe<4>(vs, c.nb, vis);
+    uint32_t m = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
+        if (pos < deg && vis[k] == 0u && pos != worst_i && pos != excluded_i) m |= 1u << k;       // :308
+    }
+    return m;
 }
 
 // set / clear a visited flag (lane 0 only)
@@ -937,54 +923,86 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
         uint32_t skip_n_best = 0;
         bool went_back = false;
         uint32_t node = second;
+        uint2 rec = a.rows[node];
         for (;;) {                                          // :243
-            const uint2 rec = a.rows[node];
             const uint32_t row = rfl(rec.x);
             const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
             bool go_back = false;
             uint32_t chosen = 0;
-            // the first 256 entries stay in registers through all three passes; longer lists re-read the rest
+            // the first 256 entries stay in registers through all passes; longer lists re-read the rest (L1 / L2)
             const Chunk c0 = load_chunk(a.ents, row, 0u, deg, lane);
+            uint32_t o0[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o0[k] = det_ord_of<SQRT>(c0.mb[k]);
+            uint32_t chosen_nbr = 0;
+            bool chosen_anchor = false;
             if (deg == 0 || skip_n_best >= deg - 1) {       // :245, :267
                 go_back = true;
             } else {
                 evals += deg;
                 steps++;
-                // rank 0 = maximum key, rank deg-1 = minimum key (:289-296)
-                uint64_t kmax = 0, kmin = ~0ull;
+                // ---- rank 0 and rank deg-1 (:289-296)
+                uint32_t lmax = 0u, lmin = ~0u;
+                for (uint32_t base = 0; base < deg; base += 256) {
+                    const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (base + 4u * (uint32_t) lane + (uint32_t) k < deg) {
+                            const uint32_t o = base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]);
+                            lmax = max(lmax, o);
+                            lmin = min(lmin, o);
+                        }
+                }
+                const uint32_t omax = wave_max_u32(lmax), omin = wave_min_u32(lmin);
+                uint32_t best_i = 0xFFFFFFFFu, worst_i = 0u;
                 for (uint32_t base = 0; base < deg; base += 256) {
                     const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
-                        if (pos < deg) {
-                            const uint64_t key = det_key_of<SQRT>(c, k, pos);
-                            kmax = key > kmax ? key : kmax;
-                            kmin = key < kmin ? key : kmin;
-                        }
+                        const bool valid = base + 4u * (uint32_t) lane + (uint32_t) k < deg;
+                        const uint32_t o = base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]);
+                        const uint64_t bm = __ballot(valid && o == omax), wm = __ballot(valid && o == omin);
+                        if (bm) best_i = min(best_i, base + 4u * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
+                        if (wm) worst_i = max(worst_i, base + 4u * (uint32_t) (63 - __clzll((unsigned long long) wm)) + (uint32_t) k);
                     }
                 }
-                kmax = wave_max_u64(kmax);
-                kmin = wave_min_u64(kmin);
-                const uint32_t best_i = 0xFFFFFFFFu - (uint32_t) kmax;     // rank 0
-                const uint32_t worst_i = 0xFFFFFFFFu - (uint32_t) kmin;    // rank deg-1: never eligible (:302)
-                uint64_t kc = 0;
+                const uint32_t excluded_i = skip_n_best != 0 ? best_i : 0xFFFFFFFFu;        // after a go-back (:299)
+                // ---- the best eligible entry (:299-315)
+                uint32_t lc = 0u, elig0 = 0u;
+                bool any = false;
                 for (uint32_t base = 0; base < deg; base += 256) {
                     const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
-                    bool vis[4];
-                    lane_visited(c, vs, base, deg, lane, vis);
+                    const uint32_t em = det_eligible(c, vs, base, deg, lane, worst_i, excluded_i);
+                    if (base == 0) elig0 = em;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
-                        if (pos < deg && pos != worst_i && !(skip_n_best != 0 && pos == best_i) && !vis[k]) {   // :308
-                            const uint64_t key = det_key_of<SQRT>(c, k, pos);
-                            kc = key > kc ? key : kc;
+                    for (int k = 0; k < 4; k++)
+                        if ((em >> k) & 1u) lc = max(lc, base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]));
+                    any |= em != 0u;
+                }
+                if (!__ballot(any)) {
+                    go_back = true;                         // :318
+                } else {
+                    const uint32_t oc = wave_max_u32(lc);
+                    chosen = 0xFFFFFFFFu;
+                    for (uint32_t base = 0; base < deg && chosen == 0xFFFFFFFFu; base += 256) {
+                        const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+                        const uint32_t em = base == 0 ? elig0 : det_eligible(c, vs, base, deg, lane, worst_i, excluded_i);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint64_t hm = __ballot(((em >> k) & 1u) && (base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k])) == oc);
+                            if (hm) {
+                                const int fl = __ffsll((unsigned long long) hm) - 1;
+                                const uint32_t p = base + 4u * (uint32_t) fl + (uint32_t) k;
+                                if (p < chosen) {
+                                    chosen = p;
+                                    const uint32_t e = readlane_u32(c.nb[k], fl);
+                                    chosen_nbr = e & 0x7FFFFFFFu;
+                                    chosen_anchor = (e >> 31) != 0;
+                                }
+                            }
                         }
                     }
                 }
-                kc = wave_max_u64(kc);
-                if (kc == 0) go_back = true;                // :318
-                else chosen = 0xFFFFFFFFu - (uint32_t) kc;
             }
             if (go_back) {
                 if (step_index == 0) break;                 // :246-248,268-271,319-322
@@ -997,11 +1015,10 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 node = rfl(ws.pn[m]);
                 if (lane == 0) visited_clear(vs, node);     // :262,284,335
                 wave_sync();
+                rec = a.rows[node];
                 continue;
             }
-            const uint2 cent = a.ents[row + chosen];
-            const uint32_t chosen_nbr = rfl(cent.x & 0x7FFFFFFFu);
-            const bool chosen_anchor = rfl(cent.x >> 31) != 0;
+            rec = a.rows[chosen_nbr];       // the next step's row record, requested before this step's bookkeeping
             // :340-347: the FIRST entry in list order with the same (q_index, t_index) is pushed
             uint32_t pushed = chosen;
             for (uint32_t base = 0; base < deg; base += 256) {
@@ -1034,7 +1051,10 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 if (far_mark) ws.lg[nlog] = node;
             }
             if (far_mark) nlog++;
-            acc += edge_delta(a.qt, eidx);
+            {   // (readfirstlane keeps the loop-carried sum in scalar registers)
+                const uint2 qt = a.qt[eidx];
+                acc += (int64_t) rfl(qt.x) - (int64_t) rfl(qt.y);
+            }
             m++;
             node = chosen_nbr;                              // :356
             wave_sync();
@@ -1153,7 +1173,7 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
 
 template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
-    __shared__ uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
+    __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
