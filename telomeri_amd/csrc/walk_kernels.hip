@@ -870,6 +870,180 @@ __device__ __forceinline__ uint32_t det_eligible(const Chunk &c, const Visited &
     return m;
 }
 
+struct DetPick {
+    bool go_back;           // no eligible entry (:318)
+    uint32_t chosen;        // list position of the wanted entry
+    uint32_t chosen_nbr;    // its neighbour
+    bool chosen_anchor;     // ... and whether that is an anchor
+    uint32_t pushed;        // :340-347: the FIRST entry in list order with the same (q_index, t_index) is pushed
+};
+
+// Lists of up to 64*K entries, K consecutive entries per lane, everything in registers: one read of the list per step.
+template <int K, bool SQRT>
+__device__ __forceinline__ DetPick det_select_regs(const uint2 *ents, const Visited &vs, int lane, uint32_t row,
+                                                   uint32_t deg, uint32_t skip_n_best) {
+    DetPick r{false, 0xFFFFFFFFu, 0u, false, 0xFFFFFFFFu};
+    uint32_t nb[K], mb[K], o[K], vis[K];
+    lane_load<K>(ents, row, 0u, deg, lane, nb, mb);         // lanes past the list repeat lane 0's entries: masked by cnt
+    const int cnt = (int) deg - K * lane;                     // entries of this lane inside the list (<= 0: none)
+    const uint32_t pos0 = (uint32_t) (K * lane);
+    lane_probe<K>(vs, nb, vis);
+    // ---- rank 0 and rank deg-1 (:289-296)
+    uint32_t lmax = 0u, lmin = ~0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        o[k] = det_ord_of<SQRT>(mb[k]);
+        if (k < cnt) {
+            lmax = max(lmax, o[k]);
+            lmin = min(lmin, o[k]);
+        }
+    }
+    const uint32_t omax = wave_max_u32(lmax), omin = wave_min_u32(lmin);
+    uint32_t best_i = 0xFFFFFFFFu, worst_i = 0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t bm = __ballot(k < cnt && o[k] == omax), wm = __ballot(k < cnt && o[k] == omin);
+        if (bm) best_i = min(best_i, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
+        if (wm) worst_i = max(worst_i, (uint32_t) K * (uint32_t) (63 - __clzll((unsigned long long) wm)) + (uint32_t) k);
+    }
+    const uint32_t excluded_i = skip_n_best != 0 ? best_i : 0xFFFFFFFFu;        // after a go-back (:299)
+    // ---- the best eligible entry (:299-315)
+    uint32_t lc = 0u;
+    bool el[K], any = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        el[k] = k < cnt && vis[k] == 0u && pos0 != worst_i - (uint32_t) k && pos0 != excluded_i - (uint32_t) k;   // :308
+        if (el[k]) lc = max(lc, o[k]);
+        any |= el[k];
+    }
+    if (!__ballot(any)) {
+        r.go_back = true;                                   // :318
+        return r;
+    }
+    const uint32_t oc = wave_max_u32(lc);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t hm = __ballot(el[k] && o[k] == oc);
+        if (hm) {
+            const int fl = __ffsll((unsigned long long) hm) - 1;
+            const uint32_t p = (uint32_t) K * (uint32_t) fl + (uint32_t) k;
+            if (p < r.chosen) {
+                r.chosen = p;
+                const uint32_t e = readlane_u32(nb[k], fl);
+                r.chosen_nbr = e & 0x7FFFFFFFu;
+                r.chosen_anchor = (e >> 31) != 0;
+            }
+        }
+    }
+    // ---- :340-347
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t hm = __ballot(k < cnt && (nb[k] & 0x7FFFFFFFu) == r.chosen_nbr);
+        if (hm) r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
+    }
+    return r;
+}
+
+// Longer lists: chunks of 256 entries, the first one kept in registers, the others re-read pass by pass (L1 / L2).
+template <bool SQRT>
+__device__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
+                                   uint32_t skip_n_best) {
+    struct { const uint2 *ents; } a{ents_tab};
+    bool go_back = false;
+    uint32_t chosen = 0;
+    // the first 256 entries stay in registers through all passes; longer lists re-read the rest (L1 / L2)
+    const Chunk c0 = load_chunk(a.ents, row, 0u, deg, lane);
+    uint32_t o0[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o0[k] = det_ord_of<SQRT>(c0.mb[k]);
+    uint32_t chosen_nbr = 0;
+    bool chosen_anchor = false;
+    {
+        // ---- rank 0 and rank deg-1 (:289-296)
+        uint32_t lmax = 0u, lmin = ~0u;
+        for (uint32_t base = 0; base < deg; base += 256) {
+            const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (base + 4u * (uint32_t) lane + (uint32_t) k < deg) {
+                    const uint32_t o = base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]);
+                    lmax = max(lmax, o);
+                    lmin = min(lmin, o);
+                }
+        }
+        const uint32_t omax = wave_max_u32(lmax), omin = wave_min_u32(lmin);
+        uint32_t best_i = 0xFFFFFFFFu, worst_i = 0u;
+        for (uint32_t base = 0; base < deg; base += 256) {
+            const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool valid = base + 4u * (uint32_t) lane + (uint32_t) k < deg;
+                const uint32_t o = base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]);
+                const uint64_t bm = __ballot(valid && o == omax), wm = __ballot(valid && o == omin);
+                if (bm) best_i = min(best_i, base + 4u * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
+                if (wm) worst_i = max(worst_i, base + 4u * (uint32_t) (63 - __clzll((unsigned long long) wm)) + (uint32_t) k);
+            }
+        }
+        const uint32_t excluded_i = skip_n_best != 0 ? best_i : 0xFFFFFFFFu;        // after a go-back (:299)
+        // ---- the best eligible entry (:299-315)
+        uint32_t lc = 0u, elig0 = 0u;
+        bool any = false;
+        for (uint32_t base = 0; base < deg; base += 256) {
+            const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+            const uint32_t em = det_eligible(c, vs, base, deg, lane, worst_i, excluded_i);
+            if (base == 0) elig0 = em;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((em >> k) & 1u) lc = max(lc, base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]));
+            any |= em != 0u;
+        }
+        if (!__ballot(any)) {
+            go_back = true;                         // :318
+        } else {
+            const uint32_t oc = wave_max_u32(lc);
+            chosen = 0xFFFFFFFFu;
+            for (uint32_t base = 0; base < deg && chosen == 0xFFFFFFFFu; base += 256) {
+                const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+                const uint32_t em = base == 0 ? elig0 : det_eligible(c, vs, base, deg, lane, worst_i, excluded_i);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint64_t hm = __ballot(((em >> k) & 1u) && (base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k])) == oc);
+                    if (hm) {
+                        const int fl = __ffsll((unsigned long long) hm) - 1;
+                        const uint32_t p = base + 4u * (uint32_t) fl + (uint32_t) k;
+                        if (p < chosen) {
+                            chosen = p;
+                            const uint32_t e = readlane_u32(c.nb[k], fl);
+                            chosen_nbr = e & 0x7FFFFFFFu;
+                            chosen_anchor = (e >> 31) != 0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // :340-347: the FIRST entry in list order with the same (q_index, t_index) is pushed
+    uint32_t pushed = chosen;
+    for (uint32_t base = 0; base < deg; base += 256) {
+        const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
+        uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
+            const uint64_t hm = __ballot(pos < deg && (c.nb[k] & 0x7FFFFFFFu) == chosen_nbr);
+            if (hm) {
+                const uint32_t p = base + 4u * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k;
+                best = p < best ? p : best;
+            }
+        }
+        if (best != 0xFFFFFFFFu) {
+            pushed = best;
+            break;
+        }
+    }
+    return DetPick{go_back, chosen, chosen_nbr, chosen_anchor, pushed};
+}
+
 // set / clear a visited flag (lane 0 only)
 __device__ __forceinline__ void visited_set(const Visited &vs, uint32_t n) {
     const uint32_t d = n - vs.lo;
@@ -928,82 +1102,18 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
             const uint32_t row = rfl(rec.x);
             const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
             bool go_back = false;
-            uint32_t chosen = 0;
-            // the first 256 entries stay in registers through all passes; longer lists re-read the rest (L1 / L2)
-            const Chunk c0 = load_chunk(a.ents, row, 0u, deg, lane);
-            uint32_t o0[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) o0[k] = det_ord_of<SQRT>(c0.mb[k]);
-            uint32_t chosen_nbr = 0;
-            bool chosen_anchor = false;
-            if (deg == 0 || skip_n_best >= deg - 1) {       // :245, :267
-                go_back = true;
-            } else {
+            DetPick pk{true, 0u, 0u, false, 0u};            // :245, :267: nothing to rank
+            if (deg != 0 && skip_n_best < deg - 1) {
                 evals += deg;
                 steps++;
-                // ---- rank 0 and rank deg-1 (:289-296)
-                uint32_t lmax = 0u, lmin = ~0u;
-                for (uint32_t base = 0; base < deg; base += 256) {
-                    const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (base + 4u * (uint32_t) lane + (uint32_t) k < deg) {
-                            const uint32_t o = base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]);
-                            lmax = max(lmax, o);
-                            lmin = min(lmin, o);
-                        }
-                }
-                const uint32_t omax = wave_max_u32(lmax), omin = wave_min_u32(lmin);
-                uint32_t best_i = 0xFFFFFFFFu, worst_i = 0u;
-                for (uint32_t base = 0; base < deg; base += 256) {
-                    const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool valid = base + 4u * (uint32_t) lane + (uint32_t) k < deg;
-                        const uint32_t o = base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]);
-                        const uint64_t bm = __ballot(valid && o == omax), wm = __ballot(valid && o == omin);
-                        if (bm) best_i = min(best_i, base + 4u * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
-                        if (wm) worst_i = max(worst_i, base + 4u * (uint32_t) (63 - __clzll((unsigned long long) wm)) + (uint32_t) k);
-                    }
-                }
-                const uint32_t excluded_i = skip_n_best != 0 ? best_i : 0xFFFFFFFFu;        // after a go-back (:299)
-                // ---- the best eligible entry (:299-315)
-                uint32_t lc = 0u, elig0 = 0u;
-                bool any = false;
-                for (uint32_t base = 0; base < deg; base += 256) {
-                    const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
-                    const uint32_t em = det_eligible(c, vs, base, deg, lane, worst_i, excluded_i);
-                    if (base == 0) elig0 = em;
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if ((em >> k) & 1u) lc = max(lc, base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k]));
-                    any |= em != 0u;
-                }
-                if (!__ballot(any)) {
-                    go_back = true;                         // :318
-                } else {
-                    const uint32_t oc = wave_max_u32(lc);
-                    chosen = 0xFFFFFFFFu;
-                    for (uint32_t base = 0; base < deg && chosen == 0xFFFFFFFFu; base += 256) {
-                        const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
-                        const uint32_t em = base == 0 ? elig0 : det_eligible(c, vs, base, deg, lane, worst_i, excluded_i);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint64_t hm = __ballot(((em >> k) & 1u) && (base == 0 ? o0[k] : det_ord_of<SQRT>(c.mb[k])) == oc);
-                            if (hm) {
-                                const int fl = __ffsll((unsigned long long) hm) - 1;
-                                const uint32_t p = base + 4u * (uint32_t) fl + (uint32_t) k;
-                                if (p < chosen) {
-                                    chosen = p;
-                                    const uint32_t e = readlane_u32(c.nb[k], fl);
-                                    chosen_nbr = e & 0x7FFFFFFFu;
-                                    chosen_anchor = (e >> 31) != 0;
-                                }
-                            }
-                        }
-                    }
-                }
+                pk = deg <= 256u   ? det_select_regs<4, SQRT>(a.ents, vs, lane, row, deg, skip_n_best)
+                     : deg <= 384u ? det_select_regs<6, SQRT>(a.ents, vs, lane, row, deg, skip_n_best)
+                     : deg <= 512u ? det_select_regs<8, SQRT>(a.ents, vs, lane, row, deg, skip_n_best)
+                                   : det_select_long<SQRT>(a.ents, vs, lane, row, deg, skip_n_best);
             }
+            go_back = pk.go_back;
+            const uint32_t chosen_nbr = pk.chosen_nbr, pushed = pk.pushed;
+            const bool chosen_anchor = pk.chosen_anchor;
             if (go_back) {
                 if (step_index == 0) break;                 // :246-248,268-271,319-322
                 if (went_back) break;                       // :251-253,274-276,325-327
@@ -1019,25 +1129,6 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 continue;
             }
             rec = a.rows[chosen_nbr];       // the next step's row record, requested before this step's bookkeeping
-            // :340-347: the FIRST entry in list order with the same (q_index, t_index) is pushed
-            uint32_t pushed = chosen;
-            for (uint32_t base = 0; base < deg; base += 256) {
-                const Chunk c = base == 0 ? c0 : load_chunk(a.ents, row, base, deg, lane);
-                uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
-                    const uint64_t hm = __ballot(pos < deg && (c.nb[k] & 0x7FFFFFFFu) == chosen_nbr);
-                    if (hm) {
-                        const uint32_t p = base + 4u * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k;
-                        best = p < best ? p : best;
-                    }
-                }
-                if (best != 0xFFFFFFFFu) {
-                    pushed = best;
-                    break;
-                }
-            }
             if (m + 2 > a.cap || nlog + 1 > a.cap) {
                 status = ST_SCRATCH_OVF;
                 break;
@@ -1171,8 +1262,12 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     }
 }
 
+// 6 waves per SIMD (80 vector registers): measured 9.9 ms against 10.2 ms at 5 and 9.96 ms at 8 (A. thaliana config)
+#ifndef TLM_DET_WAVES
+#define TLM_DET_WAVES 6
+#endif
 template <bool SQRT>
-__global__ __launch_bounds__(WALK_BLOCK) void walk_det_kernel(WalkArgs a) {
+__global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
