@@ -333,22 +333,6 @@ __global__ void padded_degree_kernel(uint32_t n_nodes, const uint32_t *__restric
     }
 }
 
-// Rows of the walk layout: node i (walk order) of padded length pd <= pitch starts at i * pitch (the walk kernel can
-// then address the list of a neighbour from its index alone, before that neighbour's row record has arrived); longer
-// rows are packed behind the region.  over[i] = padded length of an overflow row, else 0; then, after the scan of
-// over[], the starts.
-__global__ void overflow_degree_kernel(uint32_t n_nodes, const uint32_t *__restrict__ pd, uint32_t pitch,
-                                       uint32_t *__restrict__ over) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_nodes) over[i] = pd[i] > pitch ? pd[i] : 0u;
-}
-
-__global__ void row_start_kernel(uint32_t n_nodes, const uint32_t *__restrict__ pd, uint32_t pitch, uint32_t region,
-                                 uint32_t *__restrict__ start /* in: scan of over[]; out: row starts */) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_nodes) start[i] = pd[i] > pitch ? region + start[i] : i * pitch;
-}
-
 __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
                                                           const uint32_t *__restrict__ old_of_new,
                                                           const uint32_t *__restrict__ new_of_old,
@@ -359,7 +343,7 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
                                                           const uint32_t *__restrict__ q_start,
                                                           const uint32_t *__restrict__ t_start, uint2 *__restrict__ w_row,
                                                           uint2 *__restrict__ w_ent_es, uint2 *__restrict__ w_ent_os,
-                                                          uint2 *__restrict__ w_qt, uint32_t nb_shift, uint32_t pitch) {
+                                                          uint2 *__restrict__ w_qt, uint32_t nb_shift) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -379,11 +363,7 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
             if (real) {
                 es = ent_es[r0 + j];
                 os = ent_os[r0 + j];
-                // class of the neighbour: its padded list length / 8 when its row lies in the fixed-pitch region
-                const uint32_t on = es.x & 0x7FFFFFFFu;
-                const uint32_t pdn = tlm_padded_degree(row_ptr[on + 1] - row_ptr[on]);
-                const uint32_t cls = (pitch != 0u && pdn != 0u && pdn <= pitch) ? pdn / 8u : 0u;
-                const uint32_t w = tlm_nb_encode(new_of_old[on], cls, es.x >> 31, nb_shift);   // list order is kept
+                const uint32_t w = tlm_nb_encode(new_of_old[es.x & 0x7FFFFFFFu], 0u, es.x >> 31, nb_shift);   // list order is kept
                 es.x = w;
                 os.x = w;
             }
@@ -495,46 +475,22 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         if (int rc = dev_alloc(pd, ((size_t) N + 1) * 4)) return rc;
         if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
         uint64_t apad = 0;
-        g->w_nb_shift = N < (1u << 25) ? 12u : 6u;        // 6 class bits when the indices leave room for them
-        g->w_pitch = 0;
         if (N) {
-            const uint64_t packed_bound = g->n_adj + 23ull * N;
-            TLM_CHECK(packed_bound < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
-            // Fixed-pitch region: pitch = the longest padded list a class can name (63 * 8 entries), less if no list is
-            // that long, less again if N * pitch would not fit four times the packed layout (HBM is plentiful: 288 GB)
-            // or the u32 entry index.  Rows longer than the pitch are packed behind the region.
-            uint32_t pitch = 0;
-            if (g->w_nb_shift == 12u && !getenv("TLM_NO_FIXED_PITCH")) {
-                pitch = std::min<uint32_t>(tlm_padded_degree(g->info.max_degree), 504u);     // multiples of 8 entries (64 B)
-                const uint64_t budget = std::min<uint64_t>((1ull << 32) - 256 - packed_bound,
-                                                           std::max<uint64_t>(4ull * packed_bound, 1ull << 26));
-                if ((uint64_t) N * pitch > budget) pitch = (uint32_t) (budget / N / 8u) * 8u;
-                if (pitch < 48u) pitch = 0;
-            }
-            g->w_pitch = pitch;
+            TLM_CHECK(g->n_adj + 23ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
             hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, g->w_old_of_new,
                                pd.as<uint32_t>());
-            DevBuf over;
-            if (int rc = dev_alloc(over, ((size_t) N + 1) * 4)) return rc;
-            // pitch 0: every row is an "overflow" row, i.e. the packed layout
-            hipLaunchKernelGGL(overflow_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pd.as<uint32_t>(), pitch,
-                               over.as<uint32_t>());
             size_t tb = 0;
-            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, over.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
                                             rocprim::plus<uint32_t>(), s));
             DevBuf tmp;
             if (int rc = dev_alloc(tmp, tb)) return rc;
-            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, over.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
                                             rocprim::plus<uint32_t>(), s));
-            uint32_t last_scan = 0, last_over = 0;
-            TLM_HIP(hipMemcpyAsync(&last_scan, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipMemcpyAsync(&last_over, over.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            uint32_t last_start = 0, last_pd = 0;
+            TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(&last_pd, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
             TLM_HIP(hipStreamSynchronize(s));
-            const uint64_t region = (uint64_t) N * pitch;
-            apad = region + last_scan + last_over;
-            TLM_CHECK(apad < (1ull << 32) - 256, TLM_EINTERNAL, "walk layout: %llu entries", (unsigned long long) apad);
-            hipLaunchKernelGGL(row_start_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pd.as<uint32_t>(), pitch,
-                               (uint32_t) region, ws.as<uint32_t>());
+            apad = (uint64_t) last_start + last_pd;
         }
         g->n_adj_pad = apad;
         TLM_HIP(hipMalloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2)));
@@ -547,8 +503,7 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         if (N) {
             hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
                                g->w_old_of_new, new_of_old.as<uint32_t>(), ws.as<uint32_t>(), g->node_flags, g->ent_es,
-                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt, g->w_nb_shift,
-                               g->w_pitch);
+                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt, g->w_nb_shift);
         }
         TLM_HIP(hipStreamSynchronize(s));
     }
