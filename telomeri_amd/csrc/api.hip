@@ -456,8 +456,6 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         a.qt = g->w_qt;
         a.node_len = g->node_len;
         a.n_nodes = N;
-        a.nb_shift = g->w_nb_shift;
-        a.pitch = g->w_pitch;
         a.anchors = g->anchors;
         a.w_anchors = g->w_anchors;
         a.old_of_new = g->w_old_of_new;

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
                                                           const uint32_t *__restrict__ q_start,
                                                           const uint32_t *__restrict__ t_start, uint2 *__restrict__ w_row,
                                                           uint2 *__restrict__ w_ent_es, uint2 *__restrict__ w_ent_os,
-                                                          uint2 *__restrict__ w_qt, uint32_t nb_shift) {
+                                                          uint2 *__restrict__ w_qt) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -359,11 +359,11 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
             const bool real = j < deg;
             // padding names the row's own node: visited whenever a Monte-Carlo walk stands on it, so the walk kernel
             // needs no validity test per entry (no anchor bit, metric 0)
-            uint2 es = make_uint2(tlm_nb_encode(node, 0u, 0u, nb_shift), 0u), os = es;
+            uint2 es = make_uint2(node, 0u), os = make_uint2(node, 0u);
             if (real) {
                 es = ent_es[r0 + j];
                 os = ent_os[r0 + j];
-                const uint32_t w = tlm_nb_encode(new_of_old[es.x & 0x7FFFFFFFu], 0u, es.x >> 31, nb_shift);   // list order is kept
+                const uint32_t w = new_of_old[es.x & 0x7FFFFFFFu] | (es.x & 0x80000000u);   // list order is kept
                 es.x = w;
                 os.x = w;
             }
@@ -503,7 +503,7 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         if (N) {
             hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
                                g->w_old_of_new, new_of_old.as<uint32_t>(), ws.as<uint32_t>(), g->node_flags, g->ent_es,
-                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt, g->w_nb_shift);
+                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt);
         }
         TLM_HIP(hipStreamSynchronize(s));
     }

@@ -61,8 +61,6 @@ struct tlm_graph {
     // walk layout: every row padded to a multiple of 4 entries (32 B), so that a lane
     // reads its 4 consecutive entries with two aligned 16-byte loads; one 8-byte record per node
     uint64_t n_adj_pad = 0;
-    uint32_t w_nb_shift = 6;           // neighbour-word encoding of the walk layout, see tlm_nb_encode()
-    uint32_t w_pitch = 0;              // entries between consecutive rows of the fixed-pitch region (0 = none)
     uint2 *w_row = nullptr;            // [N] {padded row start, degree | order-safety flags << 24}
     uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
     uint2 *w_qt = nullptr;             // [n_adj_pad] {q_start, t_start}
@@ -76,19 +74,6 @@ struct tlm_graph {
     std::vector<uint64_t> h_det_off;
     tlm_graph_info info{};
 };
-
-// Neighbour word of a walk-layout entry.  From the top: the node's walk-order index without its low 5 bits, then
-// `sh - 6` bits of "class" (padded list length of that node / 8, 0 = unknown), the anchor bit (bit 5), and the low 5
-// bits of the index at the bottom -- where v_bfe_i32 finds the bit number of the visited-band word without a shift.
-// sh = 12 (6 class bits, indices below 2^25) or 6 (no class bits, indices below 2^31).
-__host__ __device__ inline uint32_t tlm_nb_encode(uint32_t id, uint32_t cls, uint32_t anchor, uint32_t sh) {
-    return ((id >> 5) << sh) | (cls << 6) | (anchor << 5) | (id & 31u);
-}
-__host__ __device__ inline uint32_t tlm_nb_id(uint32_t w, uint32_t sh) { return ((w >> sh) << 5) | (w & 31u); }
-__host__ __device__ inline uint32_t tlm_nb_anchor(uint32_t w) { return (w >> 5) & 1u; }
-__host__ __device__ inline uint32_t tlm_nb_class(uint32_t w, uint32_t sh) { return (w >> 6) & ((1u << (sh - 6u)) - 1u); }
-// the bits of a word that name the node (index high part + low 5 bits)
-__host__ __device__ inline uint32_t tlm_nb_idmask(uint32_t sh) { return ~(((1u << sh) - 1u) & ~31u); }
 
 // internal per-unit status codes beyond the public TLM_UNIT_* ones
 enum : uint8_t { ST_ABANDONED = 0, ST_ACCEPTED = 1, ST_NEGATIVE = 2, ST_SCRATCH_OVF = 3, ST_ARENA_OVF = 4, ST_NOT_RUN = 255 };

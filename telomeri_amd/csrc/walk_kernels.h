@@ -34,8 +34,6 @@ struct WalkArgs {
     const uint32_t *node_len;       // reference order
     const uint32_t *old_of_new;     // reference node index of a walk-order node (results are reported in those)
     uint32_t n_nodes;
-    uint32_t nb_shift;              // neighbour-word encoding (tlm_nb_encode)
-    uint32_t pitch;                 // fixed-pitch region: row of node i starts at i * pitch when its class is known
     uint32_t flag_bit;              // 1 << metric
     int32_t metric;
     // a launch may carry the same units under a second metric ("slot" 1): work item w = slot * n_units + unit

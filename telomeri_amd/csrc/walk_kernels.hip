@@ -60,8 +60,6 @@ struct HotArgs {
     uint32_t flag_bit;
     int32_t backtrack_attempts;
     int64_t len_threshold;
-    uint32_t nb_shift;
-    uint32_t pitch;
 };
 
 // Orders a wave's own LDS / global traffic between its lanes (lane 0 writes, all lanes read):
@@ -182,21 +180,9 @@ constexpr uint32_t WIN_WORDS = WIN_BITS / 32;
 constexpr uint32_t AFTER_SLOTS = 8;                     // closing sums of the first 8 chunks (2048 entries) of a long list
 struct Visited {
     uint32_t *win;      // 2 KB-aligned in LDS
-    uint32_t lo;        // first id of the band, a multiple of 32
+    uint32_t lo;
     uint32_t *bm;
-    uint32_t sh;        // neighbour-word encoding (tlm_nb_encode)
-    uint32_t lo_enc;    // (lo >> 5) << sh: subtracting it from a neighbour word leaves (id - lo) >> 5 above bit sh
 };
-
-__device__ __forceinline__ Visited make_visited(uint32_t *win, uint32_t *bm, uint32_t start, uint32_t sh) {
-    Visited vs;
-    vs.win = win;
-    vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
-    vs.bm = bm;
-    vs.sh = sh;
-    vs.lo_enc = (vs.lo >> 5) << sh;
-    return vs;
-}
 
 // LDS byte address of the band (the low 32 bits of a generic pointer into LDS are its LDS offset)
 __device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
@@ -371,18 +357,17 @@ __device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint3
 // Returns its position relative to the chunk (lane*K+k) or -1.  Padding entries carry no anchor bit; an inactive
 // lane repeats lane 0's entries, and lane 0 wins the find-first.
 template <int K>
-__device__ __forceinline__ int forced_in_lanes(const uint32_t (&nb)[K], uint32_t start, uint32_t sh, uint32_t &nbr_out) {
+__device__ __forceinline__ int forced_in_lanes(const uint32_t (&nb)[K], uint32_t start, uint32_t &nbr_out) {
     int best = -1;
-    const uint32_t idm = tlm_nb_idmask(sh), start_enc = tlm_nb_encode(start, 0u, 0u, sh);
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const uint64_t fm = __ballot(tlm_nb_anchor(nb[k]) && (nb[k] & idm) != start_enc);
+        const uint64_t fm = __ballot((nb[k] >> 31) && (nb[k] & 0x7FFFFFFFu) != start);
         if (fm) {
             const int fl = __ffsll((unsigned long long) fm) - 1;
             const int pos = fl * K + k;
             if (best < 0 || pos < best) {
                 best = pos;
-                nbr_out = tlm_nb_id(readlane_u32(nb[k], fl), sh);
+                nbr_out = readlane_u32(nb[k], fl) & 0x7FFFFFFFu;
             }
         }
     }
@@ -400,26 +385,25 @@ __device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&n
     for (int k = 0; k < K; k++) vis[k] = 0u;
     (void) any;
 #else
-    const uint32_t wb = lds_addr(vs.win);                             // multiple of 2048: `|` instead of `+`
+    const uint32_t wb = lds_addr(vs.win);                             // multiple of 2048: `|` instead of `+` (v_and_or_b32)
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        // ((id - lo) >> 5) sits above bit sh of d, the word's low bits ride along untouched (lo is a multiple of 32)
-        const uint32_t d = nb[k] - vs.lo_enc;
+        const uint32_t d = nb[k] - vs.lo;
         any |= d;
-        // word ((id - lo) >> 5) mod 512 of the band: always inside it, whatever d is.  Two instructions (the
-        // compiler's own form, shift + mask + or, takes three: a VOP3 cannot carry the literal)
+        // word (d >> 5) mod 512 of the band: always inside it, whatever d is
+        // two instructions (the compiler's own form, shift + mask + or, takes three: a VOP3 cannot carry the literal)
         static_assert(WIN_WORDS == 512u, "the bit-field width below is log2(WIN_WORDS)");
         uint32_t addr;
-        asm("v_bfe_u32 %0, %1, %3, 9\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=v"(addr) : "v"(d), "s"(wb), "s"(vs.sh));
+        asm("v_bfe_u32 %0, %1, 5, 9\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=v"(addr) : "v"(d), "s"(wb));
         vis[k] = *(__attribute__((address_space(3))) const uint32_t *) (uintptr_t) addr;
     }
-    // bit id & 31 = the word's own low 5 bits (v_bfe_i32 reads 5 bits of the offset): 0 or all ones
+    // bit (id - lo) & 31 == id & 31 (lo is a multiple of 32; v_bfe_i32 reads 5 bits of the offset): 0 or all ones
 #pragma unroll
     for (int k = 0; k < K; k++) vis[k] = (uint32_t) __builtin_amdgcn_sbfe((int) vis[k], nb[k], 1u);
-    if (__ballot(any >= (WIN_WORDS << vs.sh))) {    // rare: a neighbour outside the band
+    if (__ballot(any >= WIN_BITS)) {    // rare: an anchor neighbour, or a neighbour outside the band
 #pragma unroll
         for (int k = 0; k < K; k++)
-            if (nb[k] - vs.lo_enc >= (WIN_WORDS << vs.sh)) vis[k] = visited_test(vs, tlm_nb_id(nb[k], vs.sh)) ? ~0u : 0u;
+            if (nb[k] - vs.lo >= WIN_BITS) vis[k] = visited_test(vs, nb[k] & 0x7FFFFFFFu) ? ~0u : 0u;
     }
 #endif
 }
@@ -488,8 +472,8 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
     const int k = __builtin_amdgcn_readlane(myk, hl);
     const uint32_t e = readlane_u32(mynb, hl);
     s.pick = (int) base + hl * K + k;
-    s.nbr = tlm_nb_id(e, vs.sh);
-    s.anchor = tlm_nb_anchor(e) != 0;
+    s.nbr = e & 0x7FFFFFFFu;
+    s.anchor = (e >> 31) != 0;
 }
 
 // A list of at most 64*K entries: one load, one visited probe, ONE scan (it yields the total and every lane's
@@ -504,7 +488,7 @@ __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visite
     clk.mark(CLK_LIST_WAIT, true);
     if (anchor_nbr) {
         uint32_t fn = 0;
-        const int fpos = forced_in_lanes<K>(nb, start, vs.sh, fn);
+        const int fpos = forced_in_lanes<K>(nb, start, fn);
         if (fpos >= 0) {
             s.pick = fpos;
             s.nbr = fn;
@@ -546,7 +530,7 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, 
         const bool act = lane_load<K>(a.ents, row, base, deg, lane, nb, mb);
         if (anchor_nbr) {
             uint32_t fn = 0;
-            const int fpos = forced_in_lanes<K>(nb, start, vs.sh, fn);
+            const int fpos = forced_in_lanes<K>(nb, start, fn);
             if (fpos >= 0) {
                 s.pick = (int) base + fpos;
                 s.nbr = fn;
@@ -618,8 +602,8 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, 
         const int k = __builtin_amdgcn_readlane(myk, hl);
         const uint32_t e = readlane_u32(mynb, hl);
         s.pick = (int) base + hl * K + k;
-        s.nbr = tlm_nb_id(e, vs.sh);
-        s.anchor = tlm_nb_anchor(e) != 0;
+        s.nbr = e & 0x7FFFFFFFu;
+        s.anchor = (e >> 31) != 0;
         return s;
     }
     return s;
@@ -650,9 +634,9 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
             const uint32_t i = base + lane;
             const bool valid = i < deg;
             const uint2 ent = valid ? a.ents[row + i] : make_uint2(0u, 0u);
-            const uint32_t nbr = tlm_nb_id(ent.x, vs.sh);
+            const uint32_t nbr = ent.x & 0x7FFFFFFFu;
             if (pass == 0) {
-                const uint64_t fm = __ballot(valid && tlm_nb_anchor(ent.x) && nbr != start);     // :57
+                const uint64_t fm = __ballot(valid && (ent.x >> 31) && nbr != start);     // :57
                 if (fm) {
                     const int fl = __ffsll((unsigned long long) fm) - 1;
                     s.pick = (int) base + fl;
@@ -673,7 +657,7 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
                 if (pass == 1 && run >= random) {                                     // :110
                     s.pick = (int) base + j;
                     s.nbr = readlane_u32(nbr, j);
-                    s.anchor = tlm_nb_anchor(readlane_u32(ent.x, j)) != 0;
+                    s.anchor = (readlane_u32(ent.x, j) >> 31) != 0;
                     return s;
                 }
             }
@@ -689,7 +673,10 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     // `start` and every node id below are walk-order indices
     Rng rng{mt, ws.rng, 0};
     mt_seed((lds_u32 *) mt, (glb_u32 *) ws.rng, lane, seed);
-    const Visited vs = make_visited(win, ws.bm, start, a.nb_shift);
+    Visited vs;
+    vs.win = win;
+    vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
+    vs.bm = ws.bm;
     for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
     uint32_t n = start;
     uint32_t m = 0;          // p.edges_.size()
@@ -750,7 +737,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                     for (uint32_t base = 0; base < bdeg && !t; base += 64) {
                         const uint32_t i = base + lane;
                         const bool valid = i < bdeg;
-                        const uint32_t nbr = valid ? tlm_nb_id(a.ents[brow + i].x, vs.sh) : 0u;
+                        const uint32_t nbr = valid ? (a.ents[brow + i].x & 0x7FFFFFFFu) : 0u;
                         if (__ballot(valid && !visited_test(vs, valid ? nbr : vs.lo))) t = true;
                     }
                 } while (m != 0 && !t);
@@ -943,15 +930,15 @@ __device__ __forceinline__ DetPick det_select_regs(const uint2 *ents, const Visi
             if (p < r.chosen) {
                 r.chosen = p;
                 const uint32_t e = readlane_u32(nb[k], fl);
-                r.chosen_nbr = tlm_nb_id(e, vs.sh);
-                r.chosen_anchor = tlm_nb_anchor(e) != 0;
+                r.chosen_nbr = e & 0x7FFFFFFFu;
+                r.chosen_anchor = (e >> 31) != 0;
             }
         }
     }
     // ---- :340-347
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const uint64_t hm = __ballot(k < cnt && (nb[k] & tlm_nb_idmask(vs.sh)) == tlm_nb_encode(r.chosen_nbr, 0u, 0u, vs.sh));
+        const uint64_t hm = __ballot(k < cnt && (nb[k] & 0x7FFFFFFFu) == r.chosen_nbr);
         if (hm) r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
     }
     return r;
@@ -1027,8 +1014,8 @@ __device__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int
                         if (p < chosen) {
                             chosen = p;
                             const uint32_t e = readlane_u32(c.nb[k], fl);
-                            chosen_nbr = tlm_nb_id(e, vs.sh);
-                            chosen_anchor = tlm_nb_anchor(e) != 0;
+                            chosen_nbr = e & 0x7FFFFFFFu;
+                            chosen_anchor = (e >> 31) != 0;
                         }
                     }
                 }
@@ -1043,7 +1030,7 @@ __device__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t pos = base + 4u * (uint32_t) lane + (uint32_t) k;
-            const uint64_t hm = __ballot(pos < deg && (c.nb[k] & tlm_nb_idmask(vs.sh)) == tlm_nb_encode(chosen_nbr, 0u, 0u, vs.sh));
+            const uint64_t hm = __ballot(pos < deg && (c.nb[k] & 0x7FFFFFFFu) == chosen_nbr);
             if (hm) {
                 const uint32_t p = base + 4u * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k;
                 best = p < best ? p : best;
@@ -1073,12 +1060,15 @@ __device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
 template <bool SQRT>
 __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, int lane, uint32_t ui, uint32_t start,
                          uint32_t start_ref, uint32_t first_slot) {
-    const Visited vs = make_visited(win, ws.bm, start, a.nb_shift);
+    Visited vs;
+    vs.win = win;
+    vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
+    vs.bm = ws.bm;
     for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
     const uint32_t first = rfl(a.rows[start].x) + first_slot;
     const uint2 ent0 = a.ents[first];
-    const uint32_t second = tlm_nb_id(rfl(ent0.x), a.nb_shift);
-    const bool second_anchor = tlm_nb_anchor(rfl(ent0.x)) != 0;
+    const uint32_t second = rfl(ent0.x & 0x7FFFFFFFu);
+    const bool second_anchor = rfl(ent0.x >> 31) != 0;
     const int64_t len0 = (int64_t) a.node_len[start_ref];
     uint32_t m = 1, nlog = 0;           // nlog: marks that went to the HBM map
     int64_t acc = edge_delta(a.qt, first);
@@ -1267,8 +1257,6 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
         h.flag_bit = slot1 ? ca->flag_bit1 : a.flag_bit;
         h.backtrack_attempts = a.backtrack_attempts;
         h.len_threshold = a.len_threshold;
-        h.nb_shift = a.nb_shift;
-        h.pitch = a.pitch;
         const int64_t len0 = (int64_t) rfl(ca->node_len[start_ref]);
         mc_walk<SQRT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], lane, cu, start, walk_seed_dev(metric, start_ref, r), len0);
     }
