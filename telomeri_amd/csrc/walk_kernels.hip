@@ -667,9 +667,42 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
     return s;
 }
 
+// The path under construction (edge i, node i + 1) goes to the wave's HBM scratch -- but not one store per step: on
+// gfx9 loads and stores share one outstanding-operation counter and return out of order with respect to each other,
+// so a wave with a store in flight has to wait for ALL its memory operations before it may touch a loaded value.
+// The last PATH_RING entries live in LDS and are written out 32 at a time, by 64 lanes, in two store instructions.
+constexpr uint32_t PATH_RING = 32;
+struct PathRing {
+    uint32_t *ring;     // LDS: [0, 32) edge indices, [32, 64) nodes
+    uint32_t base;      // index of the first edge held in the ring
+    uint32_t cnt;       // edges held
+};
+
+__device__ __forceinline__ void ring_flush(PathRing &pr, const WaveScratch &ws, int lane) {
+    if (pr.cnt != 0u) {
+        const uint32_t j = (uint32_t) lane & (PATH_RING - 1u);
+        if (j < pr.cnt) {
+            const uint32_t v = pr.ring[lane];
+            if (lane < (int) PATH_RING) ws.pe[pr.base + j] = v;
+            else ws.pn[pr.base + j + 1u] = v;
+        }
+        pr.base += pr.cnt;
+        pr.cnt = 0u;
+    }
+    wave_sync();
+}
+
+// before the scratch is READ (backtracking, the end of the walk): everything out, and arrived
+__device__ __forceinline__ void ring_sync(PathRing &pr, const WaveScratch &ws, int lane) {
+    ring_flush(pr, ws, lane);
+    // the wave's own stores, then its own loads: in order through the same L1 / L2 once the stores are acknowledged
+    // (no cache maintenance: an agent-scope fence here invalidates the die's L2 under every other walk)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <bool SQRT>
-__device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after, int lane,
-                        uint32_t ui, uint32_t start, uint32_t seed, int64_t len0) {
+__device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after,
+                        uint32_t *ring, int lane, uint32_t ui, uint32_t start, uint32_t seed, int64_t len0) {
     // `start` and every node id below are walk-order indices
     Rng rng{mt, ws.rng, 0};
     mt_seed((lds_u32 *) mt, (glb_u32 *) ws.rng, lane, seed);
@@ -678,6 +711,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
     vs.bm = ws.bm;
     for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
+    PathRing pr{ring, 0u, 0u};
     uint32_t n = start;
     uint32_t m = 0;          // p.edges_.size()
     uint32_t nlog = 0;       // marks that went to the HBM map (ids outside the LDS band)
@@ -724,6 +758,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                                         // dereferences a null Edge* there; oracle and kernel abandon the walk
             // :72 dead end
             if (backtracks < a.backtrack_attempts && m > 1) {    // :76
+                ring_sync(pr, ws, lane);                // the pops below read the path from the scratch
                 bool t = false;
                 do {                                    // :78-88
                     // pop edge m-1: it was the pending one (never added); the new last edge m-2 leaves the sum
@@ -741,6 +776,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                         if (__ballot(valid && !visited_test(vs, valid ? nbr : vs.lo))) t = true;
                     }
                 } while (m != 0 && !t);
+                pr.base = m;                            // the ring is empty; the next edge pushed is edge m again
                 if (m == 0) break;                      // :90-95
                 ++backtracks;
                 n = rfl(ws.pn[m]);                      // :98
@@ -766,8 +802,8 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         const uint32_t md = s.nbr - vs.lo;
         const bool mark_far = md >= WIN_BITS && !s.forced;     // a forced pick ends the walk: nothing probes it again
         if (lane == 0) {
-            ws.pe[m] = eidx;
-            ws.pn[m + 1] = s.nbr;
+            pr.ring[pr.cnt] = eidx;                                             // edge m
+            pr.ring[PATH_RING + pr.cnt] = s.nbr;                                // node m + 1
             if (md < WIN_BITS) atomicOr(win + (md >> 5), 1u << (md & 31u));     // :123 (ds_or_b32)
             else if (mark_far) {
                 ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
@@ -791,6 +827,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         m++;
         n = s.nbr;
         wave_sync();
+        if (++pr.cnt == PATH_RING) ring_flush(pr, ws, lane);
         clk.mark(CLK_ADVANCE, false);
         if (len <= 0) break;                            // :126-128
         if (s.anchor) {                                 // :131-134
@@ -800,6 +837,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         if (len >= a.len_threshold) break;              // :137-142
     }
     clk.flush(lane);
+    ring_sync(pr, ws, lane);
     // acc holds the increments of edges 0..m-2 (the last pushed edge is still pending): exactly Path::length()
     const int64_t len_final = len0 + acc;
     if (acceptable && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :146-155
@@ -1230,6 +1268,7 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
     __shared__ double after_s[WALK_WAVES_PER_BLOCK][AFTER_SLOTS];
+    __shared__ uint32_t ring_s[WALK_WAVES_PER_BLOCK][2 * PATH_RING];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
@@ -1258,7 +1297,8 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
         h.backtrack_attempts = a.backtrack_attempts;
         h.len_threshold = a.len_threshold;
         const int64_t len0 = (int64_t) rfl(ca->node_len[start_ref]);
-        mc_walk<SQRT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], lane, cu, start, walk_seed_dev(metric, start_ref, r), len0);
+        mc_walk<SQRT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], ring_s[wib], lane, cu, start,
+                      walk_seed_dev(metric, start_ref, r), len0);
     }
 }
 
