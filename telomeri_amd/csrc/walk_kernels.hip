@@ -1096,8 +1096,8 @@ __device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
 }
 
 template <bool SQRT>
-__device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, int lane, uint32_t ui, uint32_t start,
-                         uint32_t start_ref, uint32_t first_slot) {
+__device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, uint32_t *ring, int lane, uint32_t ui,
+                         uint32_t start, uint32_t start_ref, uint32_t first_slot) {
     Visited vs;
     vs.win = win;
     vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
@@ -1109,6 +1109,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     const bool second_anchor = rfl(ent0.x >> 31) != 0;
     const int64_t len0 = (int64_t) a.node_len[start_ref];
     uint32_t m = 1, nlog = 0;           // nlog: marks that went to the HBM map
+    PathRing pr{ring, 1u, 0u};          // edge 0 and nodes 0, 1 are written directly below
     int64_t acc = edge_delta(a.qt, first);
     uint32_t steps = 0;
     uint64_t evals = 0;
@@ -1158,7 +1159,9 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 went_back = true;
                 step_index -= 1;
                 skip_n_best += 1;
+                ring_sync(pr, ws, lane);                    // the pop reads the path from the scratch
                 m--;                                        // pop node + edge
+                pr.base = m;
                 acc -= edge_delta(a.qt, rfl(ws.pe[m]));
                 node = rfl(ws.pn[m]);
                 if (lane == 0) visited_clear(vs, node);     // :262,284,335
@@ -1174,8 +1177,8 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
             const uint32_t eidx = row + pushed;
             const bool far_mark = node - vs.lo >= WIN_BITS;
             if (lane == 0) {
-                ws.pe[m] = eidx;
-                ws.pn[m + 1] = chosen_nbr;
+                pr.ring[pr.cnt] = eidx;                     // edge m
+                pr.ring[PATH_RING + pr.cnt] = chosen_nbr;   // node m + 1
                 visited_set(vs, node);                      // :355 marks the node being left
                 if (far_mark) ws.lg[nlog] = node;
             }
@@ -1187,6 +1190,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
             m++;
             node = chosen_nbr;                              // :356
             wave_sync();
+            if (++pr.cnt == PATH_RING) ring_flush(pr, ws, lane);
             if (chosen_anchor) {                            // :364-367
                 all_ok = true;
                 break;
@@ -1194,6 +1198,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
             step_index += 1;
         }
     }
+    ring_sync(pr, ws, lane);
     const int64_t len_final = len0 + acc - edge_delta(a.qt, rfl(ws.pe[m - 1]));
     if (all_ok && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :372-384
     finish_unit(ws, lane, ui, status, m, nlog, len_final, steps, evals, 0);
@@ -1309,6 +1314,7 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
 template <bool SQRT>
 __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
+    __shared__ uint32_t ring_s[WALK_WAVES_PER_BLOCK][2 * PATH_RING];
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
@@ -1324,7 +1330,7 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(Wal
             if (a.det_off[mid] <= unit) lo = mid;
             else hi = mid;
         }
-        det_walk<SQRT>(b, ws, win_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
+        det_walk<SQRT>(b, ws, win_s[wib], ring_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
                        (uint32_t) (unit - a.det_off[lo]));
     }
 }
