@@ -211,8 +211,31 @@ void parse_range(const char *p, const char *end, Chunk &c) {
 bool OverlapGraph::load(char *filepath, bool anchors) {
     ulong ctr = 0;
     if (!tokenize(filepath, anchors, ctr)) return false;
+    if (deferred_) {
+        pending_.emplace_back(filepath, ctr);
+        return true;
+    }
     if (!rebuild()) return false;
     std::cout << "Loaded " << edges_.size() << '/' << ctr << " edges from " << filepath << std::endl;   // :150
+    return true;
+}
+
+bool OverlapGraph::end_loads() {
+    deferred_ = false;
+    if (pending_.empty()) return true;
+    if (!rebuild()) return false;
+    tlm_graph_info gi;
+    tlm_graph_get_info(dev_, &gi);
+    // edges_.size() after each load in the reference = kept records of all files up to that one
+    const size_t first = files_.size() - pending_.size();
+    uint64_t kept = 0;
+    for (size_t i = 0; i < files_.size(); i++) {
+        kept += i < 4 ? gi.n_kept_per_file[i] : 0;      // (the ABI reports the first four files)
+        if (i >= first)
+            std::cout << "Loaded " << kept << '/' << pending_[i - first].second << " edges from " << pending_[i - first].first
+                      << std::endl;
+    }
+    pending_.clear();
     return true;
 }
 

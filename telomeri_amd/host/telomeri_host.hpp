@@ -79,6 +79,11 @@ public:
      *  Calls accumulate into one graph (Main.cpp:223 loads rr then cr). */
     bool load(char *filepath, bool anchors);
     std::string stats();                // OverlapGraph.cpp:24-95
+    /** Not in the reference.  Between begin_loads() and end_loads(), load() only tokenises its file; the device graph
+     *  is built and the public members are filled ONCE, by end_loads(), which then prints the "Loaded K/R edges" line
+     *  of every file.  Without the pair every load() rebuilds everything loaded so far (same final state). */
+    void begin_loads() { deferred_ = true; }
+    bool end_loads();
 
     // --- device side (not in the reference) ---
     tlm_graph *device_graph() const { return dev_; }
@@ -104,6 +109,8 @@ private:
     tlm_graph *dev_ = nullptr;
     double build_ms_ = 0, parse_ms_ = 0, download_ms_ = 0;
     bool parsed_parallel_ = false;
+    bool deferred_ = false;
+    std::vector<std::pair<std::string, ulong>> pending_;   // (path, records read) of the loads since begin_loads()
     bool rebuild();                     // device build over all files loaded so far + download into nodes_/edges_
 };
 
