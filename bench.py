@@ -42,6 +42,8 @@ def main() -> None:
     ap.add_argument("--no-det", action="store_true", help="skip the deterministic builders (diagnostics only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--separate-launches", action="store_true", help="one launch per builder and metric (diagnostics)")
+    ap.add_argument("--serial-builders", action="store_true",
+                    help="the deterministic launch after the Monte-Carlo launch has ended instead of in its tail (diagnostics)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,14 +100,18 @@ def main() -> None:
     def one_step():
         # the four builders of Main.cpp:237-243; the two metrics of a builder share one persistent launch
         sets, ctrs = [], []
-        if args.separate_launches:
+        if not (args.separate_launches or args.serial_builders or args.no_det):
+            # one call: the deterministic launch is queued behind the Monte-Carlo launch on a second stream
+            sets = list(g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, mc_range, (d0, d1)))
+            ctrs = [("mc", sets[0].counters), ("mc", sets[1].counters), ("det", sets[2].counters), ("det", sets[3].counters)]
+        elif args.separate_launches:
             for metric in (capi.METRIC_ES, capi.METRIC_OS):
                 ps = g.walk_mc(metric, wp, *mc_range)
                 sets.append(ps); ctrs.append(("mc", ps.counters))
         else:
             a, b = g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range)
             sets += [a, b]; ctrs += [("mc", a.counters), ("mc", b.counters)]
-        if not args.no_det:
+        if not args.no_det and (args.separate_launches or args.serial_builders):
             if args.separate_launches:
                 for metric in (capi.METRIC_ES, capi.METRIC_OS):
                     ps = g.walk_det(metric, d0, d1)

@@ -196,6 +196,15 @@ int tlm_walk_mc2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, c
 int tlm_walk_det2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, uint64_t unit_begin, uint64_t unit_end,
                   tlm_pathset **out2, tlm_counters *ctr2);
 
+/** The reference's four builder calls of main() (src/Main.cpp:237-243: buildMonteCarlo under two metrics, then
+ *  buildDeterministic under the same two) as ONE call: the deterministic launch is queued on a second, low-priority
+ *  stream behind the Monte-Carlo launch and fills the tail in which ever fewer Monte-Carlo waves are still walking.
+ *  out4 / counters4 (may be null): MC metric_a, MC metric_b, DET metric_a, DET metric_b -- the same Path sets,
+ *  element for element, as tlm_walk_mc2 + tlm_walk_det2 return. */
+int tlm_walk_builders(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, const tlm_walk_params *p,
+                      uint64_t mc_unit_begin, uint64_t mc_unit_end, uint64_t det_unit_begin, uint64_t det_unit_end,
+                      tlm_pathset **out4, tlm_counters *counters4);
+
 /* ---- a9: packed Path set -------------------------------------------------------------------- */
 /* path i = nodes[off[i] .. off[i+1]); slots[k] = position, inside nodes[k]'s list, of the edge to
  * nodes[k+1] (0xFFFFFFFF at a path's last node); unit[i] ascending; length[i] = Path::length(). */

@@ -112,6 +112,8 @@ def lib() -> C.CDLL:
     L.tlm_walk_det.argtypes = [V, V, C.c_int, C.c_uint64, C.c_uint64, P(V), P(Counters)]
     L.tlm_walk_mc2.argtypes = [V, V, C.c_int, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, P(V), P(Counters)]
     L.tlm_walk_det2.argtypes = [V, V, C.c_int, C.c_int, C.c_uint64, C.c_uint64, P(V), P(Counters)]
+    L.tlm_walk_builders.argtypes = [V, V, C.c_int, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                    P(V), P(Counters)]
     L.tlm_pathset_sizes.argtypes = [V, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
     L.tlm_pathset_export.argtypes = [V, C.c_int, V, V, V, V, V]
     L.tlm_pathset_unit_stats.argtypes = [V, V]
@@ -324,6 +326,16 @@ class Graph:
         ctr = (Counters * 2)()
         _check(lib().tlm_walk_det2(self.ctx._h, self._h, metric_a, metric_b, unit_begin, unit_end, h, ctr), "tlm_walk_det2")
         return PathSet(C.c_void_p(h[0]), ctr[0], self.ctx), PathSet(C.c_void_p(h[1]), ctr[1], self.ctx)
+
+    def walk_builders(self, metric_a: int, metric_b: int, wp: "WalkParams", mc_range=None, det_range=None):
+        """tlm_walk_builders: MC a, MC b, DET a, DET b (the deterministic launch fills the Monte-Carlo launch's tail)."""
+        mc0, mc1 = mc_range if mc_range is not None else (0, self.mc_units(wp))
+        d0, d1 = det_range if det_range is not None else (0, self.det_units())
+        h = (C.c_void_p * 4)()
+        ctr = (Counters * 4)()
+        _check(lib().tlm_walk_builders(self.ctx._h, self._h, metric_a, metric_b, C.byref(wp), mc0, mc1, d0, d1, h, ctr),
+               "tlm_walk_builders")
+        return tuple(PathSet(C.c_void_p(h[k]), ctr[k], self.ctx) for k in range(4))
 
     def walk_det(self, metric: int, unit_begin: int = 0, unit_end: Optional[int] = None) -> PathSet:
         if unit_end is None:

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include "tlm_common.h"
 #include "walk_kernels.h"
@@ -46,8 +48,17 @@ struct Workspace {   // walk scratch kept across calls (bench loops); bitmaps st
     }
 };
 
-struct CtxImpl : tlm_ctx {
+// A walk launch needs a stream, two events and a workspace.  Lane 0 is the context's own stream; lane 1 is a second,
+// low-priority stream on which tlm_walk_builders runs the deterministic builders into the tail of the Monte-Carlo launch.
+struct WalkLane {
     Workspace ws;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct CtxImpl : tlm_ctx {
+    Workspace ws;           // lane 0 (with ctx->stream, ev0, ev1)
+    WalkLane side;          // lane 1
 };
 
 extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
@@ -63,9 +74,14 @@ extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
     CtxImpl *c = new CtxImpl();
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // numerically lower = higher priority
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
         || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
-        || hipMalloc((void **) &c->ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess) {
+        || hipMalloc((void **) &c->ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess
+        || hipStreamCreateWithPriority(&c->side.stream, hipStreamNonBlocking, prio_lo) != hipSuccess
+        || hipEventCreate(&c->side.ev0) != hipSuccess || hipEventCreate(&c->side.ev1) != hipSuccess
+        || hipMalloc((void **) &c->side.ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess) {
         tlm_set_error("tlm_ctx_create: stream/event creation failed");
         delete c;
         return TLM_EHIP;
@@ -79,9 +95,16 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     (void) hipSetDevice(c->device);
     (void) hipStreamSynchronize(c->stream);
+    if (c->side.stream) (void) hipStreamSynchronize(c->side.stream);
     c->ws.release_scratch();
     c->ws.release_arena();
     (void) hipFree(c->ws.cursor);
+    c->side.ws.release_scratch();
+    c->side.ws.release_arena();
+    (void) hipFree(c->side.ws.cursor);
+    if (c->side.ev0) (void) hipEventDestroy(c->side.ev0);
+    if (c->side.ev1) (void) hipEventDestroy(c->side.ev1);
+    if (c->side.stream) (void) hipStreamDestroy(c->side.stream);
     (void) hipEventDestroy(c->ev0);
     (void) hipEventDestroy(c->ev1);
     (void) hipStreamDestroy(c->stream);
@@ -337,13 +360,12 @@ template <class T> int dmalloc(T **p, size_t n) {
     return TLM_OK;
 }
 
-int ensure_scratch(CtxImpl *c, uint32_t waves, uint32_t cap, uint32_t bm_words) {
-    Workspace &w = c->ws;
+int ensure_scratch(Workspace &w, hipStream_t stream, uint32_t waves, uint32_t cap, uint32_t bm_words) {
     if (w.waves >= waves && w.cap == cap && w.bm_words == bm_words) return TLM_OK;
     w.release_scratch();
     if (int rc = dmalloc(&w.scratch, (size_t) waves * cap * 3)) return rc;
     if (int rc = dmalloc(&w.bitmaps, (size_t) waves * bm_words)) return rc;
-    TLM_HIP(hipMemsetAsync(w.bitmaps, 0, (size_t) waves * bm_words * 4, c->stream));
+    TLM_HIP(hipMemsetAsync(w.bitmaps, 0, (size_t) waves * bm_words * 4, stream));
     w.waves = waves;
     w.cap = cap;
     w.bm_words = bm_words;
@@ -351,14 +373,13 @@ int ensure_scratch(CtxImpl *c, uint32_t waves, uint32_t cap, uint32_t bm_words) 
 }
 
 // Grow the arena to `need` entries, keeping the first `keep` entries.
-int ensure_arena(CtxImpl *c, uint64_t need, uint64_t keep) {
-    Workspace &w = c->ws;
+int ensure_arena(Workspace &w, hipStream_t stream, uint64_t need, uint64_t keep) {
     if (w.ar_cap >= need) return TLM_OK;
     uint2 *nn = nullptr;
     if (int rc = dmalloc(&nn, (size_t) need)) return rc;
     if (keep) {
-        TLM_HIP(hipMemcpyAsync(nn, w.arena, keep * sizeof(uint2), hipMemcpyDeviceToDevice, c->stream));
-        TLM_HIP(hipStreamSynchronize(c->stream));
+        TLM_HIP(hipMemcpyAsync(nn, w.arena, keep * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
+        TLM_HIP(hipStreamSynchronize(stream));
     }
     w.release_arena();
     w.arena = nn;
@@ -368,8 +389,15 @@ int ensure_arena(CtxImpl *c, uint64_t need, uint64_t keep) {
 
 // One launch over `n_slots` (1 or 2) metrics of the same units: work item = slot * n_units + unit.  Two metrics in one
 // persistent launch share the work queue, which halves the share of the tail (walk lengths differ by 2.5x).
+// `lane` 1 = the side stream and its workspace; `launched` (optional) is set once the first kernel of the call is in its
+// stream, or when the call gives up earlier; `wait_for` (optional) is waited for before that first kernel is launched.
 int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const int *metrics, const tlm_walk_params *p,
-              uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr) {
+              uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr, int lane = 0,
+              std::atomic<int> *launched = nullptr, std::atomic<int> *wait_for = nullptr) {
+    struct Signal {
+        std::atomic<int> *f;
+        ~Signal() { if (f) f->store(1); }
+    } signal{launched};
     TLM_CHECK(ctx && g && out && metrics, TLM_EINVAL, "walk: null argument");
     TLM_CHECK(g->ctx == ctx, TLM_EINVAL, "walk: graph belongs to another context");
     TLM_CHECK(n_slots == 1 || n_slots == 2, TLM_EINVAL, "walk: one or two metrics per launch");
@@ -381,7 +409,9 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     TLM_HIP(hipSetDevice(ctx->device));
     (void) hipGetLastError();     // a stale error of an unrelated earlier call must not be blamed on this one
-    hipStream_t s = ctx->stream;
+    Workspace &W = lane ? c->side.ws : c->ws;
+    hipStream_t s = lane ? c->side.stream : ctx->stream;
+    hipEvent_t ev0 = lane ? c->side.ev0 : ctx->ev0, ev1 = lane ? c->side.ev1 : ctx->ev1;
     const uint64_t total = is_mc ? tlm_mc_units(g, p) : tlm_det_units(g);
     if (unit_end > total) unit_end = total;
     if (unit_begin > unit_end) unit_begin = unit_end;
@@ -430,17 +460,17 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         waves = std::min<uint32_t>(waves, ((n_all + 3) / 4) * 4);
         waves = std::max<uint32_t>(4u, (waves / 4) * 4);
         cnt[0].waves = waves;
-        if (int rc = ensure_scratch(c, waves, cap, bm_words)) return rc;
+        if (int rc = ensure_scratch(W, s, waves, cap, bm_words)) return rc;
         // arena for the accepted paths: the worst case (every unit accepted at full buffer length) when
         // that fits 8 GiB, else a guess that the overflow re-run below corrects
         {
             const uint64_t worst = (uint64_t) n_all * cap;
             const uint64_t budget = (8ull << 30) / 8;
             const uint64_t want = worst <= budget ? worst : std::max<uint64_t>(budget, (uint64_t) n_all * 256u);
-            if (int rc = ensure_arena(c, std::max<uint64_t>(1u << 20, want), 0)) return rc;
+            if (int rc = ensure_arena(W, s, std::max<uint64_t>(1u << 20, want), 0)) return rc;
         }
-        unsigned long long *ar_cursor = (unsigned long long *) (c->ws.cursor + 2);
-        TLM_HIP(hipMemsetAsync(c->ws.cursor, 0, 16, s));
+        unsigned long long *ar_cursor = (unsigned long long *) (W.cursor + 2);
+        TLM_HIP(hipMemsetAsync(W.cursor, 0, 16, s));
 
         auto ents_of = [&](int m) { return (m == TLM_METRIC_ES || m == TLM_METRIC_ES_SQRT) ? g->w_ent_es : g->w_ent_os; };
         WalkArgs a;
@@ -465,7 +495,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         a.rebuild_attempts = is_mc ? p->rebuild_attempts : 1;
         a.backtrack_attempts = is_mc ? p->backtrack_attempts : 0;
         a.len_threshold = is_mc ? p->len_threshold : 0;
-        a.cursor = c->ws.cursor;
+        a.cursor = W.cursor;
         a.units = u.units;
 
         std::vector<uint32_t> work;     // empty = identity
@@ -480,25 +510,30 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             // quarter anchors keep the hit rate and cost nothing.
             a.chunk = !work.empty() ? 8u : is_mc ? (uint32_t) std::max(1, p->rebuild_attempts / 4) : 32u;
             if (const char *e = getenv("TLM_WALK_CHUNK")) a.chunk = (uint32_t) std::max(1, atoi(e));   // tuning experiments
-            a.scratch = c->ws.scratch;
-            a.cap = c->ws.cap;
-            a.bitmaps = c->ws.bitmaps;
-            a.bm_words = c->ws.bm_words;
-            a.arena = c->ws.arena;
-            a.ar_cap = c->ws.ar_cap;
+            a.scratch = W.scratch;
+            a.cap = W.cap;
+            a.bitmaps = W.bitmaps;
+            a.bm_words = W.bm_words;
+            a.arena = W.arena;
+            a.ar_cap = W.ar_cap;
             uint32_t launch_waves = std::min<uint32_t>(cur_waves, ((n_work + 3) / 4) * 4);
             launch_waves = std::max<uint32_t>(4u, launch_waves);
-            TLM_HIP(hipMemsetAsync(c->ws.cursor + WALK_QUEUE_BASE, 0, WALK_QUEUE_STRIDE * WALK_XCDS * 4, s));
-            TLM_HIP(hipEventRecord(ctx->ev0, s));
+            TLM_HIP(hipMemsetAsync(W.cursor + WALK_QUEUE_BASE, 0, WALK_QUEUE_STRIDE * WALK_XCDS * 4, s));
+            if (wait_for) {
+                while (!wait_for->load()) std::this_thread::yield();
+                wait_for = nullptr;
+            }
+            TLM_HIP(hipEventRecord(ev0, s));
             if (is_mc) tlm_launch_walk_mc(s, launch_waves / 4, sq, a);
             else tlm_launch_walk_det(s, launch_waves / 4, sq, a);
             TLM_HIP(hipGetLastError());
-            TLM_HIP(hipEventRecord(ctx->ev1, s));
+            TLM_HIP(hipEventRecord(ev1, s));
+            if (launched) launched->store(1);
             TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipEventSynchronize(ctx->ev1));
+            TLM_HIP(hipEventSynchronize(ev1));
             TLM_HIP(hipStreamSynchronize(s));
             float ms = 0;
-            TLM_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            TLM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             cnt[0].kernel_ms += ms;          // the launch is shared by the slots: it is booked on the first one
             cnt[0].kernel_launches++;
             // overflow handling: re-run the affected units with a full-size path buffer / a larger arena
@@ -515,7 +550,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 uint64_t keep = ~0ull, extra = 0;
                 for (uint32_t i : ar_ovf) { keep = std::min<uint64_t>(keep, h_units[i].off); extra += h_units[i].nnodes; }
                 // every reservation after the first failed one failed too, so [0, keep) is all valid paths
-                if (int rc = ensure_arena(c, (keep + extra) + (keep + extra) / 4 + (1u << 20), keep)) return rc;
+                if (int rc = ensure_arena(W, s, (keep + extra) + (keep + extra) / 4 + (1u << 20), keep)) return rc;
                 unsigned long long k = keep;
                 TLM_HIP(hipMemcpyAsync(ar_cursor, &k, 8, hipMemcpyHostToDevice, s));
                 TLM_HIP(hipStreamSynchronize(s));
@@ -527,7 +562,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 const uint64_t per_wave = (uint64_t) full_cap * 12u + (uint64_t) bm_words * 4u;
                 uint64_t w = (8ull << 30) / per_wave;
                 cur_waves = (uint32_t) std::max<uint64_t>(4, std::min<uint64_t>(cur_waves, (w / 4) * 4));
-                if (int rc = ensure_scratch(c, cur_waves, cur_cap, bm_words)) return rc;
+                if (int rc = ensure_scratch(W, s, cur_waves, cur_cap, bm_words)) return rc;
             }
             work = sc_ovf;
             work.insert(work.end(), ar_ovf.begin(), ar_ovf.end());
@@ -558,7 +593,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         if (n_units) {
             uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
             hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, du,
-                               u.p_index, u.n_off, c->ws.arena, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
+                               u.p_index, u.n_off, W.arena, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
             TLM_HIP(hipGetLastError());
         }
         TLM_HIP(hipMemcpyAsync(ps->off + ps->n_paths, &ps->n_nodes_total, 8, hipMemcpyHostToDevice, s));
@@ -612,6 +647,43 @@ extern "C" int tlm_walk_det2(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int
                              uint64_t unit_end, tlm_pathset **out2, tlm_counters *ctr2) {
     const int m[2] = {metric_a, metric_b};
     return run_walks(ctx, g, false, 2, m, nullptr, unit_begin, unit_end, out2, ctr2);
+}
+
+/* The reference's four builder calls (Main.cpp:237-243) as one call.  The deterministic walks are few and long: their
+ * launch lasts as long as its longest walk while most of the chip idles, and the Monte-Carlo launch ends in a tail in
+ * which ever fewer waves are still walking.  Here the deterministic launch goes to a second, low-priority stream right
+ * after the Monte-Carlo launch: its workgroups start wherever a Monte-Carlo workgroup has finished, i.e. in that tail.
+ * out4 / ctr4: MC metric_a, MC metric_b, DET metric_a, DET metric_b -- the Path sets of the four separate calls. */
+extern "C" int tlm_walk_builders(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, const tlm_walk_params *p,
+                                 uint64_t mc_begin, uint64_t mc_end, uint64_t det_begin, uint64_t det_end,
+                                 tlm_pathset **out4, tlm_counters *ctr4) {
+    TLM_CHECK(ctx && g && out4 && p, TLM_EINVAL, "tlm_walk_builders: null argument");
+    for (int k = 0; k < 4; k++) out4[k] = nullptr;
+    const int m[2] = {metric_a, metric_b};
+    tlm_counters cd[2], cm[2];
+    std::memset(cd, 0, sizeof(cd));
+    std::memset(cm, 0, sizeof(cm));
+    std::atomic<int> mc_launched{0};
+    int rc_det = TLM_OK;
+    char det_err[512] = "";
+    std::thread side([&] {
+        rc_det = run_walks(ctx, g, false, 2, m, nullptr, det_begin, det_end, out4 + 2, cd, 1, nullptr, &mc_launched);
+        if (rc_det != TLM_OK) std::snprintf(det_err, sizeof(det_err), "%s", tlm_last_error());
+    });
+    const int rc_mc = run_walks(ctx, g, true, 2, m, p, mc_begin, mc_end, out4, cm, 0, &mc_launched);
+    side.join();
+    if (rc_mc != TLM_OK || rc_det != TLM_OK) {
+        if (rc_mc == TLM_OK) tlm_set_error("%s", det_err);
+        for (int k = 0; k < 4; k++) {
+            tlm_pathset_destroy(out4[k]);
+            out4[k] = nullptr;
+        }
+        return rc_mc != TLM_OK ? rc_mc : rc_det;
+    }
+    if (ctr4) {
+        ctr4[0] = cm[0]; ctr4[1] = cm[1]; ctr4[2] = cd[0]; ctr4[3] = cd[1];
+    }
+    return TLM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -213,6 +213,33 @@ def test_two_metric_launch_equals_two_launches(ctx):
         dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS_SQRT, wp)
 
 
+@pytest.mark.parametrize("config,rb", [("toy", 30), ("sparse", 60)])
+def test_builders_call_equals_separate_calls(ctx, config, rb):
+    """tlm_walk_builders (DET queued on a second stream behind MC): the four Path sets of the four separate calls, and
+    of the oracle."""
+    ds = synth.make_config(config)
+    fp = capi.FilterParams.default()
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    wp = capi.WalkParams.default(rb_att=rb)
+    for rep in range(2):        # the second round reuses both workspaces
+        sets = dg.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp)
+        for ps, m in zip(sets[:2], (capi.METRIC_ES, capi.METRIC_OS)):
+            ops, octr, ostats = og.walk_mc(m, H.to_oracle_wp(wp), po.SEED_PER_WALK)
+            H.assert_stats_equal(ps.unit_stats(), ostats)
+            H.assert_paths_equal(ps.to_host(), ops)
+        for ps, m in zip(sets[2:], (capi.METRIC_ES, capi.METRIC_OS)):
+            ops, octr, ostats = og.walk_det(m)
+            H.assert_stats_equal(ps.unit_stats(), ostats)
+            H.assert_paths_equal(ps.to_host(), ops)
+    # unit ranges (the sharding contract) pass through
+    n_mc, n_det = dg.mc_units(wp), dg.det_units()
+    part = dg.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, (n_mc // 3, n_mc // 2), (1, max(1, n_det // 2)))
+    whole = dg.walk_mc(capi.METRIC_OS, wp).unit_stats()
+    np.testing.assert_array_equal(part[1].unit_stats(), whole[n_mc // 3:n_mc // 2])
+    np.testing.assert_array_equal(part[3].unit_stats(), dg.walk_det(capi.METRIC_OS).unit_stats()[1:max(1, n_det // 2)])
+
+
 @pytest.mark.parametrize("name,mode", [("quirks", "min"), ("tiny", "avg"), ("toy", "avg")])
 def test_filter_unique_and_anchor_pairs_on_device(ctx, name, mode):
     """SURVEY.md §8f row 1 on the packed Path sets: concat (paths_ of one PathManager), filterUnique,
