@@ -19,6 +19,10 @@ struct StepClock {
         t = __builtin_amdgcn_s_memtime();
     }
     __device__ __forceinline__ void mark(int phase, bool wait_loads) {     // closes `phase`
+#ifdef TLM_TIMING_ROW1
+        if (wait_loads && phase == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // leave the youngest load out
+        else
+#endif
         if (wait_loads) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint64_t now = __builtin_amdgcn_s_memtime();
         acc[phase] += now - t;
@@ -49,6 +53,14 @@ __device__ __forceinline__ ColdArgs *cold_args() {
     uint64_t p = (uint64_t) __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return (ColdArgs *) p;
+}
+
+// A {u32, u32} record of a table that no kernel writes, at a wave-uniform index: through the constant address space the
+// load becomes s_load_dwordx2 -- the scalar cache path, results in scalar registers, counted by lgkmcnt: it neither
+// occupies vector registers around the loop nor takes part in the in-order return of the vector loads.
+__device__ __forceinline__ uint2 scalar_load_u2(const uint2 *table, uint32_t index) {
+    const uint64_t v = ((__attribute__((address_space(4))) const uint64_t *) table)[index];
+    return make_uint2((uint32_t) v, (uint32_t) (v >> 32));
 }
 
 // What the step loop itself reads (stays in scalar registers for the whole walk).
@@ -347,7 +359,11 @@ __device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint3
     const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + (act ? first : base));
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
+#ifdef TLM_ABLATE_HALFLIST  /* timing-only build: half the list bytes, same instruction stream (results are wrong) */
+        const uint4 v = p[j & (K / 4 - 1 >= 0 ? (K / 4 > 0 ? K / 4 - 1 : 0) : 0)];
+#else
         const uint4 v = p[j];      // (non-temporal loads were tried: 120 -> 179 ms, the lists do get reused in L2)
+#endif
         nb[2 * j] = v.x; mb[2 * j] = v.y; nb[2 * j + 1] = v.z; mb[2 * j + 1] = v.w;
     }
     return act;
@@ -732,7 +748,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         win[d >> 5] |= 1u << (d & 31u);
     }
     wave_sync();
-    uint2 rec = a.rows[n];
+    uint2 rec = scalar_load_u2(a.rows, n);
     StepClock clk;
     clk.start();
     for (;;) {                                          // :48
@@ -782,18 +798,18 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                 n = rfl(ws.pn[m]);                      // :98
                 {   // the new last edge's increment becomes the pending one again
                     const uint32_t le = rfl(ws.pe[m - 1]);
-                    const uint2 qt = a.qt[le];
+                    const uint2 qt = scalar_load_u2(a.qt, le);
                     pend_qs = qt.x;
                     pend_ts = qt.y;
                     have_pend = true;
                 }
-                rec = a.rows[n];
+                rec = scalar_load_u2(a.rows, n);
                 continue;
             }
             break;                                      // :101
         }
         // ---- advance (:118-123)
-        rec = a.rows[s.nbr];        // the next step's row record: requested before this step's bookkeeping
+        rec = scalar_load_u2(a.rows, s.nbr);    // the next step's row record: requested before this step's bookkeeping
         if (m + 2 > a.cap || nlog + 1 > a.cap) {
             status = ST_SCRATCH_OVF;
             break;
@@ -818,11 +834,16 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         // them for a divergent loop -- every loop-carried scalar would then live in a vector register)
         if (have_pend) acc += (int64_t) rfl(pend_qs) - (int64_t) rfl(pend_ts);
         const int64_t len = len0 + acc;
+#ifdef TLM_ABLATE_NOQT      /* timing-only build: no {q_start, t_start} load (results are wrong) */
+        pend_qs = 8u;
+        pend_ts = 3u;
+#else
         {
-            const uint2 qt = a.qt[eidx];
+            const uint2 qt = scalar_load_u2(a.qt, eidx);
             pend_qs = qt.x;
             pend_ts = qt.y;
         }
+#endif
         have_pend = true;
         m++;
         n = s.nbr;
