@@ -1131,7 +1131,6 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     const int64_t len0 = (int64_t) a.node_len[start_ref];
     uint32_t m = 1, nlog = 0;           // nlog: marks that went to the HBM map
     PathRing pr{ring, 1u, 0u};          // edge 0 and nodes 0, 1 are written directly below
-    int64_t acc = edge_delta(a.qt, first);
     uint32_t steps = 0;
     uint64_t evals = 0;
     uint8_t status = ST_ABANDONED;
@@ -1157,7 +1156,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
         uint32_t skip_n_best = 0;
         bool went_back = false;
         uint32_t node = second;
-        uint2 rec = a.rows[node];
+        uint2 rec = scalar_load_u2(a.rows, node);
         for (;;) {                                          // :243
             const uint32_t row = rfl(rec.x);
             const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
@@ -1183,14 +1182,13 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 ring_sync(pr, ws, lane);                    // the pop reads the path from the scratch
                 m--;                                        // pop node + edge
                 pr.base = m;
-                acc -= edge_delta(a.qt, rfl(ws.pe[m]));
                 node = rfl(ws.pn[m]);
                 if (lane == 0) visited_clear(vs, node);     // :262,284,335
                 wave_sync();
-                rec = a.rows[node];
+                rec = scalar_load_u2(a.rows, node);
                 continue;
             }
-            rec = a.rows[chosen_nbr];       // the next step's row record, requested before this step's bookkeeping
+            rec = scalar_load_u2(a.rows, chosen_nbr);       // the next step's row record, requested before the bookkeeping
             if (m + 2 > a.cap || nlog + 1 > a.cap) {
                 status = ST_SCRATCH_OVF;
                 break;
@@ -1204,10 +1202,6 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 if (far_mark) ws.lg[nlog] = node;
             }
             if (far_mark) nlog++;
-            {   // (readfirstlane keeps the loop-carried sum in scalar registers)
-                const uint2 qt = a.qt[eidx];
-                acc += (int64_t) rfl(qt.x) - (int64_t) rfl(qt.y);
-            }
             m++;
             node = chosen_nbr;                              // :356
             wave_sync();
@@ -1220,7 +1214,13 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
         }
     }
     ring_sync(pr, ws, lane);
-    const int64_t len_final = len0 + acc - edge_delta(a.qt, rfl(ws.pe[m - 1]));
+    // Path::length() (Path.cpp:6-16): the first node plus the increments of all edges but the last.  Nothing in the
+    // walk depends on it (:372-384 look at it once, at the end), so it is summed here, from the finished path, by all
+    // lanes -- not edge by edge inside the step loop.
+    int64_t part = 0;
+    for (uint32_t i = lane; i + 1u < m; i += 64) part += edge_delta(a.qt, ws.pe[i]);
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+    const int64_t len_final = len0 + (int64_t) __shfl(part, 0);
     if (all_ok && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :372-384
     finish_unit(ws, lane, ui, status, m, nlog, len_final, steps, evals, 0);
 }
