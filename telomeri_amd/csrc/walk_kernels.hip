@@ -314,8 +314,8 @@ __device__ inline void finish_unit(const WaveScratch &ws, int lane, uint32_t ui,
 struct Selection {
     int pick;            // position in the list, -1 = none
     uint32_t nbr;        // neighbour at `pick`
-    bool anchor;         // its anchor flag
-    bool forced;         // taken by the forced-anchor rule (:57-60)
+    uint32_t anchor;     // its anchor flag (0 / 1: 32-bit on purpose -- a bool carried around in scalar registers is a 64-bit lane mask)
+    uint32_t forced;     // taken by the forced-anchor rule (:57-60)
     uint32_t ncand;      // unvisited neighbours seen (0 with pick < 0 = dead end)
     uint32_t evals;      // adjacency entries examined
 };
@@ -489,7 +489,7 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
     const uint32_t e = readlane_u32(mynb, hl);
     s.pick = (int) base + hl * K + k;
     s.nbr = e & 0x7FFFFFFFu;
-    s.anchor = (e >> 31) != 0;
+    s.anchor = e >> 31;
 }
 
 // A list of at most 64*K entries: one load, one visited probe, ONE scan (it yields the total and every lane's
@@ -498,7 +498,7 @@ template <int K, bool SQRT>
 __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
                                                   uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
                                                   uint32_t &draws, StepClock &clk) {
-    Selection s{-1, 0u, false, false, 0u, deg};
+    Selection s{-1, 0u, 0u, 0u, 0u, deg};
     uint32_t nb[K], mb[K], vis[K];
     const bool act = lane_load<K>(a.ents, row, 0u, deg, lane, nb, mb);
     clk.mark(CLK_LIST_WAIT, true);
@@ -508,7 +508,7 @@ __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visite
         if (fpos >= 0) {
             s.pick = fpos;
             s.nbr = fn;
-            s.anchor = s.forced = true;
+            s.anchor = s.forced = 1u;
             s.evals = (uint32_t) fpos + 1u;
             return s;
         }
@@ -537,7 +537,7 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, 
                                               uint32_t &draws) {
     constexpr int K = 8;
     constexpr uint32_t C = 64u * K;
-    Selection s{-1, 0u, false, false, 0u, deg};
+    Selection s{-1, 0u, 0u, 0u, 0u, deg};
     double total = 0.0;
     uint32_t ci = 0;
     bool any_cand = false;
@@ -550,7 +550,7 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, 
             if (fpos >= 0) {
                 s.pick = (int) base + fpos;
                 s.nbr = fn;
-                s.anchor = s.forced = true;
+                s.anchor = s.forced = 1u;
                 s.evals = (uint32_t) s.pick + 1u;
                 return s;
             }
@@ -619,7 +619,7 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, 
         const uint32_t e = readlane_u32(mynb, hl);
         s.pick = (int) base + hl * K + k;
         s.nbr = e & 0x7FFFFFFFu;
-        s.anchor = (e >> 31) != 0;
+        s.anchor = e >> 31;
         return s;
     }
     return s;
@@ -632,7 +632,7 @@ template <bool SQRT>
 __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
                                                 uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws, bool have_u,
                                                 double u_given) {
-    Selection s{-1, 0u, false, false, 0u, deg};
+    Selection s{-1, 0u, 0u, 0u, 0u, deg};
     double total = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         double run = 0.0;
@@ -657,7 +657,7 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
                     const int fl = __ffsll((unsigned long long) fm) - 1;
                     s.pick = (int) base + fl;
                     s.nbr = readlane_u32(nbr, fl);
-                    s.anchor = s.forced = true;
+                    s.anchor = s.forced = 1u;
                     s.evals = (uint32_t) s.pick + 1u;
                     return s;
                 }
@@ -673,7 +673,7 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
                 if (pass == 1 && run >= random) {                                     // :110
                     s.pick = (int) base + j;
                     s.nbr = readlane_u32(nbr, j);
-                    s.anchor = (readlane_u32(ent.x, j) >> 31) != 0;
+                    s.anchor = readlane_u32(ent.x, j) >> 31;
                     return s;
                 }
             }
@@ -733,7 +733,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     uint32_t nlog = 0;       // marks that went to the HBM map (ids outside the LDS band)
     int64_t acc = 0;         // sum of the increments of edges 0..m-2 (all but the last pushed one)
     uint32_t pend_qs = 0, pend_ts = 0;   // q_start / t_start of the last pushed edge, in flight
-    bool have_pend = false;
+    uint32_t have_pend = 0u;   // (32-bit on purpose, see Selection)
     int backtracks = 0;
     uint32_t steps = 0, draws = 0;
     uint64_t evals = 0;
@@ -779,7 +779,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                 do {                                    // :78-88
                     // pop edge m-1: it was the pending one (never added); the new last edge m-2 leaves the sum
                     m--;
-                    have_pend = false;
+                    have_pend = 0u;
                     if (m >= 1) acc -= edge_delta(a.qt, rfl(ws.pe[m - 1]));
                     const uint32_t back = rfl(ws.pn[m]);
                     const uint2 brec = a.rows[back];
@@ -801,7 +801,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                     const uint2 qt = scalar_load_u2(a.qt, le);
                     pend_qs = qt.x;
                     pend_ts = qt.y;
-                    have_pend = true;
+                    have_pend = 1u;
                 }
                 rec = scalar_load_u2(a.rows, n);
                 continue;
@@ -844,7 +844,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
             pend_ts = qt.y;
         }
 #endif
-        have_pend = true;
+        have_pend = 1u;
         m++;
         n = s.nbr;
         wave_sync();
