@@ -1,11 +1,12 @@
 // telomeri_amd/csrc/walk_kernels.h -- device side of the contig-to-contig walks (gfx950).
 //
 // One 64-lane wavefront per live walk (north_star): the neighbour list of the current node is
-// read as coalesced 8-byte {neighbour|anchor, metric} entries, lane i holding entry base+i; the
+// read as coalesced 8-byte {neighbour|anchor, metric} entries, lane l holding K consecutive entries
+// (K = 4 / 6 / 8 by list length: aligned 16-byte loads, the list read once per step); the
 // forced-anchor test, the visited test, the roulette prefix sums (MC) and the rank arg-max (DET)
-// are wave ballots / scans / reductions.  Waves are persistent and pull walk units from one atomic
-// cursor, so divergent walk lengths do not idle the chip; every wave leaves when the cursor passes
-// the end of the work list.  No MFMA: integer / fp32 / fp64 scalar work bound by HBM/L2 gathers.
+// are wave ballots / DPP scans / DPP reductions.  Waves are persistent and pull walk units from one
+// atomic cursor per XCD, so divergent walk lengths do not idle the chip; every wave leaves when all
+// cursors have passed the end of the work list.  No MFMA: integer / fp32 / fp64 work on HBM/L2 gathers.
 //
 //   MC  : PathManager::buildMonteCarlo     reference src/PathManager.cpp:12-177
 //   DET : PathManager::buildDeterministic  reference src/PathManager.cpp:179-386
@@ -27,7 +28,7 @@ struct UnitOut {
 
 // Kernel arguments.  Kept small on purpose: every pointer is two SGPRs that stay live across the walk loop.
 struct WalkArgs {
-    // graph (tlm_graph, walk layout: rows padded to 4 entries, nodes in locality order)
+    // graph (tlm_graph, walk layout: rows padded to 8 entries, nodes in locality order)
     const uint2 *rows;              // per node {row start, degree | order-safety flags << 24}
     const uint2 *ents;              // w_ent_es or w_ent_os
     const uint2 *qt;                // per entry {q_start, t_start}: the length increment of Path::updateLength
