@@ -58,8 +58,9 @@ struct tlm_graph {
     uint32_t *node_len = nullptr;
     uint8_t *node_anchor = nullptr;
     uint8_t *node_flags = nullptr;
-    // walk layout: every row padded to a multiple of 4 entries (32 B), so that a lane
-    // reads its 4 consecutive entries with two aligned 16-byte loads; one 8-byte record per node
+    // walk layout: every row padded to a multiple of 8 entries (24 for degrees 257..384), so that a lane
+    // reads its 4 / 6 / 8 consecutive entries with aligned 16-byte loads; padding names the row's own node; one
+    // 8-byte record per node
     uint64_t n_adj_pad = 0;
     uint2 *w_row = nullptr;            // [N] {padded row start, degree | order-safety flags << 24}
     uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
