@@ -685,6 +685,18 @@ static void mc_walk(scratch *s, int metric, const tlo_walk_params *p, uint32_t s
     clear_visited(s);
 }
 
+/* Rank key of a metric for the deterministic builder's sort: for every pair of non-NaN values, key(a) > key(b)
+ * exactly when a > b (with -0 == +0), i.e. the comparator of PathManager.cpp:293-295.  With a NaN in the list (the
+ * square root of a negative score) that comparator is not a strict weak ordering and std::stable_sort's result is
+ * undefined; oracle and kernel define it: NaNs are ordered by their bit pattern, negative ones below every number,
+ * positive ones above (the IEEE total order).  DESIGN.md section 5. */
+static inline uint32_t rank_key(float m) {
+    uint32_t b;
+    memcpy(&b, &m, 4);
+    if (b == 0x80000000u) b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 /* stable merge sort of edge indices, descending by metric (PathManager.cpp:289-296) */
 static void sort_desc_stable(const tlo_graph *g, int metric, uint64_t *a, uint64_t *tmp, uint64_t n) {
     for (uint64_t w = 1; w < n; w *= 2) {
@@ -693,7 +705,7 @@ static void sort_desc_stable(const tlo_graph *g, int metric, uint64_t *a, uint64
             uint64_t i = lo, j = mid, k = lo;
             while (i < mid && j < hi) {
                 /* take from the right run only if it is strictly greater: stability */
-                if (metric_of(g, metric, a[j]) > metric_of(g, metric, a[i])) tmp[k++] = a[j++];
+                if (rank_key(metric_of(g, metric, a[j])) > rank_key(metric_of(g, metric, a[i]))) tmp[k++] = a[j++];
                 else tmp[k++] = a[i++];
             }
             while (i < mid) tmp[k++] = a[i++];

@@ -378,6 +378,49 @@ def test_walks_across_lane_widths(ctx):
     _walk_both(ctx, dg, og, capi.METRIC_OS, None, mc=False)
 
 
+@pytest.mark.parametrize("seed", list(range(64)))
+def test_fuzz_small_graphs(ctx, seed):
+    """Random small graphs with everything the generators above keep apart mixed together: nodes without a list,
+    multi-edges, lists of one entry, several anchors next to each other or none reachable, metrics that are zero,
+    negative zero, negative, huge, tiny or equal (ties in the deterministic ranks), random walk parameters."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(4, 70))
+    degrees = rng.integers(0, int(rng.choice([3, 8, 70, 300])), size=n).astype(np.int64)
+    anchors = (rng.random(n) < rng.choice([0.05, 0.2, 0.6])).astype(np.uint8)
+    if anchors.sum() == 0:
+        anchors[int(rng.integers(0, n))] = 1
+    row_ptr = np.zeros(n + 1, np.uint64)
+    row_ptr[1:] = np.cumsum(degrees)
+    a = int(row_ptr[-1])
+    nbr = rng.integers(0, n, size=a).astype(np.uint32)
+    owner = np.repeat(np.arange(n, dtype=np.uint32), degrees)
+    nbr = np.where(nbr == owner, (nbr + 1) % n, nbr).astype(np.uint32)
+    kind = rng.choice(["ints", "ties", "wild", "zeros"])
+    if kind == "ints":
+        es = rng.integers(0, 5000, size=a).astype(np.float32)
+        os_ = (rng.integers(0, 40000, size=a) / 16.0).astype(np.float32)
+    elif kind == "ties":
+        es = rng.integers(1, 4, size=a).astype(np.float32)
+        os_ = np.full(a, 2.5, np.float32)
+    elif kind == "wild":
+        es = ((rng.random(a) - 0.2) * np.exp2(rng.integers(-30, 40, size=a))).astype(np.float32)
+        os_ = (rng.random(a) * np.exp2(rng.integers(-60, 60, size=a))).astype(np.float32)
+    else:
+        es = np.where(rng.random(a) < 0.7, 0.0, 3.0).astype(np.float32)
+        os_ = np.where(rng.random(a) < 0.5, -0.0, 0.0).astype(np.float32)
+    q_start = rng.integers(0, 9000, size=a).astype(np.uint32)
+    t_start = rng.integers(0, 9000, size=a).astype(np.uint32)
+    node_len = rng.integers(1, 90000, size=n).astype(np.uint32)
+    args = (row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    dg = ctx.graph_from_csr(*args)
+    og = po.Graph.from_csr(*args)
+    wp = capi.WalkParams.default(rb_att=int(rng.integers(1, 40)), bt_att=int(rng.integers(0, 8)),
+                                 len_thr=int(rng.choice([20_000, 200_000, 4_700_000])))
+    for metric in (capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_ES_SQRT, capi.METRIC_OS_SQRT):
+        _walk_both(ctx, dg, og, metric, wp, mc=True)
+        _walk_both(ctx, dg, og, metric, None, mc=False)
+
+
 def test_rng_stream_through_long_walks(ctx):
     """More than 312 draws in one walk crosses an mt19937 twist on the device."""
     row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors = _synthetic_csr(n_reads=3000, deg=40, seed=3)
