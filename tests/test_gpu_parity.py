@@ -123,6 +123,46 @@ def test_graph_build_single_file_and_empty(ctx):
     assert len(ps.to_host()) == 0
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_graph_build(ctx, seed):
+    """Random records, degenerate ones included (start beyond end, zero lengths, matches above the overlap, the same
+    pair many times, a name only ever seen as query, contigs as queries): filter, scores and adjacency bit for bit."""
+    import dataclasses
+    rng = np.random.default_rng(500 + seed)
+    base = synth.make_config("tiny")
+    n_names = base.n_reads + base.n_contigs
+
+    def records(n, ctg_targets):
+        ln = rng.integers(1, 60_000, size=n_names)
+        q = rng.integers(0, n_names, size=n)
+        t = rng.integers(base.n_reads, n_names, size=n) if ctg_targets else rng.integers(0, n_names, size=n)
+        if rng.random() < 0.5:                      # a few pairs many times over (multi-edges)
+            k = max(1, n // 5)
+            q[:k], t[:k] = q[0], t[0]
+        qs = (rng.random(n) * ln[q]).astype(np.int64)
+        qe = np.minimum(qs + rng.integers(0, 30_000, size=n), ln[q])
+        ts = (rng.random(n) * ln[t]).astype(np.int64)
+        te = np.minimum(ts + rng.integers(0, 30_000, size=n), ln[t])
+        bad = rng.random(n) < 0.05                  # start beyond end
+        qs[bad], qe[bad] = qe[bad] + 3, qs[bad]
+        m = (rng.random(n) * (np.abs(qe - qs) + 5)).astype(np.int64)
+        i32 = lambda v: torch.tensor(np.asarray(v), dtype=torch.int32)
+        return synth.Records(i32(q), i32(t), i32(ln[q]), i32(qs), i32(qe), i32(ln[t]), i32(ts), i32(te), i32(m),
+                             i32(rng.integers(0, 2, size=n)))
+
+    ds = dataclasses.replace(base, rr=records(int(rng.integers(0, 400)), False), cr=records(int(rng.integers(1, 60)), True))
+    mode = str(rng.choice(["avg", "min", "max", "sum"]))
+    extra = {} if rng.random() < 0.5 else dict(min_oll=int(rng.integers(0, 8000)), min_olp=float(rng.random() * 0.3),
+                                               max_ohl=int(rng.integers(100, 40_000)), max_ohp=float(rng.random()))
+    fp = capi.FilterParams.default(mode, **extra)
+    dg = H.device_graph(ctx, ds, fp)
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    H.assert_csr_equal(dg.download(), og.csr())
+    assert dg.det_units() == og.det_units()
+    ids = dg.download().node_name_id
+    assert [og.node_ext_id(i) for i in range(len(ids))] == ids.tolist()
+
+
 # ---------------------------------------------------------------------------------------------
 # a7 / a8
 
