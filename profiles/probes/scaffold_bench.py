@@ -35,7 +35,8 @@ def main():
         out["input_bytes"] = sum(os.path.getsize(p) for p in (rr, cr, reads, contigs))
         out["dataset_written_s"] = time.time() - t0
         t0 = time.time()
-        res = subprocess.run([binary, rr, cr, reads, contigs, fasta], capture_output=True, text=True)
+        res = subprocess.run([binary, rr, cr, reads, contigs, fasta], capture_output=True, text=True, env=dict(os.environ, TLM_HOST_TIMING="1"))
+        out["host_timing"] = [ln for ln in res.stderr.splitlines() if ln.startswith("[host timing]")]
         out["wall_s"] = time.time() - t0
         out["exit"] = res.returncode
         done = [float(x) for x in re.findall(r"Done \(([0-9.e+-]+)s\)", res.stdout)]

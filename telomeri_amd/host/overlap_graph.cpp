@@ -424,6 +424,7 @@ bool OverlapGraph::rebuild() {
                            si.data(), es.data(), strand.data(), node_len.data(), anchor.data(), name_id.data()) != TLM_OK)
         die("tlm_graph_download");
     if (tlm_graph_kept_records(dev_, kept.data()) != TLM_OK) die("tlm_graph_kept_records");
+    const auto t_copied = std::chrono::steady_clock::now();
     nodes_.clear();
     nodes_.resize(N);
     std::vector<uint32_t> node_of_name(names_.size(), 0xFFFFFFFFu);
@@ -449,22 +450,53 @@ bool OverlapGraph::rebuild() {
             });
         for (auto &x : th) x.join();
     }
+    const auto t_nodes = std::chrono::steady_clock::now();
     // edges_ in record order (OverlapGraph.cpp:241): the k-th kept record's unswapped copy is the next unread
-    // entry of its target's list (per-node order is record order, each record adds one entry to either list)
-    edges_.clear();
-    edges_.reserve(kept.size());
-    std::vector<uint32_t> cursor(N, 0);
+    // entry of its target's list (per-node order is record order, each record adds one entry to either list).
+    // Every thread scans all kept records but advances only the list cursors of its own range of nodes, and writes the
+    // edges_ slots of the records whose target lies in that range.
+    const size_t K = kept.size();
+    std::vector<uint32_t> qn(K), tn(K);
     std::vector<size_t> base(files_.size() + 1, 0);
     for (size_t i = 0; i < files_.size(); i++) base[i + 1] = base[i] + files_[i].q_id.size();
-    for (uint32_t g : kept) {
-        size_t fi = 0;
-        while (g >= base[fi + 1]) fi++;
-        const size_t r = g - base[fi];
-        const uint32_t qn = node_of_name[(size_t) files_[fi].q_id[r]], tn = node_of_name[(size_t) files_[fi].t_id[r]];
-        edges_.push_back(nodes_[tn].edges[cursor[tn]++]);
-        cursor[qn]++;
+    edges_.clear();
+    edges_.resize(K);
+    {
+        unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        if (K < 65536) nt = 1;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                size_t fi = 0;
+                for (size_t k = K * t / nt; k < K * (t + 1) / nt; k++) {
+                    const uint32_t g = kept[k];
+                    while (g >= base[fi + 1]) fi++;
+                    while (g < base[fi]) fi--;
+                    const size_t r = g - base[fi];
+                    qn[k] = node_of_name[(size_t) files_[fi].q_id[r]];
+                    tn[k] = node_of_name[(size_t) files_[fi].t_id[r]];
+                }
+            });
+        for (auto &x : th) x.join();
+        th.clear();
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                const uint32_t lo = (uint32_t) (N * t / nt), hi = (uint32_t) (N * (t + 1) / nt);
+                std::vector<uint32_t> cursor(hi - lo, 0);
+                for (size_t k = 0; k < K; k++) {
+                    const uint32_t a = tn[k], q = qn[k];
+                    if (a >= lo && a < hi) edges_[k] = nodes_[a].edges[cursor[a - lo]++];
+                    if (q >= lo && q < hi) cursor[q - lo]++;
+                }
+            });
+        for (auto &x : th) x.join();
     }
-    download_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count();
+    const auto t_end = std::chrono::steady_clock::now();
+    download_ms_ = std::chrono::duration<double, std::milli>(t_end - t_dl).count();
+    if (getenv("TLM_HOST_TIMING"))
+        std::cerr << "[host timing] device->host copies " << std::chrono::duration<double, std::milli>(t_copied - t_dl).count()
+                  << " ms, nodes_ " << std::chrono::duration<double, std::milli>(t_nodes - t_copied).count() << " ms, edges_ "
+                  << std::chrono::duration<double, std::milli>(t_end - t_nodes).count() << " ms" << std::endl;
     return true;
 }
 

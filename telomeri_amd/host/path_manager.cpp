@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 #include "../../include/telomeri_hip.h"
 
@@ -74,21 +75,29 @@ void PathManager::append_from(const OverlapGraph &g, tlm_pathset *ps) {
         std::cerr << "telomeri_hip: export failed: " << tlm_last_error() << std::endl;
         std::exit(1);
     }
-    // Path objects in set order = the reference's append order (PathManager.cpp:154,226,382)
-    paths_.reserve(paths_.size() + n_paths);
-    for (uint64_t i = 0; i < n_paths; i++) {
-        Path p;
-        const uint64_t a = off[i], b = off[i + 1];
-        p.nodes_.reserve(b - a);
-        p.edges_.reserve(b - a - 1);
-        for (uint64_t k = a; k < b; k++) {
-            const OverlapGraph::Node *n = &g.nodes_[nodes[k]];
-            p.nodes_.push_back(n);
-            if (k + 1 < b) p.edges_.push_back(&n->edges[slots[k]]);
-        }
-        p.setLength((long) length[i]);
-        paths_.push_back(std::move(p));
-    }
+    // Path objects in set order = the reference's append order (PathManager.cpp:154,226,382); the pointer chasing
+    // into nodes_[..].edges is spread over the host cores
+    const size_t base = paths_.size();
+    paths_.resize(base + n_paths);
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (n_paths < 256) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            for (uint64_t i = n_paths * t / nt; i < n_paths * (t + 1) / nt; i++) {
+                Path &p = paths_[base + i];
+                const uint64_t a = off[i], b = off[i + 1];
+                p.nodes_.resize(b - a);
+                p.edges_.resize(b - a - 1);
+                for (uint64_t k = a; k < b; k++) {
+                    const OverlapGraph::Node *n = &g.nodes_[nodes[k]];
+                    p.nodes_[k - a] = n;
+                    if (k + 1 < b) p.edges_[k - a] = &n->edges[slots[k]];
+                }
+                p.setLength((long) length[i]);
+            }
+        });
+    for (auto &x : th) x.join();
 }
 
 tlm_pathset *PathManager::single_set() {
