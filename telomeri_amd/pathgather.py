@@ -109,7 +109,12 @@ def allgather_paths(local: Sequence[PackedPaths], group=None) -> List[PackedPath
     max_len = max(int(m[-1]) for m in metas)
     padded = torch.zeros(max(max_len, 1), dtype=torch.int64, device=payload.device)
     padded[:payload.shape[0]] = payload
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)          # the single exchange of the data path
+    # one receive buffer, rank r's shard at [r * max_len, (r + 1) * max_len): RCCL writes it in place
+    recv = torch.empty(world * padded.shape[0], dtype=torch.int64, device=payload.device)
+    bufs = list(recv.chunk(world))
+    try:
+        dist.all_gather_into_tensor(recv, padded, group=group)      # the single exchange of the data path
+    except (RuntimeError, NotImplementedError):                      # backends without the flat variant
+        dist.all_gather(bufs, padded, group=group)
     per_rank = [unpack(m[:-1], b[:int(m[-1])]) for m, b in zip(metas, bufs)]
     return [concat([per_rank[r][b] for r in range(world)]) for b in range(len(local))]
