@@ -768,6 +768,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         clk.mark(CLK_SELECT, false);
 #ifdef TLM_TIMING
         clk.steps++;
+        if (anchor_nbr) clk.acc[CLK_OTHER]++;       // steps on rows that hold an anchor
 #endif
         if (s.pick < 0) {
             if (s.ncand != 0) break;    // no prefix reached `random` (NaN / negative metrics): the reference
@@ -1384,9 +1385,9 @@ void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const 
         (void) hipStreamSynchronize(s);
         (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(tlm_timing), sizeof(h));
         if (h[5])
-            fprintf(stderr, "[tlm timing] %llu steps; cycles per step: row-record wait %.0f, list wait %.0f, selection %.0f, "
-                            "bookkeeping %.0f\n", h[5], (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5],
-                    (double) h[3] / h[5]);
+            fprintf(stderr, "[tlm timing] %llu steps (%.1f %% on rows that hold an anchor); cycles per step: row-record wait "
+                            "%.0f, list wait %.0f, selection %.0f, bookkeeping %.0f\n", h[5], 100.0 * h[4] / h[5],
+                    (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[3] / h[5]);
     }
 #endif
 }
