@@ -21,6 +21,26 @@ void tlm_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *tlm_last_error(void) { return g_err; }
+
+int tlm_pool_alloc(void **p, size_t bytes, hipStream_t s) {
+    static thread_local int warmed_device = -1;
+    int dev = 0;
+    TLM_HIP(hipGetDevice(&dev));
+    if (warmed_device != dev) {         // keep freed blocks in the pool instead of returning them to the driver
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t never = ~0ull;
+            (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
+        }
+        warmed_device = dev;
+    }
+    TLM_HIP(hipMallocAsync(p, bytes ? bytes : 1, s));
+    return TLM_OK;
+}
+
+void tlm_pool_free(void *p) {
+    if (p) (void) hipFreeAsync(p, nullptr);
+}
 extern "C" int tlm_abi_version(void) { return TLM_ABI_VERSION; }
 
 extern "C" uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r) {
@@ -350,8 +370,8 @@ struct UnitBufs {
     uint64_t *n_off = nullptr, *totals = nullptr;
     uint32_t *work_list = nullptr;
     ~UnitBufs() {
-        (void) hipFree(units); (void) hipFree(p_index); (void) hipFree(n_off); (void) hipFree(totals);
-        (void) hipFree(work_list);
+        tlm_pool_free(units); tlm_pool_free(p_index); tlm_pool_free(n_off); tlm_pool_free(totals);
+        tlm_pool_free(work_list);
     }
 };
 
@@ -359,6 +379,8 @@ template <class T> int dmalloc(T **p, size_t n) {
     TLM_HIP(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
     return TLM_OK;
 }
+
+template <class T> int pmalloc(T **p, size_t n, hipStream_t s) { return tlm_pool_alloc((void **) p, (n ? n : 1) * sizeof(T), s); }
 
 int ensure_scratch(Workspace &w, hipStream_t stream, uint32_t waves, uint32_t cap, uint32_t bm_words) {
     if (w.waves >= waves && w.cap == cap && w.bm_words == bm_words) return TLM_OK;
@@ -436,11 +458,11 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
     std::memset(cnt, 0, sizeof(cnt));
 
     UnitBufs u;
-    if (int rc = dmalloc(&u.units, n_all)) return rc;
-    if (int rc = dmalloc(&u.p_index, n_units)) return rc;
-    if (int rc = dmalloc(&u.n_off, n_units)) return rc;
-    if (int rc = dmalloc(&u.totals, 2)) return rc;
-    if (int rc = dmalloc(&u.work_list, n_all)) return rc;
+    if (int rc = pmalloc(&u.units, n_all, s)) return rc;
+    if (int rc = pmalloc(&u.p_index, n_units, s)) return rc;
+    if (int rc = pmalloc(&u.n_off, n_units, s)) return rc;
+    if (int rc = pmalloc(&u.totals, 2, s)) return rc;
+    if (int rc = pmalloc(&u.work_list, n_all, s)) return rc;
     TLM_HIP(hipMemsetAsync(u.units, 0xFF, (size_t) (n_all ? n_all : 1) * sizeof(UnitOut), s));   // status = not run
 
     std::vector<UnitOut> h_units(n_all);
@@ -585,11 +607,11 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             ps->n_paths = h_tot[0];
             ps->n_nodes_total = h_tot[1];
         }
-        if (int rc = dmalloc(&ps->unit, ps->n_paths)) return rc;
-        if (int rc = dmalloc(&ps->length, ps->n_paths)) return rc;
-        if (int rc = dmalloc(&ps->off, ps->n_paths + 1)) return rc;
-        if (int rc = dmalloc(&ps->nodes, ps->n_nodes_total)) return rc;
-        if (int rc = dmalloc(&ps->slots, ps->n_nodes_total)) return rc;
+        if (int rc = pmalloc(&ps->unit, ps->n_paths, s)) return rc;
+        if (int rc = pmalloc(&ps->length, ps->n_paths, s)) return rc;
+        if (int rc = pmalloc(&ps->off, ps->n_paths + 1, s)) return rc;
+        if (int rc = pmalloc(&ps->nodes, ps->n_nodes_total, s)) return rc;
+        if (int rc = pmalloc(&ps->slots, ps->n_nodes_total, s)) return rc;
         if (n_units) {
             uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
             hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, du,
@@ -721,7 +743,10 @@ extern "C" int tlm_pathset_unit_stats(const tlm_pathset *ps, tlm_unit_stat *stat
 extern "C" void tlm_pathset_destroy(tlm_pathset *ps) {
     if (!ps) return;
     (void) hipSetDevice(ps->device);
-    (void) hipFree(ps->unit); (void) hipFree(ps->length); (void) hipFree(ps->off); (void) hipFree(ps->nodes);
-    (void) hipFree(ps->slots);
+    // hipFree used to wait for the device; the pool does not, so make sure no kernel is still reading the set (a
+    // no-op when the device is idle, which it is whenever a caller lets go of a set after using it)
+    (void) hipDeviceSynchronize();
+    tlm_pool_free(ps->unit); tlm_pool_free(ps->length); tlm_pool_free(ps->off); tlm_pool_free(ps->nodes);
+    tlm_pool_free(ps->slots);
     delete ps;
 }

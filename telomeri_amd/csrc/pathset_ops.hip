@@ -18,9 +18,9 @@
 
 namespace {
 
-template <class T> int dmalloc(T **p, size_t n) {
-    TLM_HIP(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
-    return TLM_OK;
+// path-set buffers come from the stream-ordered pool (tlm_pathset_destroy releases them with tlm_pool_free)
+template <class T> int dmalloc(T **p, size_t n, hipStream_t s) {
+    return tlm_pool_alloc((void **) p, (n ? n : 1) * sizeof(T), s);
 }
 
 struct Tmp {
@@ -34,8 +34,9 @@ int alloc_pathset(tlm_ctx *ctx, uint64_t n_paths, uint64_t n_nodes, tlm_pathset 
     ps->device = ctx->device;
     ps->n_paths = n_paths;
     ps->n_nodes_total = n_nodes;
-    if (dmalloc(&ps->unit, n_paths) || dmalloc(&ps->length, n_paths) || dmalloc(&ps->off, n_paths + 1)
-        || dmalloc(&ps->nodes, n_nodes) || dmalloc(&ps->slots, n_nodes)) {
+    hipStream_t s = ctx->stream;
+    if (dmalloc(&ps->unit, n_paths, s) || dmalloc(&ps->length, n_paths, s) || dmalloc(&ps->off, n_paths + 1, s)
+        || dmalloc(&ps->nodes, n_nodes, s) || dmalloc(&ps->slots, n_nodes, s)) {
         tlm_pathset_destroy(ps);
         return TLM_EHIP;
     }

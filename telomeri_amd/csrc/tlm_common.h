@@ -91,6 +91,12 @@ struct tlm_pathset {
     std::vector<tlm_unit_stat> stats;   // host copy
 };
 
+// Buffers that live for one call or belong to a path set come from the device's stream-ordered memory pool (kept warm:
+// release threshold = never): hipMalloc / hipFree of hundreds of megabytes per builder call cost milliseconds and
+// synchronise the device.  tlm_pool_free may run after the context is gone (path sets outlive it in the Python tests).
+int tlm_pool_alloc(void **p, size_t bytes, hipStream_t s);
+void tlm_pool_free(void *p);
+
 // graph build (csr_build.hip)
 int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g);   // node_flags, anchors, det_off, info
 
