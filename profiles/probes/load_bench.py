@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """SURVEY.md §8f row 2 measurement: wall-clock of PAF ingestion on E. coli-shaped text (4.9 M records, ~0.5 GB).
   * C++ host tokeniser alone, 1 thread and all threads (`telomeri_hip --parse-only`)
-  * the oracle's sequential loader (C restatement of the reference's operator>> loop + filter + adjacency), as the
-    CPU baseline ("port"; the unmodified reference's load is O(nodes x records) and would take hours here)
+    (the CPU comparison -- the oracle's sequential loader -- is a test-tier matter: tests/test_host_ingest.py; nothing
+    outside tests/, smoke() and bench.py's cpu_baseline leg touches oracle/)
   * the full host load (tokenise + device graph build + download) through `telomeri_hip`
 Writes one JSON line.  Run on the GPU box: python profiles/probes/load_bench.py [config]"""
 import json
@@ -19,7 +19,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import pandas as pd
 
-from oracle import pyoracle as po
 from telomeri_amd import synth
 
 
@@ -57,13 +56,6 @@ def main():
             out[label + "_ms"] = ms
             out[label + "_records_per_s"] = out["records"] / (ms * 1e-3)
             out[label + "_GBps"] = out["bytes"] / (ms * 1e-3) / 1e9
-        t0 = time.time()
-        g = po.Graph()
-        fp = po.FilterParams.default()
-        assert g.load_paf(rr, False, fp) and g.load_paf(cr, True, fp)
-        c = g.csr()
-        out["oracle_load_ms"] = 1e3 * (time.time() - t0)
-        out["oracle_records_per_s"] = out["records"] / (time.time() - t0)
         if os.path.exists("/dev/kfd"):
             t0 = time.time()
             res = subprocess.run([binary, "--rb-att", "1", rr, cr, "r", "c", "o"], capture_output=True, text=True, check=True)
@@ -72,8 +64,6 @@ def main():
                           r"download\+materialise ([0-9.e+-]+) ms", res.stdout)
             out["host_load"] = {"tokenise_ms": float(m.group(1)), "mode": m.group(2), "device_build_ms": float(m.group(3)),
                                 "download_materialise_ms": float(m.group(4))}
-            k = re.search(r"Loaded (\d+)/", res.stdout.split("cr.paf")[0].rsplit("\n", 1)[-1] + "cr.paf")
-            out["kept_matches_oracle"] = ("Loaded %d/" % c.n_edges) in res.stdout
     print(json.dumps(out))
 
 

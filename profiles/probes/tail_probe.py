@@ -31,4 +31,4 @@ print("anchors by mean, longest first: %.3f" % (makespan(lpt) / ideal))
 pil = per_anchor[:, :16].mean(axis=1)          # what a 16-trial pilot would see
 lpt2 = np.concatenate([per_anchor[i] for i in np.argsort(-pil)])
 print("anchors by 16-trial pilot mean: %.3f" % (makespan(lpt2) / ideal))
-print("walks sorted, longest first (oracle): %.3f" % (makespan(np.sort(steps)[::-1]) / ideal))
+print("walks sorted, longest first (hindsight): %.3f" % (makespan(np.sort(steps)[::-1]) / ideal))
