@@ -76,6 +76,11 @@ def main() -> None:
     torch.cuda.synchronize(dev)
     t_gen = time.time() - t0
     fp = capi.FilterParams.default()
+    # the graph is built twice: the first build pays one-off costs (code-object loading of the rocPRIM kernels, first
+    # hipMalloc of GB-sized buffers), the second one is what a build costs
+    g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+    cold_build_ms = float(g.info().build_ms)
+    del g
     t0 = time.time()
     g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
     t_build = time.time() - t0
@@ -197,7 +202,7 @@ def main() -> None:
         "kernels": {"walk_mc_ms_per_step": mc_ms / max(args.steps, 1), "walk_det_ms_per_step": det_ms / max(args.steps, 1),
                     "walk_mc_evals_per_s": mc_evals / (mc_ms * 1e-3) if mc_ms else None,
                     "walk_det_evals_per_s": det_evals / (det_ms * 1e-3) if det_ms else None,
-                    "graph_build_device_ms": gi.build_ms, "filter_score_ms": gi.filter_ms,
+                    "graph_build_cold_ms": cold_build_ms, "graph_build_device_ms": gi.build_ms, "filter_score_ms": gi.filter_ms,
                     "filter_score_records_per_s": n_records / (gi.filter_ms * 1e-3) if gi.filter_ms else None,
                     "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
         "paths_per_step": paths_total,

@@ -175,17 +175,18 @@ extern "C" int tlm_filter_score(tlm_ctx *ctx, const tlm_filter_params *p, const 
 extern "C" void tlm_graph_destroy(tlm_graph *g) {
     if (!g) return;
     (void) hipSetDevice(g->device);
-    (void) hipFree(g->row_ptr); (void) hipFree(g->ent_es); (void) hipFree(g->ent_os);
-    (void) hipFree(g->q_start); (void) hipFree(g->t_start); (void) hipFree(g->q_end); (void) hipFree(g->t_end);
-    (void) hipFree(g->si); (void) hipFree(g->strand); (void) hipFree(g->node_len); (void) hipFree(g->node_anchor);
-    (void) hipFree(g->node_flags); (void) hipFree(g->node_name_id); (void) hipFree(g->anchors); (void) hipFree(g->det_off);
-    (void) hipFree(g->w_row); (void) hipFree(g->w_ent_es); (void) hipFree(g->w_ent_os); (void) hipFree(g->w_qt);
-    (void) hipFree(g->kept_rec); (void) hipFree(g->w_old_of_new); (void) hipFree(g->w_anchors);
+    (void) hipDeviceSynchronize();      // the pool does not wait for kernels that may still read the graph
+    tlm_pool_free(g->row_ptr); tlm_pool_free(g->ent_es); tlm_pool_free(g->ent_os);
+    tlm_pool_free(g->q_start); tlm_pool_free(g->t_start); tlm_pool_free(g->q_end); tlm_pool_free(g->t_end);
+    tlm_pool_free(g->si); tlm_pool_free(g->strand); tlm_pool_free(g->node_len); tlm_pool_free(g->node_anchor);
+    tlm_pool_free(g->node_flags); tlm_pool_free(g->node_name_id); tlm_pool_free(g->anchors); tlm_pool_free(g->det_off);
+    tlm_pool_free(g->w_row); tlm_pool_free(g->w_ent_es); tlm_pool_free(g->w_ent_os); tlm_pool_free(g->w_qt);
+    tlm_pool_free(g->kept_rec); tlm_pool_free(g->w_old_of_new); tlm_pool_free(g->w_anchors);
     delete g;
 }
 
 template <class T> static int upload(T **dst, const T *src, size_t n, hipStream_t s) {
-    TLM_HIP(hipMalloc((void **) dst, (n ? n : 1) * sizeof(T)));
+    if (int rc = tlm_pool_alloc((void **) dst, (n ? n : 1) * sizeof(T), s)) return rc;
     if (n && src) TLM_HIP(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
     else if (n) TLM_HIP(hipMemsetAsync(*dst, 0, n * sizeof(T), s));
     return TLM_OK;

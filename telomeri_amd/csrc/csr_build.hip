@@ -27,20 +27,22 @@
 
 namespace {
 
+// Every buffer of a build -- temporaries and the graph's own arrays -- comes from the stream-ordered pool
+// (tlm_pool_alloc): a second build reuses the first one's memory instead of paying for fresh GB-sized mappings.
+static thread_local hipStream_t t_build_stream = nullptr;     // the stream of the build running on this thread
+
 struct DevBuf {   // RAII for temporaries
     void *p = nullptr;
-    ~DevBuf() { if (p) (void) hipFree(p); }
+    ~DevBuf() { if (p) tlm_pool_free(p); }
     template <class T> T *as() { return (T *) p; }
 };
 
 int dev_alloc(DevBuf &b, size_t bytes) {
-    TLM_HIP(hipMalloc(&b.p, bytes ? bytes : 16));
-    return TLM_OK;
+    return tlm_pool_alloc(&b.p, bytes ? bytes : 16, t_build_stream);
 }
 
 template <class T> int dev_alloc_keep(T **out, size_t n) {
-    TLM_HIP(hipMalloc((void **) out, (n ? n : 1) * sizeof(T)));
-    return TLM_OK;
+    return tlm_pool_alloc((void **) out, (n ? n : 1) * sizeof(T), t_build_stream);
 }
 
 struct FileCols {
@@ -384,8 +386,9 @@ unsigned grid_for(uint64_t n) {
 
 int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     hipStream_t s = ctx->stream;
+    t_build_stream = s;
     const uint32_t N = g->n_nodes;
-    TLM_HIP(hipMalloc((void **) &g->node_flags, N ? N : 1));
+    if (int rc = tlm_pool_alloc((void **) &g->node_flags, N ? N : 1, s)) return rc;
     DevBuf cnts;
     if (int rc = dev_alloc(cnts, 8 * sizeof(uint32_t))) return rc;
     TLM_HIP(hipMemsetAsync(cnts.p, 0, 8 * sizeof(uint32_t), s));
@@ -408,14 +411,14 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     g->info.n_anchors = na;
     g->info.n_nodes = N;
     g->info.n_adj = g->n_adj;
-    TLM_HIP(hipMalloc((void **) &g->anchors, (na ? na : 1) * sizeof(uint32_t)));
-    TLM_HIP(hipMalloc((void **) &g->w_anchors, (na ? na : 1) * sizeof(uint32_t)));
-    TLM_HIP(hipMalloc((void **) &g->det_off, ((size_t) na + 1) * sizeof(uint64_t)));
+    if (int rc = tlm_pool_alloc((void **) &g->anchors, (na ? na : 1) * sizeof(uint32_t), s)) return rc;
+    if (int rc = tlm_pool_alloc((void **) &g->w_anchors, (na ? na : 1) * sizeof(uint32_t), s)) return rc;
+    if (int rc = tlm_pool_alloc((void **) &g->det_off, ((size_t) na + 1) * sizeof(uint64_t), s)) return rc;
     g->h_det_off.assign((size_t) na + 1, 0);
     if (na) TLM_HIP(hipMemcpyAsync(g->anchors, g->h_anchors.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
 
     // ---- walk order: (nearest anchor, BFS level, reference index); identity if TLM_NO_LOCALIZE is set
-    TLM_HIP(hipMalloc((void **) &g->w_old_of_new, ((size_t) N + 1) * 4));
+    if (int rc = tlm_pool_alloc((void **) &g->w_old_of_new, ((size_t) N + 1) * 4, s)) return rc;
     DevBuf new_of_old;
     if (int rc = dev_alloc(new_of_old, ((size_t) N + 1) * 4)) return rc;
     const bool localize = N && na && !std::getenv("TLM_NO_LOCALIZE");
@@ -493,10 +496,10 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
             apad = (uint64_t) last_start + last_pd;
         }
         g->n_adj_pad = apad;
-        TLM_HIP(hipMalloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2)));
-        TLM_HIP(hipMalloc((void **) &g->w_qt, (apad + 256) * sizeof(uint2)));
+        if (int rc = tlm_pool_alloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2), s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2), s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2), s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &g->w_qt, (apad + 256) * sizeof(uint2), s)) return rc;
         // 256 zero entries of slack after the last row: a lane's 8-entry read never leaves the buffer
         TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
         TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
@@ -577,6 +580,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     TLM_CHECK(n_files >= 1 && n_files <= MAX_FILES, TLM_EINVAL, "tlm_graph_build: n_files must be 1..%d", MAX_FILES);
     TLM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    t_build_stream = s;
     FileTable ft;
     std::memset(&ft, 0, sizeof(ft));
     ft.n_files = n_files;
