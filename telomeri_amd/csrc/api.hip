@@ -41,6 +41,10 @@ int tlm_pool_alloc(void **p, size_t bytes, hipStream_t s) {
 void tlm_pool_free(void *p) {
     if (p) (void) hipFreeAsync(p, nullptr);
 }
+
+// after a batch of tlm_pool_free: the frees are ordered on the null stream; once that stream has drained the blocks may
+// be handed to an allocation on any stream (otherwise the pool grows by fresh mappings, which is what costs)
+void tlm_pool_settle() { (void) hipStreamSynchronize(nullptr); }
 extern "C" int tlm_abi_version(void) { return TLM_ABI_VERSION; }
 
 extern "C" uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r) {
@@ -182,6 +186,7 @@ extern "C" void tlm_graph_destroy(tlm_graph *g) {
     tlm_pool_free(g->node_flags); tlm_pool_free(g->node_name_id); tlm_pool_free(g->anchors); tlm_pool_free(g->det_off);
     tlm_pool_free(g->w_row); tlm_pool_free(g->w_ent_es); tlm_pool_free(g->w_ent_os); tlm_pool_free(g->w_qt);
     tlm_pool_free(g->kept_rec); tlm_pool_free(g->w_old_of_new); tlm_pool_free(g->w_anchors);
+    tlm_pool_settle();
     delete g;
 }
 
@@ -373,6 +378,7 @@ struct UnitBufs {
     ~UnitBufs() {
         tlm_pool_free(units); tlm_pool_free(p_index); tlm_pool_free(n_off); tlm_pool_free(totals);
         tlm_pool_free(work_list);
+        tlm_pool_settle();
     }
 };
 
@@ -749,5 +755,6 @@ extern "C" void tlm_pathset_destroy(tlm_pathset *ps) {
     (void) hipDeviceSynchronize();
     tlm_pool_free(ps->unit); tlm_pool_free(ps->length); tlm_pool_free(ps->off); tlm_pool_free(ps->nodes);
     tlm_pool_free(ps->slots);
+    tlm_pool_settle();
     delete ps;
 }

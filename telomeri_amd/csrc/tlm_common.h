@@ -96,6 +96,7 @@ struct tlm_pathset {
 // synchronise the device.  tlm_pool_free may run after the context is gone (path sets outlive it in the Python tests).
 int tlm_pool_alloc(void **p, size_t bytes, hipStream_t s);
 void tlm_pool_free(void *p);
+void tlm_pool_settle();      // after a batch of frees: lets any stream reuse the blocks
 
 // graph build (csr_build.hip)
 int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g);   // node_flags, anchors, det_off, info
