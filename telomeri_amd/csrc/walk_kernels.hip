@@ -169,7 +169,7 @@ struct Rng {
 };
 
 __device__ __forceinline__ double mt_canonical(Rng &g, int lane) {
-    if (g.idx >= 312) {
+    if (__builtin_expect(g.idx >= 312, 0)) {
         mt_twist((lds_u32 *) g.mt, (glb_u32 *) g.raw, lane);
         g.idx = 0;
     }
@@ -416,7 +416,7 @@ __device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&n
     // bit (id - lo) & 31 == id & 31 (lo is a multiple of 32; v_bfe_i32 reads 5 bits of the offset): 0 or all ones
 #pragma unroll
     for (int k = 0; k < K; k++) vis[k] = (uint32_t) __builtin_amdgcn_sbfe((int) vis[k], nb[k], 1u);
-    if (__ballot(any >= WIN_BITS)) {    // rare: an anchor neighbour, or a neighbour outside the band
+    if (__builtin_expect(__ballot(any >= WIN_BITS) != 0, 0)) {    // rare: an anchor neighbour, or a neighbour outside the band
 #pragma unroll
         for (int k = 0; k < K; k++)
             if (nb[k] - vs.lo >= WIN_BITS) vis[k] = visited_test(vs, nb[k] & 0x7FFFFFFFu) ? ~0u : 0u;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
 #endif
     const double total = readlane_f64(incl, 63);
     const bool has = act && va != ~0u;
-    if (total == 0.0) {                                                            // dead end, or candidates of metric 0
+    if (__builtin_expect(total == 0.0, 0)) {                                       // dead end, or candidates of metric 0
         if (!__ballot(has)) return;                                                // :72
     }
     s.ncand = 1;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
     draws++;
     int hl, myk = K - 1;
     uint32_t mynb = nb[K - 1];
-    if (random == 0.0) {
+    if (__builtin_expect(random == 0.0, 0)) {
         // `sum >= 0` holds at the first candidate of the list (:110); rare enough to probe again
         hl = __ffsll((unsigned long long) __ballot(has)) - 1;
         uint32_t vis[K], nb2[K];
@@ -502,7 +502,7 @@ __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visite
     uint32_t nb[K], mb[K], vis[K];
     const bool act = lane_load<K>(a.ents, row, 0u, deg, lane, nb, mb);
     clk.mark(CLK_LIST_WAIT, true);
-    if (anchor_nbr) {
+    if (__builtin_expect(anchor_nbr, 0)) {
         uint32_t fn = 0;
         const int fpos = forced_in_lanes<K>(nb, start, fn);
         if (fpos >= 0) {
@@ -770,7 +770,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         clk.steps++;
         if (anchor_nbr) clk.acc[CLK_OTHER]++;       // steps on rows that hold an anchor
 #endif
-        if (s.pick < 0) {
+        if (__builtin_expect(s.pick < 0, 0)) {
             if (s.ncand != 0) break;    // no prefix reached `random` (NaN / negative metrics): the reference
                                         // dereferences a null Edge* there; oracle and kernel abandon the walk
             // :72 dead end
@@ -811,7 +811,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         }
         // ---- advance (:118-123)
         rec = scalar_load_u2(a.rows, s.nbr);    // the next step's row record: requested before this step's bookkeeping
-        if (m + 2 > a.cap || nlog + 1 > a.cap) {
+        if (__builtin_expect(m + 2 > a.cap || nlog + 1 > a.cap, 0)) {
             status = ST_SCRATCH_OVF;
             break;
         }
