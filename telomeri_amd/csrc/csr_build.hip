@@ -152,13 +152,39 @@ __global__ __launch_bounds__(256) void row_ptr_kernel(uint64_t n_adj, uint32_t n
     if (blockIdx.x == 0 && threadIdx.x == 0) row_ptr[n_nodes] = (uint32_t) n_adj;
 }
 
-// step 5
-__global__ __launch_bounds__(256) void gather_kernel(FileTable ft, uint64_t n_adj, const uint32_t *__restrict__ sorted_e,
-                                                     const uint32_t *__restrict__ kept_rec,
-                                                     const uint32_t *__restrict__ node_of_name,
-                                                     const uint8_t *__restrict__ node_anchor,
-                                                     const float *__restrict__ r_si, const float *__restrict__ r_os,
-                                                     const float *__restrict__ r_es, uint2 *__restrict__ ent_es,
+// step 5a: one 48-byte record per KEPT overlap, in kept order (kept_rec is increasing, so the column reads are almost
+// coalesced): everything both adjacency entries of the overlap need.  The gather below then touches one such record
+// per entry instead of a dozen scattered 4-byte words.
+struct KeptFields {
+    uint4 a;    // qn, tn, q_start, q_end          (node indices of query and target)
+    uint4 b;    // t_start, t_end, ES bits, OS bits
+    uint4 c;    // SI bits, strand | anchor(qn) << 1 | anchor(tn) << 2, -, -
+};
+
+__global__ __launch_bounds__(256) void kept_fields_kernel(FileTable ft, uint64_t n_kept,
+                                                          const uint32_t *__restrict__ kept_rec,
+                                                          const uint32_t *__restrict__ node_of_name,
+                                                          const uint8_t *__restrict__ node_anchor,
+                                                          const float *__restrict__ r_si, const float *__restrict__ r_os,
+                                                          const float *__restrict__ r_es, KeptFields *__restrict__ out) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < n_kept; k += stride) {
+        const uint64_t g = kept_rec[k];
+        const FileCols &f = ft.f[file_of(ft, g)];
+        const uint64_t r = g - f.base;
+        const uint32_t qn = node_of_name[f.q_id[r]], tn = node_of_name[f.t_id[r]];
+        KeptFields o;
+        o.a = make_uint4(qn, tn, (uint32_t) f.q_start[r], (uint32_t) f.q_end[r]);
+        o.b = make_uint4((uint32_t) f.t_start[r], (uint32_t) f.t_end[r], __float_as_uint(r_es[g]), __float_as_uint(r_os[g]));
+        const uint32_t st = f.strand ? (f.strand[r] != 0 ? 1u : 0u) : 0u;
+        o.c = make_uint4(__float_as_uint(r_si[g]), st | ((uint32_t) node_anchor[qn] << 1) | ((uint32_t) node_anchor[tn] << 2), 0u, 0u);
+        out[k] = o;
+    }
+}
+
+// step 5b
+__global__ __launch_bounds__(256) void gather_kernel(uint64_t n_adj, const uint32_t *__restrict__ sorted_e,
+                                                     const KeptFields *__restrict__ kf, uint2 *__restrict__ ent_es,
                                                      uint2 *__restrict__ ent_os, uint32_t *__restrict__ q_start,
                                                      uint32_t *__restrict__ q_end, uint32_t *__restrict__ t_start,
                                                      uint32_t *__restrict__ t_end, float *__restrict__ si,
@@ -166,23 +192,20 @@ __global__ __launch_bounds__(256) void gather_kernel(FileTable ft, uint64_t n_ad
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
     for (uint64_t d = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; d < n_adj; d += stride) {
         const uint32_t e = sorted_e[d];
-        const uint64_t g = kept_rec[e >> 1];
         const bool swapped = (e & 1u) != 0;
-        const FileCols &f = ft.f[file_of(ft, g)];
-        const uint64_t r = g - f.base;
-        const uint32_t qn = node_of_name[f.q_id[r]], tn = node_of_name[f.t_id[r]];
+        const KeptFields f = kf[e >> 1];
+        const uint32_t qn = f.a.x, tn = f.a.y, qs = f.a.z, qe = f.a.w, ts = f.b.x, te = f.b.y;
         const uint32_t nbr = swapped ? tn : qn;       // Edge::q_index of the entry
-        const uint32_t word = nbr | ((uint32_t) node_anchor[nbr] << 31);
-        ent_es[d] = make_uint2(word, __float_as_uint(r_es[g]));
-        ent_os[d] = make_uint2(word, __float_as_uint(r_os[g]));
-        const uint32_t qs = (uint32_t) f.q_start[r], qe = (uint32_t) f.q_end[r];
-        const uint32_t ts = (uint32_t) f.t_start[r], te = (uint32_t) f.t_end[r];
+        const uint32_t anchor = swapped ? (f.c.y >> 2) & 1u : (f.c.y >> 1) & 1u;
+        const uint32_t word = nbr | (anchor << 31);
+        ent_es[d] = make_uint2(word, f.b.z);
+        ent_os[d] = make_uint2(word, f.b.w);
         q_start[d] = swapped ? ts : qs;
         q_end[d] = swapped ? te : qe;
         t_start[d] = swapped ? qs : ts;
         t_end[d] = swapped ? qe : te;
-        si[d] = r_si[g];
-        strand[d] = f.strand ? (f.strand[r] != 0) : 0;
+        si[d] = __uint_as_float(f.c.x);
+        strand[d] = (uint8_t) (f.c.y & 1u);
     }
 }
 
@@ -723,11 +746,15 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, owner.as<uint32_t>(), sorted_owner.as<uint32_t>(), eidx.as<uint32_t>(),
                                           sorted_e.as<uint32_t>(), (size_t) A, 0, end_bit, s));
         hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, N, sorted_owner.as<uint32_t>(), g->row_ptr);
-        // 5. gather
-        hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, ft, A, sorted_e.as<uint32_t>(),
-                           g->kept_rec, node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(),
-                           r_os.as<float>(), r_es.as<float>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start,
-                           g->t_end, g->si, g->strand);
+        // 5. gather, through one compact record per kept overlap
+        DevBuf kf;
+        if (int rc = dev_alloc(kf, (size_t) K * sizeof(KeptFields))) return rc;
+        hipLaunchKernelGGL(kept_fields_kernel, dim3(grid_for(K)), dim3(256), 0, s, ft, K, g->kept_rec,
+                           node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(), r_os.as<float>(),
+                           r_es.as<float>(), kf.as<KeptFields>());
+        hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, sorted_e.as<uint32_t>(),
+                           kf.as<KeptFields>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start, g->t_end, g->si,
+                           g->strand);
         TLM_HIP(hipStreamSynchronize(s));
     }
     // 6.
