@@ -82,8 +82,11 @@ __global__ __launch_bounds__(256) void first_seen_kernel(FileTable ft, int fi, c
         if (!keep[g]) continue;
         const uint32_t k = krank[g];
         kept_rec[k] = (uint32_t) g;
-        atomicMin(&first_pos[f.q_id[i]], 2u * k);
-        atomicMin(&first_pos[f.t_id[i]], 2u * k + 1u);
+        // (a plain read first: after the first few records of a name nearly every atomic would lose anyway, and a
+        // stale value only means one atomic too many)
+        const uint32_t q = (uint32_t) f.q_id[i], t = (uint32_t) f.t_id[i];
+        if (2u * k < __builtin_nontemporal_load(&first_pos[q])) atomicMin(&first_pos[q], 2u * k);
+        if (2u * k + 1u < __builtin_nontemporal_load(&first_pos[t])) atomicMin(&first_pos[t], 2u * k + 1u);
     }
 }
 
