@@ -10,8 +10,11 @@ scored and turned into the CSR by the library; graph-build timings are reported 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Weak scaling: every rank walks `--anchors-per-gpu` anchors (25 = 200 anchors / 8 GPUs, the A. thaliana
-config) with the reference's default 2000 Monte-Carlo trials per anchor.
+Strong scaling (north_star: "anchor contigs and their Monte-Carlo trial bundles shard across the 8 GPUs"): the
+workload is the WHOLE A. thaliana-shaped config -- all 200 anchors x the reference's default 2000 Monte-Carlo trials
+x {ES, OS} + the deterministic builders -- and rank r of N walks the contiguous bundle of ceil(200 / N) anchors
+number r (N = 1: everything; N = 8: 25 anchors per GPU).  `--anchors-per-gpu K` restricts every rank to K anchors
+(diagnostics; the line then says so).
 """
 import argparse
 import json
@@ -34,7 +37,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="athaliana", help="telomeri_amd.synth.CONFIGS entry")
-    ap.add_argument("--anchors-per-gpu", type=int, default=25)
+    ap.add_argument("--anchors-per-gpu", type=int, default=0, help="0 = ceil(all anchors / N): the whole config is walked")
+    ap.add_argument("--no-scaffold", action="store_true", help="skip the PAF-in / FASTA-out wall-clock leg (N = 1 only)")
+    ap.add_argument("--scaffold-config", default=None, help="config of the scaffold leg (default: --config)")
     ap.add_argument("--rb-att", type=int, default=2000)
     ap.add_argument("--bt-att", type=int, default=60)
     ap.add_argument("--len-thr", type=int, default=4_700_000)
@@ -96,8 +101,8 @@ def main() -> None:
 
     wp = capi.WalkParams.default(args.rb_att, args.bt_att, args.len_thr)
     n_anchors = int(gi.n_anchors)
-    apg = min(args.anchors_per_gpu, max(1, n_anchors // world))
-    a0, a1 = rank * apg, rank * apg + apg
+    apg = args.anchors_per_gpu if args.anchors_per_gpu > 0 else (n_anchors + world - 1) // world
+    a0, a1 = min(rank * apg, n_anchors), min(rank * apg + apg, n_anchors)
     mc_range = (a0 * args.rb_att, a1 * args.rb_att)
     _, det_off = g.anchor_table()
     d0, d1 = int(det_off[a0]), int(det_off[a1])
@@ -176,29 +181,39 @@ def main() -> None:
     value = evals_all / elapsed
     # roofline of the dominant kernel (walk_mc_kernel): 8 algorithmic bytes per eval
     ach = 8.0 * mc_evals / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
-    traffic = None
+    # HBM traffic of the dominant kernel cannot be counted from inside this process (PMC counters need rocprofv3 around
+    # it): it is taken from the tracked profile of THIS workload (profiles/run_profile.sh -> profiles/summarize.py) and
+    # reported only when that profile's launch processed the same number of evals as the launches timed here
+    traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    evals_per_launch = mc_evals / max(mc_launches, 1)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.config, {}).get("walk_mc_kernel_hbm_bytes_per_launch")
+            t = json.load(open(tpath)).get(args.config, {})
+            if t and abs(t.get("evals_per_launch", 0) - evals_per_launch) <= 1e-6 * evals_per_launch:
+                traffic = t.get("walk_mc_kernel_hbm_bytes_per_launch")
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, source tree %s)" % (
+                    t.get("source"), t.get("commit", "?"))
         except Exception:
             traffic = None
     out = {
         "metric": "edge-extension evals/sec in path build",
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s-shaped synthetic overlaps (telomeri_amd.synth.CONFIGS['%s']): %d PAF records -> "
-                               "%d nodes, %d adjacency entries; per GPU %d anchors x (%d MC trials x {ES,OS} + DET "
-                               "first edges x {ES,OS})" % (args.config, args.config, n_records, gi.n_nodes, gi.n_adj,
-                                                           apg, args.rb_att),
-                   "anchors_per_gpu": apg, "rebuild_attempts": args.rb_att, "backtrack_attempts": args.bt_att,
+                               "%d nodes, %d adjacency entries; %d of its %d anchors walked (%d per GPU) x (%d MC trials x "
+                               "{ES,OS} + DET first edges x {ES,OS})" % (args.config, args.config, n_records, gi.n_nodes,
+                                                                         gi.n_adj, min(apg * world, n_anchors), n_anchors,
+                                                                         apg, args.rb_att),
+                   "anchors_total": n_anchors, "anchors_walked": min(apg * world, n_anchors), "anchors_per_gpu": apg, "rebuild_attempts": args.rb_att, "backtrack_attempts": args.bt_att,
                    "len_threshold": args.len_thr, "seed_policy": "per-walk mt19937",
                    "partition": "anchor bundles per rank, CSR replicated, one all-gather of Paths"},
         "roofline": {"bound": "hbm", "kernel": "walk_mc_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                     "frac": ach / 8000.0, "traffic": traffic,
+                     "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                     "achieved_is": "algorithmic bytes (8 B per eval) per second, not HBM traffic",
                      "launches": int(mc_launches), "avg_launch_ms": mc_ms / max(mc_launches, 1),
-                     "algorithmic_bytes_per_eval": 8, "evals_per_launch": mc_evals / max(mc_launches, 1)},
+                     "algorithmic_bytes_per_eval": 8, "evals_per_launch": evals_per_launch},
         "kernels": {"walk_mc_ms_per_step": mc_ms / max(args.steps, 1), "walk_det_ms_per_step": det_ms / max(args.steps, 1),
                     "walk_mc_evals_per_s": mc_evals / (mc_ms * 1e-3) if mc_ms else None,
                     "walk_det_evals_per_s": det_evals / (det_ms * 1e-3) if det_ms else None,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TLM_ABI_VERSION 1
+#define TLM_ABI_VERSION 2
 
 enum {
     TLM_OK = 0,
@@ -115,6 +115,26 @@ int tlm_ctx_synchronize(tlm_ctx *ctx);
 /* Tuning: persistent wavefronts per CU for the walk kernels (0 = default) and the capacity, in
  * nodes, of a wave's path buffer before a walk is re-run with a full-size buffer (0 = default). */
 int tlm_ctx_set_walk_tuning(tlm_ctx *ctx, int waves_per_cu, uint32_t path_capacity);
+/* Tuning: upper bound, in bytes, of the arena the FIRST launch of a walk call collects accepted paths in (0 = default:
+ * sized from the number of units).  A launch that outgrows its arena is re-run for the units that did not fit with a
+ * larger one (results unchanged); tests use a small limit to exercise that. */
+int tlm_ctx_set_arena_limit(tlm_ctx *ctx, uint64_t bytes);
+
+/* Device memory held by the library on the context's device.  Every buffer (graph, temporaries, walk workspaces, path
+ * sets) comes from a cache owned by the library: blocks are hipMalloc'd once and re-used by later calls; the device's
+ * default memory pool and its attributes are never touched. */
+typedef struct {
+    uint64_t live_bytes;           /* in use by graphs, path sets, workspaces */
+    uint64_t cached_bytes;         /* released by the library, kept for re-use */
+    uint64_t peak_live_bytes;
+    uint64_t driver_allocs;        /* hipMalloc calls so far */
+    uint64_t reuses;               /* requests served from the cache */
+    double driver_alloc_ms;        /* host time spent in those hipMalloc calls */
+} tlm_memory_info;
+int tlm_ctx_memory_info(tlm_ctx *ctx, tlm_memory_info *out);
+/* Give the walk workspaces of the context and every cached block of its device back to the driver (graphs and path
+ * sets stay).  Waits for the device. */
+int tlm_ctx_trim(tlm_ctx *ctx);
 
 /* ---- a2 + a3: filter decision and SI/OS/ES per record -------------------------------------- */
 /* keep[n] (1 = passes OverlapGraph::filter), si/os/es[n] written for EVERY record; any output
@@ -146,6 +166,7 @@ int tlm_graph_from_csr(tlm_ctx *ctx, uint32_t n_nodes, uint64_t n_adj, const uin
                        const uint8_t *node_anchor, tlm_graph **out);
 void tlm_graph_destroy(tlm_graph *g);
 
+#define TLM_BUILD_PHASES 12
 typedef struct {
     uint32_t n_nodes;
     uint32_t n_anchors;
@@ -158,8 +179,15 @@ typedef struct {
     uint32_t bfs_levels;           /* levels of the multi-source BFS behind the walk layout's node order (0 = none) */
     double build_ms;               /* device time of tlm_graph_build */
     double filter_ms;              /* of which: the filter_score kernel */
+    /* the build by phase (HIP events on the context's stream, so a host stall between two kernels is booked on the
+     * phase it happens in); names from tlm_build_phase_name().  Phases a graph did not go through stay 0. */
+    double phase_ms[TLM_BUILD_PHASES];
+    double build_wall_ms;          /* host wall-clock of the build call */
+    double build_alloc_ms;         /* of which: host time in hipMalloc (0 once the library's cache is warm) */
+    uint32_t host_syncs;           /* host waits for the device during the build */
 } tlm_graph_info;
 int tlm_graph_get_info(const tlm_graph *g, tlm_graph_info *out);
+const char *tlm_build_phase_name(int phase);
 
 /* Copy the graph to HOST arrays (each pointer may be NULL to skip it).  Sizes from tlm_graph_info.
  * node_name_id[i] is the name id that created node i (-1 for tlm_graph_from_csr graphs). */

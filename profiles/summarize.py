@@ -68,14 +68,24 @@ def main(src: str, dst_prefix: str, config: str = "") -> None:
             try:
                 b = json.loads(open(p).read().strip().splitlines()[-1])
                 out.setdefault("bench_lines", {})[name] = {"value": b["value"], "ms_per_step": b["ms_per_step"],
-                                                          "roofline": b["roofline"]}
+                                                          "roofline": b["roofline"], "kernels": b.get("kernels")}
             except Exception:
                 pass
     json.dump(out, open(dst_prefix + "_summary.json", "w"), indent=1, sort_keys=True)
     if config and "walk_mc_kernel" in res and "hbm_bytes_per_launch" in res["walk_mc_kernel"]:
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
         t = json.load(open(tp)) if os.path.exists(tp) else {}
+        import subprocess
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                    cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() + "+"
+        except Exception:
+            commit = "?"
+        epl = None
+        for b in out.get("bench_lines", {}).values():
+            epl = b["roofline"].get("evals_per_launch", epl)
         t[config] = {"walk_mc_kernel_hbm_bytes_per_launch": res["walk_mc_kernel"]["hbm_bytes_per_launch"],
+                     "evals_per_launch": epl, "commit": commit,
                      "source": os.path.basename(dst_prefix) + "_summary.json"}
         json.dump(t, open(tp, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True)[:6000])

@@ -61,7 +61,18 @@ class _Records(C.Structure):
 class GraphInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_anchors", C.c_uint32), ("n_adj", C.c_uint64), ("n_records", C.c_uint64),
                 ("n_kept", C.c_uint64), ("n_kept_per_file", C.c_uint64 * 4), ("max_degree", C.c_uint32),
-                ("unsafe_nodes", C.c_uint32 * 4), ("bfs_levels", C.c_uint32), ("build_ms", C.c_double), ("filter_ms", C.c_double)]
+                ("unsafe_nodes", C.c_uint32 * 4), ("bfs_levels", C.c_uint32), ("build_ms", C.c_double), ("filter_ms", C.c_double),
+                ("phase_ms", C.c_double * 12), ("build_wall_ms", C.c_double), ("build_alloc_ms", C.c_double),
+                ("host_syncs", C.c_uint32)]
+
+    def phases(self) -> dict:
+        """{phase name: device-timeline ms} of the build (tlm_build_phase_name)."""
+        return {lib().tlm_build_phase_name(i).decode(): float(self.phase_ms[i]) for i in range(12)}
+
+
+class MemoryInfo(C.Structure):
+    _fields_ = [("live_bytes", C.c_uint64), ("cached_bytes", C.c_uint64), ("peak_live_bytes", C.c_uint64),
+                ("driver_allocs", C.c_uint64), ("reuses", C.c_uint64), ("driver_alloc_ms", C.c_double)]
 
 
 UNIT_STAT_DTYPE = np.dtype([("status", np.uint8), ("n_nodes", np.uint32), ("steps", np.uint32), ("evals", np.uint64),
@@ -93,6 +104,11 @@ def lib() -> C.CDLL:
     L.tlm_ctx_stream.restype = V
     L.tlm_ctx_synchronize.argtypes = [V]
     L.tlm_ctx_set_walk_tuning.argtypes = [V, C.c_int, C.c_uint32]
+    L.tlm_ctx_set_arena_limit.argtypes = [V, C.c_uint64]
+    L.tlm_ctx_memory_info.argtypes = [V, P(MemoryInfo)]
+    L.tlm_ctx_trim.argtypes = [V]
+    L.tlm_build_phase_name.argtypes = [C.c_int]
+    L.tlm_build_phase_name.restype = C.c_char_p
     L.tlm_filter_score.argtypes = [V, P(FilterParams), P(_Records), V, V, V, V, P(C.c_uint64)]
     L.tlm_graph_build.argtypes = [V, P(FilterParams), P(_Records), C.c_int, C.c_uint32, V, P(V)]
     L.tlm_graph_build_host.argtypes = [V, P(FilterParams), P(_Records), C.c_int, C.c_uint32, V, P(V)]
@@ -380,6 +396,17 @@ class Context:
 
     def set_walk_tuning(self, waves_per_cu: int = 0, path_capacity: int = 0) -> None:
         _check(lib().tlm_ctx_set_walk_tuning(self._h, waves_per_cu, path_capacity), "tlm_ctx_set_walk_tuning")
+
+    def set_arena_limit(self, nbytes: int) -> None:
+        _check(lib().tlm_ctx_set_arena_limit(self._h, nbytes), "tlm_ctx_set_arena_limit")
+
+    def memory_info(self) -> MemoryInfo:
+        mi = MemoryInfo()
+        _check(lib().tlm_ctx_memory_info(self._h, C.byref(mi)), "tlm_ctx_memory_info")
+        return mi
+
+    def trim(self) -> None:
+        _check(lib().tlm_ctx_trim(self._h), "tlm_ctx_trim")
 
     def filter_score(self, fp: FilterParams, rec, want_scores: bool = True):
         """-> (keep uint8, si, os, es float32) device tensors, n_kept."""

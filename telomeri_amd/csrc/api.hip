@@ -22,29 +22,6 @@ void tlm_set_error(const char *fmt, ...) {
 
 extern "C" const char *tlm_last_error(void) { return g_err; }
 
-int tlm_pool_alloc(void **p, size_t bytes, hipStream_t s) {
-    static thread_local int warmed_device = -1;
-    int dev = 0;
-    TLM_HIP(hipGetDevice(&dev));
-    if (warmed_device != dev) {         // keep freed blocks in the pool instead of returning them to the driver
-        hipMemPool_t pool;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-            uint64_t never = ~0ull;
-            (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &never);
-        }
-        warmed_device = dev;
-    }
-    TLM_HIP(hipMallocAsync(p, bytes ? bytes : 1, s));
-    return TLM_OK;
-}
-
-void tlm_pool_free(void *p) {
-    if (p) (void) hipFreeAsync(p, nullptr);
-}
-
-// after a batch of tlm_pool_free: the frees are ordered on the null stream; once that stream has drained the blocks may
-// be handed to an allocation on any stream (otherwise the pool grows by fresh mappings, which is what costs)
-void tlm_pool_settle() { (void) hipStreamSynchronize(nullptr); }
 extern "C" int tlm_abi_version(void) { return TLM_ABI_VERSION; }
 
 extern "C" uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r) {
@@ -60,13 +37,14 @@ struct Workspace {   // walk scratch kept across calls (bench loops); bitmaps st
     uint64_t ar_cap = 0;
     uint2 *arena = nullptr;
     uint32_t *cursor = nullptr;              // arena cursor (u64) at [2], filter count (u64) at [4], per-XCD work cursors
+    // (the owning stream has been synchronised, or the buffers are handed back in stream order)
     void release_scratch() {
-        (void) hipFree(scratch); (void) hipFree(bitmaps);
+        tlm_pool_free(scratch); tlm_pool_free(bitmaps);
         scratch = bitmaps = nullptr;
         waves = cap = bm_words = 0;
     }
     void release_arena() {
-        (void) hipFree(arena);
+        tlm_pool_free(arena);
         arena = nullptr;
         ar_cap = 0;
     }
@@ -106,8 +84,8 @@ extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
         || hipStreamCreateWithPriority(&c->side.stream, hipStreamNonBlocking, prio_lo) != hipSuccess
         || hipEventCreate(&c->side.ev0) != hipSuccess || hipEventCreate(&c->side.ev1) != hipSuccess
         || hipMalloc((void **) &c->side.ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess) {
-        tlm_set_error("tlm_ctx_create: stream/event creation failed");
-        delete c;
+        tlm_set_error("tlm_ctx_create: stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
+        tlm_ctx_destroy(c);         // releases whatever was created (every handle starts out null)
         return TLM_EHIP;
     }
     *out = c;
@@ -118,7 +96,7 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     if (!ctx) return;
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     (void) hipSetDevice(c->device);
-    (void) hipStreamSynchronize(c->stream);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->side.stream) (void) hipStreamSynchronize(c->side.stream);
     c->ws.release_scratch();
     c->ws.release_arena();
@@ -126,12 +104,19 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     c->side.ws.release_scratch();
     c->side.ws.release_arena();
     (void) hipFree(c->side.ws.cursor);
+    for (hipEvent_t e : c->phase_ev) (void) hipEventDestroy(e);
     if (c->side.ev0) (void) hipEventDestroy(c->side.ev0);
     if (c->side.ev1) (void) hipEventDestroy(c->side.ev1);
-    if (c->side.stream) (void) hipStreamDestroy(c->side.stream);
-    (void) hipEventDestroy(c->ev0);
-    (void) hipEventDestroy(c->ev1);
-    (void) hipStreamDestroy(c->stream);
+    if (c->side.stream) {
+        tlm_pool_forget_stream(c->device, c->side.stream);      // graphs and path sets may outlive the context
+        (void) hipStreamDestroy(c->side.stream);
+    }
+    if (c->ev0) (void) hipEventDestroy(c->ev0);
+    if (c->ev1) (void) hipEventDestroy(c->ev1);
+    if (c->stream) {
+        tlm_pool_forget_stream(c->device, c->stream);
+        (void) hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 
@@ -140,6 +125,31 @@ extern "C" void *tlm_ctx_stream(tlm_ctx *ctx) { return ctx ? (void *) ctx->strea
 extern "C" int tlm_ctx_synchronize(tlm_ctx *ctx) {
     TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_synchronize: null ctx");
     TLM_HIP(hipStreamSynchronize(ctx->stream));
+    return TLM_OK;
+}
+
+extern "C" int tlm_ctx_set_arena_limit(tlm_ctx *ctx, uint64_t bytes) {
+    TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_set_arena_limit: null ctx");
+    ctx->arena_limit = bytes;
+    return TLM_OK;
+}
+
+extern "C" int tlm_ctx_memory_info(tlm_ctx *ctx, tlm_memory_info *out) {
+    TLM_CHECK(ctx && out, TLM_EINVAL, "tlm_ctx_memory_info: null argument");
+    tlm_pool_info(ctx->device, out);
+    return TLM_OK;
+}
+
+extern "C" int tlm_ctx_trim(tlm_ctx *ctx) {
+    TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_trim: null ctx");
+    CtxImpl *c = static_cast<CtxImpl *>(ctx);
+    TLM_HIP(hipSetDevice(c->device));
+    TLM_HIP(hipDeviceSynchronize());
+    c->ws.release_scratch();
+    c->ws.release_arena();
+    c->side.ws.release_scratch();
+    c->side.ws.release_arena();
+    tlm_pool_trim(c->device);
     return TLM_OK;
 }
 
@@ -179,14 +189,11 @@ extern "C" int tlm_filter_score(tlm_ctx *ctx, const tlm_filter_params *p, const 
 extern "C" void tlm_graph_destroy(tlm_graph *g) {
     if (!g) return;
     (void) hipSetDevice(g->device);
-    (void) hipDeviceSynchronize();      // the pool does not wait for kernels that may still read the graph
-    tlm_pool_free(g->row_ptr); tlm_pool_free(g->ent_es); tlm_pool_free(g->ent_os);
-    tlm_pool_free(g->q_start); tlm_pool_free(g->t_start); tlm_pool_free(g->q_end); tlm_pool_free(g->t_end);
-    tlm_pool_free(g->si); tlm_pool_free(g->strand); tlm_pool_free(g->node_len); tlm_pool_free(g->node_anchor);
-    tlm_pool_free(g->node_flags); tlm_pool_free(g->node_name_id); tlm_pool_free(g->anchors); tlm_pool_free(g->det_off);
-    tlm_pool_free(g->w_row); tlm_pool_free(g->w_ent_es); tlm_pool_free(g->w_ent_os); tlm_pool_free(g->w_qt);
-    tlm_pool_free(g->kept_rec); tlm_pool_free(g->w_old_of_new); tlm_pool_free(g->w_anchors);
-    tlm_pool_settle();
+    (void) hipDeviceSynchronize();      // kernels of either walk lane may still read the graph
+    void *bufs[] = {g->row_ptr, g->ent_es, g->ent_os, g->q_start, g->t_start, g->q_end, g->t_end, g->si, g->strand,
+                    g->node_len, g->node_anchor, g->node_flags, g->node_name_id, g->anchors, g->det_off, g->w_row,
+                    g->w_ent_es, g->w_ent_os, g->w_qt, g->kept_rec, g->w_old_of_new, g->w_anchors};
+    for (void *b : bufs) tlm_pool_free(b, true);
     delete g;
 }
 
@@ -378,22 +385,16 @@ struct UnitBufs {
     ~UnitBufs() {
         tlm_pool_free(units); tlm_pool_free(p_index); tlm_pool_free(n_off); tlm_pool_free(totals);
         tlm_pool_free(work_list);
-        tlm_pool_settle();
     }
 };
-
-template <class T> int dmalloc(T **p, size_t n) {
-    TLM_HIP(hipMalloc((void **) p, (n ? n : 1) * sizeof(T)));
-    return TLM_OK;
-}
 
 template <class T> int pmalloc(T **p, size_t n, hipStream_t s) { return tlm_pool_alloc((void **) p, (n ? n : 1) * sizeof(T), s); }
 
 int ensure_scratch(Workspace &w, hipStream_t stream, uint32_t waves, uint32_t cap, uint32_t bm_words) {
     if (w.waves >= waves && w.cap == cap && w.bm_words == bm_words) return TLM_OK;
     w.release_scratch();
-    if (int rc = dmalloc(&w.scratch, (size_t) waves * cap * 3)) return rc;
-    if (int rc = dmalloc(&w.bitmaps, (size_t) waves * bm_words)) return rc;
+    if (int rc = pmalloc(&w.scratch, (size_t) waves * cap * 3, stream)) return rc;
+    if (int rc = pmalloc(&w.bitmaps, (size_t) waves * bm_words, stream)) return rc;
     TLM_HIP(hipMemsetAsync(w.bitmaps, 0, (size_t) waves * bm_words * 4, stream));
     w.waves = waves;
     w.cap = cap;
@@ -405,7 +406,7 @@ int ensure_scratch(Workspace &w, hipStream_t stream, uint32_t waves, uint32_t ca
 int ensure_arena(Workspace &w, hipStream_t stream, uint64_t need, uint64_t keep) {
     if (w.ar_cap >= need) return TLM_OK;
     uint2 *nn = nullptr;
-    if (int rc = dmalloc(&nn, (size_t) need)) return rc;
+    if (int rc = pmalloc(&nn, (size_t) need, stream)) return rc;
     if (keep) {
         TLM_HIP(hipMemcpyAsync(nn, w.arena, keep * sizeof(uint2), hipMemcpyDeviceToDevice, stream));
         TLM_HIP(hipStreamSynchronize(stream));
@@ -474,6 +475,20 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
 
     std::vector<UnitOut> h_units(n_all);
 
+    // a call that gives up between a launch and its completion leaves the per-wave visited maps in an unknown state:
+    // the workspace is dropped then (after the stream has drained), the next call starts from zeroed maps
+    struct Dirty {
+        Workspace &w;
+        hipStream_t s;
+        bool armed = false;
+        ~Dirty() {
+            if (armed) {
+                (void) hipStreamSynchronize(s);
+                w.release_scratch();
+            }
+        }
+    } dirty{W, s};
+
     if (n_units) {
         const uint32_t N = g->n_nodes;
         const uint32_t full_cap = N + 2;
@@ -490,13 +505,15 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         waves = std::max<uint32_t>(4u, (waves / 4) * 4);
         cnt[0].waves = waves;
         if (int rc = ensure_scratch(W, s, waves, cap, bm_words)) return rc;
-        // arena for the accepted paths: the worst case (every unit accepted at full buffer length) when
-        // that fits 8 GiB, else a guess that the overflow re-run below corrects
+        dirty.armed = true;
+        // arena for the accepted paths: the worst case (every unit accepted at full buffer length) when that is small,
+        // else 4096 nodes per unit (the A. thaliana-shaped paths average 3500) -- a guess that the overflow re-run below
+        // corrects, and that tlm_ctx_set_arena_limit can cap (tests force the re-run with it)
         {
             const uint64_t worst = (uint64_t) n_all * cap;
-            const uint64_t budget = (8ull << 30) / 8;
-            const uint64_t want = worst <= budget ? worst : std::max<uint64_t>(budget, (uint64_t) n_all * 256u);
-            if (int rc = ensure_arena(W, s, std::max<uint64_t>(1u << 20, want), 0)) return rc;
+            uint64_t want = std::min<uint64_t>(worst, std::max<uint64_t>((uint64_t) n_all * 4096u, 1u << 20));
+            if (ctx->arena_limit) want = std::max<uint64_t>(64u, std::min<uint64_t>(want, ctx->arena_limit / sizeof(uint2)));
+            if (int rc = ensure_arena(W, s, want, 0)) return rc;
         }
         unsigned long long *ar_cursor = (unsigned long long *) (W.cursor + 2);
         TLM_HIP(hipMemsetAsync(W.cursor, 0, 16, s));
@@ -649,6 +666,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         out[k] = pss[k];
     }
     guard.p = nullptr;
+    dirty.armed = false;
     return TLM_OK;
 }
 
@@ -753,8 +771,7 @@ extern "C" void tlm_pathset_destroy(tlm_pathset *ps) {
     // hipFree used to wait for the device; the pool does not, so make sure no kernel is still reading the set (a
     // no-op when the device is idle, which it is whenever a caller lets go of a set after using it)
     (void) hipDeviceSynchronize();
-    tlm_pool_free(ps->unit); tlm_pool_free(ps->length); tlm_pool_free(ps->off); tlm_pool_free(ps->nodes);
-    tlm_pool_free(ps->slots);
-    tlm_pool_settle();
+    tlm_pool_free(ps->unit, true); tlm_pool_free(ps->length, true); tlm_pool_free(ps->off, true);
+    tlm_pool_free(ps->nodes, true); tlm_pool_free(ps->slots, true);
     delete ps;
 }

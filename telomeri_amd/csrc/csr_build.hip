@@ -15,6 +15,7 @@
 // The sort and the scans are rocPRIM device primitives (native ROCm, no CUDA layer); everything
 // touching the reference's semantics is a kernel in this file.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,47 @@ int dev_alloc(DevBuf &b, size_t bytes) {
 template <class T> int dev_alloc_keep(T **out, size_t n) {
     return tlm_pool_alloc((void **) out, (n ? n : 1) * sizeof(T), t_build_stream);
 }
+
+// Phase marks of a build: HIP events on the build stream; interval k (between marks k and k+1) is booked on a phase of
+// tlm_graph_info.phase_ms once the build has ended.  Host waits for the device are counted (host_syncs).
+enum BuildPhase { PH_FILTER = 0, PH_RANK, PH_FIRST_SEEN, PH_NODES, PH_OWNER_SORT, PH_GATHER, PH_FLAGS, PH_BFS, PH_ORDER_SORT,
+                  PH_LAYOUT, PH_DET_TABLE, PH_OTHER };
+static_assert(PH_OTHER + 1 == TLM_BUILD_PHASES, "phase table");
+
+struct Phases {
+    tlm_ctx *ctx;
+    hipStream_t s;
+    int n = 0;
+    int phase_of[64];
+    uint32_t syncs = 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double malloc_ms0 = tlm_pool_thread_malloc_ms();
+    Phases(tlm_ctx *c, hipStream_t st) : ctx(c), s(st) { mark(PH_OTHER); }
+    void mark(int phase) {          // `phase` ENDS here (the first mark only opens the timeline)
+        if (n >= 64) return;
+        while ((int) ctx->phase_ev.size() <= n) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            ctx->phase_ev.push_back(e);
+        }
+        if (hipEventRecord(ctx->phase_ev[n], s) != hipSuccess) return;
+        phase_of[n++] = phase;
+    }
+    int sync() {
+        syncs++;
+        TLM_HIP(hipStreamSynchronize(s));
+        return TLM_OK;
+    }
+    void collect(tlm_graph_info &info) {     // after the final sync
+        for (int k = 1; k < n; k++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ctx->phase_ev[k - 1], ctx->phase_ev[k]) == hipSuccess) info.phase_ms[phase_of[k]] += ms;
+        }
+        info.host_syncs += syncs;
+        info.build_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        info.build_alloc_ms += tlm_pool_thread_malloc_ms() - malloc_ms0;
+    }
+};
 
 struct FileCols {
     const int32_t *q_id, *t_id, *q_len, *q_start, *q_end, *t_len, *t_start, *t_end;
@@ -305,13 +347,17 @@ __global__ void bfs_init_kernel(uint32_t n_anchors, const uint32_t *__restrict__
     frontier[k] = anchors[k];
 }
 
-__global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t n_f, const uint32_t *__restrict__ frontier, uint32_t level,
-                                                         const uint32_t *__restrict__ row_ptr, const uint2 *__restrict__ ents,
-                                                         unsigned long long *__restrict__ key, uint32_t *__restrict__ next,
-                                                         uint32_t *__restrict__ n_next) {
+// One level.  The size of the frontier is read from device memory (counts[0]; the next level's goes to counts[1]): the
+// host queues a batch of levels without waiting for any of them (a level past the last one finds an empty frontier).
+__global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t *__restrict__ counts, const uint32_t *__restrict__ frontier,
+                                                         uint32_t level, const uint32_t *__restrict__ row_ptr,
+                                                         const uint2 *__restrict__ ents, unsigned long long *__restrict__ key,
+                                                         uint32_t *__restrict__ next) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_f = counts[0];
+    uint32_t *n_next = counts + 1;
     for (uint32_t f = wave; f < n_f; f += n_waves) {
         const uint32_t u = frontier[f];
         const unsigned long long nk = ((unsigned long long) (level + 1) << 32) | (key[u] & 0xFFFFFFFFull);
@@ -332,6 +378,23 @@ __global__ void bfs_sortkey_kernel(uint32_t n_nodes, const unsigned long long *_
     // (source anchor, level); nodes no anchor reaches keep ~0 and sort last (no walk ever visits them)
     sortkey[i] = k == ~0ull ? ~0ull : ((k & 0xFFFFFFFFull) << 32) | (k >> 32);
     ids[i] = i;
+}
+
+// number of names that occur in a kept record = first index of the sorted first positions holding 0xFFFFFFFF
+__global__ void count_seen_kernel(uint32_t n_names, const uint32_t *__restrict__ sorted_pos, uint32_t *__restrict__ out) {
+    uint32_t lo = 0, hi = n_names;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (sorted_pos[mid] == 0xFFFFFFFFu) hi = mid;
+        else lo = mid + 1;
+    }
+    *out = lo;
+}
+
+__global__ void anchor_walk_ids_kernel(uint32_t n_anchors, const uint32_t *__restrict__ anchors,
+                                       const uint32_t *__restrict__ new_of_old, uint32_t *__restrict__ w_anchors) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_anchors) w_anchors[k] = new_of_old[anchors[k]];
 }
 
 __global__ void iota_perm_kernel(uint32_t n_nodes, uint32_t *__restrict__ old_of_new) {
@@ -410,7 +473,15 @@ unsigned grid_for(uint64_t n) {
 
 }  // namespace
 
-int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
+const char *const BUILD_PHASE_NAMES[TLM_BUILD_PHASES] = {
+    "filter_score", "rank_scan", "first_seen", "name_sort+nodes", "entries+owner_sort", "gather", "node_flags", "bfs",
+    "order_sort", "walk_layout", "det_table", "other"};
+
+extern "C" const char *tlm_build_phase_name(int phase) {
+    return phase >= 0 && phase < TLM_BUILD_PHASES ? BUILD_PHASE_NAMES[phase] : "";
+}
+
+static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
     hipStream_t s = ctx->stream;
     t_build_stream = s;
     const uint32_t N = g->n_nodes;
@@ -426,7 +497,8 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, sizeof(h_cnts), hipMemcpyDeviceToHost, s));
     std::vector<uint8_t> h_anchor(N);
     if (N) TLM_HIP(hipMemcpyAsync(h_anchor.data(), g->node_anchor, N, hipMemcpyDeviceToHost, s));
-    TLM_HIP(hipStreamSynchronize(s));
+    ph.mark(PH_FLAGS);
+    if (int rc = ph.sync()) return rc;
     for (int m = 0; m < 4; m++) g->info.unsafe_nodes[m] = h_cnts[m];
     g->info.max_degree = h_cnts[4];
     TLM_CHECK(h_cnts[4] < (1u << 24), TLM_ELIMIT, "a node of degree %u exceeds the 2^24 layout limit", h_cnts[4]);
@@ -450,31 +522,47 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
     const bool localize = N && na && !std::getenv("TLM_NO_LOCALIZE");
     g->info.bfs_levels = 0;
     if (N) hipLaunchKernelGGL(iota_perm_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->w_old_of_new);
+    ph.mark(PH_OTHER);
     if (localize) {
+        constexpr uint32_t BATCH = 16;      // levels queued per host round trip
         DevBuf key, f0, f1, cnt, sortkey, sortkey_out, ids;
         if (int rc = dev_alloc(key, (size_t) N * 8)) return rc;
         if (int rc = dev_alloc(f0, (size_t) N * 4)) return rc;
         if (int rc = dev_alloc(f1, (size_t) N * 4)) return rc;
-        if (int rc = dev_alloc(cnt, 4)) return rc;
+        if (int rc = dev_alloc(cnt, (BATCH + 1) * 4)) return rc;
         if (int rc = dev_alloc(sortkey, (size_t) N * 8)) return rc;
         if (int rc = dev_alloc(sortkey_out, (size_t) N * 8)) return rc;
         if (int rc = dev_alloc(ids, (size_t) N * 4)) return rc;
         TLM_HIP(hipMemsetAsync(key.p, 0xFF, (size_t) N * 8, s));
         hipLaunchKernelGGL(bfs_init_kernel, dim3((na + 255) / 256), dim3(256), 0, s, na, g->anchors,
                            key.as<unsigned long long>(), f0.as<uint32_t>());
-        uint32_t n_f = na, level = 0;
-        uint32_t *cur = f0.as<uint32_t>(), *nxt = f1.as<uint32_t>();
-        while (n_f) {
-            TLM_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
-            hipLaunchKernelGGL(bfs_expand_kernel, dim3(grid_for((uint64_t) n_f * 64)), dim3(256), 0, s, n_f, cur, level,
-                               g->row_ptr, g->ent_es, key.as<unsigned long long>(), nxt, cnt.as<uint32_t>());
-            TLM_HIP(hipMemcpyAsync(&n_f, cnt.p, 4, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipStreamSynchronize(s));
-            std::swap(cur, nxt);
-            level++;
-            TLM_CHECK(level <= N, TLM_EINTERNAL, "BFS did not terminate");
+        uint32_t level = 0;
+        uint32_t h_cnt[BATCH + 1];
+        std::memset(h_cnt, 0, sizeof(h_cnt));
+        h_cnt[0] = na;
+        uint32_t *fr[2] = {f0.as<uint32_t>(), f1.as<uint32_t>()};
+        // every level of a batch runs the same grid: one wave per frontier node, strided
+        const unsigned bfs_grid = grid_for(std::min<uint64_t>((uint64_t) N * 64, 1u << 20));
+        for (bool done = false; !done;) {
+            TLM_HIP(hipMemcpyAsync(cnt.p, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));     // {frontier size, 0, ..., 0}
+            for (uint32_t j = 0; j < BATCH; j++) {
+                hipLaunchKernelGGL(bfs_expand_kernel, dim3(bfs_grid), dim3(256), 0, s, cnt.as<uint32_t>() + j,
+                                   fr[(level + j) & 1u], level + j, g->row_ptr, g->ent_es, key.as<unsigned long long>(),
+                                   fr[(level + j + 1) & 1u]);
+            }
+            TLM_HIP(hipMemcpyAsync(h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+            if (int rc = ph.sync()) return rc;
+            uint32_t j = 1;
+            while (j <= BATCH && h_cnt[j] != 0) j++;        // level + j - 1 = the last level with a frontier
+            done = j <= BATCH;
+            level += done ? j : BATCH;
+            TLM_CHECK(level <= N + BATCH, TLM_EINTERNAL, "BFS did not terminate");
+            const uint32_t carry = h_cnt[BATCH];
+            std::memset(h_cnt, 0, sizeof(h_cnt));
+            h_cnt[0] = carry;
         }
         g->info.bfs_levels = level;
+        ph.mark(PH_BFS);
         hipLaunchKernelGGL(bfs_sortkey_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, key.as<unsigned long long>(),
                            sortkey.as<unsigned long long>(), ids.as<uint32_t>());
         size_t tb = 0;
@@ -484,21 +572,16 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         if (int rc = dev_alloc(tmp, tb)) return rc;
         TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, sortkey.as<unsigned long long>(), sortkey_out.as<unsigned long long>(),
                                           ids.as<uint32_t>(), g->w_old_of_new, (size_t) N, 0, 64, s));
-        TLM_HIP(hipStreamSynchronize(s));
+        ph.mark(PH_ORDER_SORT);
     }
     if (N) hipLaunchKernelGGL(invert_perm_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->w_old_of_new,
                               new_of_old.as<uint32_t>());
-    if (na) {
-        std::vector<uint32_t> h_new(N);
-        TLM_HIP(hipMemcpyAsync(h_new.data(), new_of_old.p, (size_t) N * 4, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipStreamSynchronize(s));
-        std::vector<uint32_t> wa(na);
-        for (uint32_t k = 0; k < na; k++) wa[k] = h_new[g->h_anchors[k]];
-        TLM_HIP(hipMemcpyAsync(g->w_anchors, wa.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        TLM_HIP(hipStreamSynchronize(s));
-    }
+    if (na) hipLaunchKernelGGL(anchor_walk_ids_kernel, dim3((na + 255) / 256), dim3(256), 0, s, na, g->anchors,
+                               new_of_old.as<uint32_t>(), g->w_anchors);
 
     // ---- walk layout
+    DevBuf det_cnt;
+    std::vector<uint64_t> h_det_cnt(na);
     {
         DevBuf pd, ws;
         if (int rc = dev_alloc(pd, ((size_t) N + 1) * 4)) return rc;
@@ -518,10 +601,20 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
             uint32_t last_start = 0, last_pd = 0;
             TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
             TLM_HIP(hipMemcpyAsync(&last_pd, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipStreamSynchronize(s));
+            // the DET unit table (reference layout) rides on the same round trip
+            if (na) {
+                if (int rc = dev_alloc(det_cnt, na * sizeof(uint64_t))) return rc;
+                hipLaunchKernelGGL(det_count_kernel, dim3((na + 63) / 64), dim3(64), 0, s, na, g->anchors, g->row_ptr,
+                                   g->ent_es, det_cnt.as<uint64_t>());
+                TLM_HIP(hipMemcpyAsync(h_det_cnt.data(), det_cnt.p, na * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            }
+            if (int rc = ph.sync()) return rc;
             apad = (uint64_t) last_start + last_pd;
         }
         g->n_adj_pad = apad;
+        for (uint32_t a = 0; a < na; a++) g->h_det_off[a + 1] = g->h_det_off[a] + h_det_cnt[a];
+        TLM_HIP(hipMemcpyAsync(g->det_off, g->h_det_off.data(), ((size_t) na + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        ph.mark(PH_DET_TABLE);
         if (int rc = tlm_pool_alloc((void **) &g->w_row, ((size_t) N + 1) * sizeof(uint2), s)) return rc;
         if (int rc = tlm_pool_alloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2), s)) return rc;
         if (int rc = tlm_pool_alloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2), s)) return rc;
@@ -529,29 +622,24 @@ int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {
         // 256 zero entries of slack after the last row: a lane's 8-entry read never leaves the buffer
         TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
         TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
+        TLM_HIP(hipMemsetAsync(g->w_qt + apad, 0, 256 * sizeof(uint2), s));
         if (N) {
             hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
                                g->w_old_of_new, new_of_old.as<uint32_t>(), ws.as<uint32_t>(), g->node_flags, g->ent_es,
                                g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt);
         }
-        TLM_HIP(hipStreamSynchronize(s));
+        ph.mark(PH_LAYOUT);
     }
-
-    // ---- DET unit table (reference layout)
-    if (na) {
-        DevBuf cnt;
-        if (int rc = dev_alloc(cnt, na * sizeof(uint64_t))) return rc;
-        hipLaunchKernelGGL(det_count_kernel, dim3((na + 63) / 64), dim3(64), 0, s, na, g->anchors, g->row_ptr, g->ent_es,
-                           cnt.as<uint64_t>());
-        std::vector<uint64_t> h_cnt(na);
-        TLM_HIP(hipMemcpyAsync(h_cnt.data(), cnt.p, na * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipStreamSynchronize(s));
-        for (uint32_t a = 0; a < na; a++) g->h_det_off[a + 1] = g->h_det_off[a] + h_cnt[a];
-    }
-    TLM_HIP(hipMemcpyAsync(g->det_off, g->h_det_off.data(), ((size_t) na + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    TLM_HIP(hipStreamSynchronize(s));
+    if (int rc = ph.sync()) return rc;       // the graph is complete when the call returns
     TLM_HIP(hipGetLastError());
     return TLM_OK;
+}
+
+int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g) {     // graphs adopted from a finished CSR (tlm_graph_from_csr)
+    Phases ph(ctx, ctx->stream);
+    const int rc = graph_finish(ctx, g, ph);
+    if (rc == TLM_OK) ph.collect(g->info);
+    return rc;
 }
 
 extern "C" int tlm_graph_kept_records(const tlm_graph *g, uint32_t *rec_host) {
@@ -633,6 +721,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     } guard{g};
 
     TLM_HIP(hipEventRecord(ctx->ev0, s));
+    Phases ph(ctx, s);
     // 1. filter + score
     DevBuf keep, r_si, r_os, r_es, krank, nk;
     if (int rc = dev_alloc(keep, R)) return rc;
@@ -640,36 +729,18 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     if (int rc = dev_alloc(r_os, R * 4)) return rc;
     if (int rc = dev_alloc(r_es, R * 4)) return rc;
     if (int rc = dev_alloc(krank, (R + 1) * 4)) return rc;
-    if (int rc = dev_alloc(nk, MAX_FILES * sizeof(unsigned long long))) return rc;
-    TLM_HIP(hipMemsetAsync(nk.p, 0, MAX_FILES * sizeof(unsigned long long), s));
-    hipEvent_t f0, f1;
-    TLM_HIP(hipEventCreate(&f0));
-    TLM_HIP(hipEventCreate(&f1));
-    TLM_HIP(hipEventRecord(f0, s));
+    if (int rc = dev_alloc(nk, (MAX_FILES + 1) * sizeof(unsigned long long))) return rc;
+    TLM_HIP(hipMemsetAsync(nk.p, 0, (MAX_FILES + 1) * sizeof(unsigned long long), s));
+    ph.mark(PH_OTHER);
     for (int i = 0; i < n_files; i++) {
         const uint64_t b = ft.f[i].base;
         tlm_launch_filter_score(s, *p, files[i], keep.as<uint8_t>() + b, r_si.as<float>() + b, r_os.as<float>() + b,
                                 r_es.as<float>() + b, nk.as<unsigned long long>() + i);
     }
-    TLM_HIP(hipEventRecord(f1, s));
+    ph.mark(PH_FILTER);
     unsigned long long h_nk[MAX_FILES] = {0, 0, 0, 0};
     TLM_HIP(hipMemcpyAsync(h_nk, nk.p, sizeof(h_nk), hipMemcpyDeviceToHost, s));
-    TLM_HIP(hipStreamSynchronize(s));
-    float fms = 0;
-    TLM_HIP(hipEventElapsedTime(&fms, f0, f1));
-    (void) hipEventDestroy(f0);
-    (void) hipEventDestroy(f1);
-    uint64_t K = 0;
-    for (int i = 0; i < n_files; i++) { g->info.n_kept_per_file[i] = h_nk[i]; K += h_nk[i]; }
-    g->info.n_records = R;
-    g->info.n_kept = K;
-    g->info.filter_ms = fms;
-    const uint64_t A = 2 * K;
-    TLM_CHECK(A < (1ull << 32) - 64, TLM_ELIMIT, "tlm_graph_build: %llu adjacency entries exceed the u32 CSR layout",
-              (unsigned long long) A);
-    g->n_adj = A;
-
-    // 2. rank of each kept record
+    // 2. rank of each kept record (queued before the host waits for the counts)
     {
         auto in = rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
         size_t tb = 0;
@@ -677,8 +748,17 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         DevBuf tmp;
         if (int rc = dev_alloc(tmp, tb)) return rc;
         TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, in, krank.as<uint32_t>(), 0u, (size_t) R, rocprim::plus<uint32_t>(), s));
-        TLM_HIP(hipStreamSynchronize(s));
     }
+    ph.mark(PH_RANK);
+    if (int rc = ph.sync()) return rc;
+    uint64_t K = 0;
+    for (int i = 0; i < n_files; i++) { g->info.n_kept_per_file[i] = h_nk[i]; K += h_nk[i]; }
+    g->info.n_records = R;
+    g->info.n_kept = K;
+    const uint64_t A = 2 * K;
+    TLM_CHECK(A < (1ull << 32) - 64, TLM_ELIMIT, "tlm_graph_build: %llu adjacency entries exceed the u32 CSR layout",
+              (unsigned long long) A);
+    g->n_adj = A;
 
     // 3. first-seen numbering
     DevBuf first_pos, name_iota, sorted_pos, sorted_name, node_of_name;
@@ -694,6 +774,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         hipLaunchKernelGGL(first_seen_kernel, dim3(grid_for(ft.f[i].n)), dim3(256), 0, s, ft, i, keep.as<uint8_t>(),
                            krank.as<uint32_t>(), first_pos.as<uint32_t>(), g->kept_rec);
     }
+    ph.mark(PH_FIRST_SEEN);
     uint32_t N = 0;
     if (n_names) {
         hipLaunchKernelGGL(iota_kernel, dim3((n_names + 255) / 256), dim3(256), 0, s, name_iota.as<uint32_t>(), n_names);
@@ -704,11 +785,11 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         if (int rc = dev_alloc(tmp, tb)) return rc;
         TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, first_pos.as<uint32_t>(), sorted_pos.as<uint32_t>(),
                                           name_iota.as<uint32_t>(), sorted_name.as<uint32_t>(), (size_t) n_names, 0, 32, s));
-        // N = number of names that occur in a kept record = first index with pos == 0xFFFFFFFF
-        std::vector<uint32_t> h_pos(n_names);
-        TLM_HIP(hipMemcpyAsync(h_pos.data(), sorted_pos.p, (size_t) n_names * 4, hipMemcpyDeviceToHost, s));
-        TLM_HIP(hipStreamSynchronize(s));
-        N = (uint32_t) (std::lower_bound(h_pos.begin(), h_pos.end(), 0xFFFFFFFFu) - h_pos.begin());
+        // N = number of names that occur in a kept record
+        uint32_t *n_dev = (uint32_t *) (nk.as<unsigned long long>() + MAX_FILES);
+        hipLaunchKernelGGL(count_seen_kernel, dim3(1), dim3(1), 0, s, n_names, sorted_pos.as<uint32_t>(), n_dev);
+        TLM_HIP(hipMemcpyAsync(&N, n_dev, 4, hipMemcpyDeviceToHost, s));
+        if (int rc = ph.sync()) return rc;
     }
     g->n_nodes = N;
     if (int rc = dev_alloc_keep(&g->node_len, N)) return rc;
@@ -719,6 +800,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
                            sorted_name.as<uint32_t>(), g->kept_rec, name_is_ctg_dev,
                            node_of_name.as<uint32_t>(), g->node_len, g->node_anchor, g->node_name_id);
     }
+    ph.mark(PH_NODES);
 
     // 4. adjacency entries, stable sort by owner
     if (int rc = dev_alloc_keep(&g->row_ptr, (size_t) N + 1)) return rc;
@@ -749,6 +831,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, owner.as<uint32_t>(), sorted_owner.as<uint32_t>(), eidx.as<uint32_t>(),
                                           sorted_e.as<uint32_t>(), (size_t) A, 0, end_bit, s));
         hipLaunchKernelGGL(row_ptr_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, N, sorted_owner.as<uint32_t>(), g->row_ptr);
+        ph.mark(PH_OWNER_SORT);
         // 5. gather, through one compact record per kept overlap
         DevBuf kf;
         if (int rc = dev_alloc(kf, (size_t) K * sizeof(KeptFields))) return rc;
@@ -758,15 +841,17 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, sorted_e.as<uint32_t>(),
                            kf.as<KeptFields>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start, g->t_end, g->si,
                            g->strand);
-        TLM_HIP(hipStreamSynchronize(s));
+        ph.mark(PH_GATHER);
     }
     // 6.
-    if (int rc = tlm_graph_finish(ctx, g)) return rc;
+    if (int rc = graph_finish(ctx, g, ph)) return rc;
     TLM_HIP(hipEventRecord(ctx->ev1, s));
     TLM_HIP(hipEventSynchronize(ctx->ev1));
     float ms = 0;
     TLM_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     g->info.build_ms = ms;
+    ph.collect(g->info);
+    g->info.filter_ms = g->info.phase_ms[PH_FILTER];
     TLM_HIP(hipGetLastError());
     guard.g = nullptr;
     *out = g;

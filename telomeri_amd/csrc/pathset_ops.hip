@@ -18,14 +18,14 @@
 
 namespace {
 
-// path-set buffers come from the stream-ordered pool (tlm_pathset_destroy releases them with tlm_pool_free)
+// path-set buffers and temporaries come from the library's device cache (device_pool.hip)
 template <class T> int dmalloc(T **p, size_t n, hipStream_t s) {
     return tlm_pool_alloc((void **) p, (n ? n : 1) * sizeof(T), s);
 }
 
-struct Tmp {
+struct Tmp {      // a temporary of one call: handed back in stream order
     void *p = nullptr;
-    ~Tmp() { if (p) (void) hipFree(p); }
+    ~Tmp() { tlm_pool_free(p); }
 };
 
 int alloc_pathset(tlm_ctx *ctx, uint64_t n_paths, uint64_t n_nodes, tlm_pathset **out) {
@@ -189,10 +189,10 @@ extern "C" int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tl
     hipStream_t s = ctx->stream;
     const uint64_t n = in->n_paths;
     Tmp keep, pidx, noff, tot;
-    TLM_HIP(hipMalloc(&keep.p, n ? n : 1));
-    TLM_HIP(hipMalloc(&pidx.p, (n ? n : 1) * 8));
-    TLM_HIP(hipMalloc(&noff.p, (n ? n : 1) * 8));
-    TLM_HIP(hipMalloc(&tot.p, 16));
+    if (int rc = tlm_pool_alloc(&keep.p, n ? n : 1, s)) return rc;
+    if (int rc = tlm_pool_alloc(&pidx.p, (n ? n : 1) * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&noff.p, (n ? n : 1) * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&tot.p, 16, s)) return rc;
     uint64_t h_tot[2] = {0, 0};
     if (n) {
         hipLaunchKernelGGL(dup_flags_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, in->off, in->nodes, (uint8_t *) keep.p);
@@ -223,16 +223,16 @@ extern "C" int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uin
     const uint64_t n = ps->n_paths;
     if (!n) return TLM_OK;
     Tmp key, idx, key2, idx2, tmp;
-    TLM_HIP(hipMalloc(&key.p, n * 8));
-    TLM_HIP(hipMalloc(&idx.p, n * 4));
-    TLM_HIP(hipMalloc(&key2.p, n * 8));
-    TLM_HIP(hipMalloc(&idx2.p, n * 4));
+    if (int rc = tlm_pool_alloc(&key.p, n * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&idx.p, n * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&key2.p, n * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&idx2.p, n * 4, s)) return rc;
     hipLaunchKernelGGL(pair_key_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, ps->off, ps->nodes,
                        (unsigned long long *) key.p, (uint32_t *) idx.p);
     size_t tb = 0;
     TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *) key.p, (unsigned long long *) key2.p, (uint32_t *) idx.p,
                                       (uint32_t *) idx2.p, (size_t) n, 0, 64, s));
-    TLM_HIP(hipMalloc(&tmp.p, tb ? tb : 16));
+    if (int rc = tlm_pool_alloc(&tmp.p, tb ? tb : 16, s)) return rc;
     TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (unsigned long long *) key.p, (unsigned long long *) key2.p, (uint32_t *) idx.p,
                                       (uint32_t *) idx2.p, (size_t) n, 0, 64, s));      // stable: paths_ order inside a bucket
     if (order_host) TLM_HIP(hipMemcpyAsync(order_host, idx2.p, n * 4, hipMemcpyDeviceToHost, s));

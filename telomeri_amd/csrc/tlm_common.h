@@ -36,6 +36,8 @@ struct tlm_ctx {
     int n_cus = 0;
     int waves_per_cu = 0;          // 0 = default
     uint32_t path_capacity = 0;    // 0 = default
+    uint64_t arena_limit = 0;      // bytes; 0 = default (tlm_ctx_set_arena_limit)
+    std::vector<hipEvent_t> phase_ev;   // graph-build phase marks, created on first use
 };
 
 // Device-resident graph.  HBM layout:
@@ -91,12 +93,17 @@ struct tlm_pathset {
     std::vector<tlm_unit_stat> stats;   // host copy
 };
 
-// Buffers that live for one call or belong to a path set come from the device's stream-ordered memory pool (kept warm:
-// release threshold = never): hipMalloc / hipFree of hundreds of megabytes per builder call cost milliseconds and
-// synchronise the device.  tlm_pool_free may run after the context is gone (path sets outlive it in the Python tests).
+// Every device buffer of the library comes from its own per-device cache (device_pool.hip): blocks are hipMalloc'd once
+// and re-used by later requests of (nearly) the same size; hipMalloc / hipFree of hundreds of megabytes per builder call
+// cost milliseconds and synchronise the device.  Nothing process-wide (the device's default memory pool) is touched.
+// tlm_pool_free may run after the context is gone (path sets outlive it in the Python tests).
 int tlm_pool_alloc(void **p, size_t bytes, hipStream_t s);
-void tlm_pool_free(void *p);
-void tlm_pool_settle();      // after a batch of frees: lets any stream reuse the blocks
+// device_is_synced: the caller has synchronised the device since the block's last use (no ordering event is needed)
+void tlm_pool_free(void *p, bool device_is_synced = false);
+void tlm_pool_forget_stream(int device, hipStream_t s);     // before a stream is destroyed
+void tlm_pool_trim(int device);                              // return every cached block to the driver
+void tlm_pool_info(int device, tlm_memory_info *out);
+double tlm_pool_thread_malloc_ms();                          // host time this thread has spent in hipMalloc so far
 
 // graph build (csr_build.hip)
 int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g);   // node_flags, anchors, det_off, info

@@ -356,14 +356,15 @@ __device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint3
                                           uint32_t (&nb)[K], uint32_t (&mb)[K]) {
     const uint32_t first = base + (uint32_t) K * (uint32_t) lane;
     const bool act = first < deg;
+#ifdef TLM_ABLATE_HALFLINES /* timing-only build (results are wrong): lanes 32..63 re-read the addresses of lanes 0..31, so
+                               a step fetches HALF the 128-byte lines of its list with the same instruction stream */
+    const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + (act ? base + (uint32_t) K * (uint32_t) (lane & 31) : base));
+#else
     const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + (act ? first : base));
+#endif
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
-#ifdef TLM_ABLATE_HALFLIST  /* timing-only build: half the list bytes, same instruction stream (results are wrong) */
-        const uint4 v = p[j & (K / 4 - 1 >= 0 ? (K / 4 > 0 ? K / 4 - 1 : 0) : 0)];
-#else
         const uint4 v = p[j];      // (non-temporal loads were tried: 120 -> 179 ms, the lists do get reused in L2)
-#endif
         nb[2 * j] = v.x; mb[2 * j] = v.y; nb[2 * j + 1] = v.z; mb[2 * j + 1] = v.w;
     }
     return act;

@@ -134,6 +134,158 @@ def test_graph_at_full_size(ctx):
     assert int(csr.node_anchor.sum()) == ds.n_contigs
 
 
+def _graph_checksums(csr) -> None:
+    """Order-independent invariants of a CSR too large to sort on the host: every kept record owns one entry in each
+    endpoint's list with the same scores and swapped coordinates (OverlapGraph.cpp:241-248), so a wrapping sum of a
+    mixed key over the entries with owner < neighbour equals the one over owner > neighbour."""
+    deg = np.diff(csr.row_ptr.astype(np.int64))
+    assert deg.min() >= 1
+    owner = np.repeat(np.arange(csr.n_nodes, dtype=np.uint32), deg)
+    lo = np.minimum(owner, csr.nbr).astype(np.uint64)
+    hi = np.maximum(owner, csr.nbr).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        key = (lo * np.uint64(0x9E3779B97F4A7C15) + hi) * np.uint64(0xBF58476D1CE4E5B9)
+        key ^= csr.es.view(np.uint32).astype(np.uint64) * np.uint64(0x94D049BB133111EB)
+        key ^= key >> np.uint64(29)
+        key *= np.uint64(0xD6E8FEB86659FD93)
+        up = owner < csr.nbr
+        assert int(key[up].sum(dtype=np.uint64)) == int(key[~up & (owner != csr.nbr)].sum(dtype=np.uint64))
+    assert int(up.sum()) * 2 + int((owner == csr.nbr).sum()) == csr.n_adj
+    assert int(csr.q_start.astype(np.int64).sum()) == int(csr.t_start.astype(np.int64).sum())
+
+
+def _oracle_sample(g, og, csr, wp, mc_units, det_units):
+    """Oracle parity on a spread of units: MC under ES and OS (per-walk seeds), DET under ES and OS."""
+    owp = po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
+    for metric in (capi.METRIC_ES, capi.METRIC_OS):
+        for u0, u1 in mc_units:
+            sub = g.walk_mc(metric, wp, u0, u1)
+            ops, _, ostats = og.walk_mc(metric, owp, po.SEED_PER_WALK, u0, u1, threads=8)
+            H.assert_stats_equal(sub.unit_stats(), ostats)
+            H.assert_paths_equal(sub.to_host(), ops)
+        for u0, u1 in det_units:
+            sub = g.walk_det(metric, u0, u1)
+            ops, _, ostats = og.walk_det(metric, u0, u1, threads=8)
+            H.assert_stats_equal(sub.unit_stats(), ostats)
+            H.assert_paths_equal(sub.to_host(), ops)
+
+
+def test_athaliana_bundle_walks(ctx):
+    """BASELINE config 4 (A. thaliana-shaped, 150.8 M records): one 25-anchor bundle (= one GPU's share of the 8-GPU
+    split) through the four builders of Main.cpp:237-243 in ONE call, exactly as bench.py runs it; every path checked
+    against the downloaded CSR, a spread of units of all four builders against the oracle."""
+    ds = synth.make_config("athaliana", device="cuda")
+    fp = capi.FilterParams.default()
+    g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+    n_contigs = ds.n_contigs
+    del ds
+    torch.cuda.empty_cache()
+    gi = g.info()
+    assert gi.n_anchors == n_contigs == 200 and gi.unsafe_nodes[0] == 0 and gi.unsafe_nodes[1] == 0
+    rb = 2000
+    wp = capi.WalkParams.default(rb_att=rb)
+    anchors, det_off = g.anchor_table()
+    a0, a1 = 75, 100                      # a bundle from the middle of the genome
+    d0, d1 = int(det_off[a0]), int(det_off[a1])
+    sets = g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, (a0 * rb, a1 * rb), (d0, d1))
+    csr = g.download(cold=False)
+    mc_anchor = lambda u: anchors[(u // rb).astype(np.int64)]
+    det_anchor = lambda u: anchors[np.searchsorted(det_off, u, side="right") - 1]
+    evals = 0
+    for k, ps in enumerate(sets):
+        st = ps.unit_stats()
+        c = ps.counters
+        assert (c.steps, c.evals, c.draws) == (int(st["steps"].sum()), int(st["evals"].sum()), int(st["draws"].sum()))
+        assert c.accepted == int((st["status"] == 1).sum()) == ps.n_paths
+        assert ps.n_units == ((a1 - a0) * rb if k < 2 else d1 - d0)
+        evals += c.evals
+        h = ps.to_host()
+        if len(h):
+            _check_paths(h, csr, mc_anchor if k < 2 else det_anchor, mc=k < 2)
+        del h
+    assert sets[0].n_paths > 1000 and sets[1].n_paths > 1000 and evals > 5e10
+    og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
+    mc_units = [(a * rb + r, a * rb + r + 40) for a, r in ((a0, 0), (a0 + 7, 1230), (a1 - 1, rb - 40))]
+    det_units = [(d0, d0 + 24), ((d0 + d1) // 2, (d0 + d1) // 2 + 24), (d1 - 24, d1)]
+    _oracle_sample(g, og, csr, wp, mc_units, det_units)
+    # the bundle equals the same units of separate calls (the sharding contract at full size)
+    sub = g.walk_mc(capi.METRIC_OS, wp, (a0 + 3) * rb, (a0 + 3) * rb + 64)
+    np.testing.assert_array_equal(sub.unit_stats(), sets[1].unit_stats()[3 * rb:3 * rb + 64])
+
+
+def test_chr1_graph_and_walks(ctx):
+    """BASELINE config 5 (human chr1-shaped: 614 M records, 936 M adjacency entries = 22 % of the 2^32 layout limit,
+    degrees above 512 -> the chunked selection path): graph invariants, then the four builders on a few anchors with
+    every path checked and a spread of units compared with the oracle."""
+    ds = synth.make_config("chr1", device="cuda")
+    fp = capi.FilterParams.default()
+    g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+    n_contigs, n_records = ds.n_contigs, len(ds.rr) + len(ds.cr)
+    del ds
+    torch.cuda.empty_cache()
+    gi = g.info()
+    assert gi.n_records == n_records and gi.n_adj == 2 * gi.n_kept and gi.n_anchors == n_contigs == 500
+    assert gi.max_degree > 512, "this config is here for the lists longer than 512 entries"
+    assert gi.unsafe_nodes[0] == 0 and gi.unsafe_nodes[1] == 0
+    csr = g.download(cold=False)
+    assert int(np.diff(csr.row_ptr.astype(np.int64)).max()) == gi.max_degree
+    _graph_checksums(csr)
+    assert int(csr.node_anchor.sum()) == n_contigs
+    rb = 2000
+    wp = capi.WalkParams.default(rb_att=rb)
+    anchors, det_off = g.anchor_table()
+    a0, a1 = 248, 251
+    d0, d1 = int(det_off[a0]), int(det_off[a1])
+    sets = g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, (a0 * rb, a1 * rb), (d0, d1))
+    mc_anchor = lambda u: anchors[(u // rb).astype(np.int64)]
+    det_anchor = lambda u: anchors[np.searchsorted(det_off, u, side="right") - 1]
+    long_steps = 0
+    for k, ps in enumerate(sets):
+        st = ps.unit_stats()
+        assert ps.counters.evals == int(st["evals"].sum()) and ps.counters.accepted == ps.n_paths
+        h = ps.to_host()
+        if len(h):
+            _check_paths(h, csr, mc_anchor if k < 2 else det_anchor, mc=k < 2)
+            deg = np.diff(csr.row_ptr.astype(np.int64))
+            long_steps += int((deg[h.nodes] > 512).sum())
+        del h
+    assert sets[0].n_paths > 100 and long_steps > 0, "no accepted path crossed a node with more than 512 neighbours"
+    og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
+    mc_units = [(a0 * rb, a0 * rb + 24), ((a0 + 1) * rb + 777, (a0 + 1) * rb + 801)]
+    det_units = [(d0, d0 + 16), (d1 - 16, d1)]
+    _oracle_sample(g, og, csr, wp, mc_units, det_units)
+
+
+def test_yeast_full_trials(ctx):
+    """BASELINE config 3 (S. cerevisiae-shaped) with the config's 1000 Monte-Carlo trials per anchor: ALL trials of two
+    anchors compared with the oracle unit for unit and path for path, under both metrics."""
+    ds = synth.make_config("yeast", device="cuda")
+    fp = capi.FilterParams.default()
+    g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+    del ds
+    csr = g.download(cold=False)
+    rb = 1000
+    wp = capi.WalkParams.default(rb_att=rb)
+    og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
+    owp = po.WalkParams(rb, wp.backtrack_attempts, wp.len_threshold)
+    a, b = g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, 11 * rb, 13 * rb)
+    for got, metric in ((a, capi.METRIC_ES), (b, capi.METRIC_OS)):
+        ops, octr, ostats = og.walk_mc(metric, owp, po.SEED_PER_WALK, 11 * rb, 13 * rb, threads=8)
+        H.assert_stats_equal(got.unit_stats(), ostats)
+        H.assert_paths_equal(got.to_host(), ops)
+        assert got.counters.evals == octr.evals and got.n_paths == octr.accepted
+    # and the whole config (30 anchors x 1000 trials x 2 metrics + DET) in one builders call, every path checked
+    anchors, det_off = g.anchor_table()
+    sets = g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp)
+    mc_anchor = lambda u: anchors[(u // rb).astype(np.int64)]
+    det_anchor = lambda u: anchors[np.searchsorted(det_off, u, side="right") - 1]
+    for k, ps in enumerate(sets):
+        h = ps.to_host()
+        if len(h):
+            _check_paths(h, csr, mc_anchor if k < 2 else det_anchor, mc=k < 2)
+    np.testing.assert_array_equal(sets[0].unit_stats()[11 * rb:13 * rb], a.unit_stats())
+
+
 def test_pack_roundtrip_on_device(ctx):
     from telomeri_amd import pathgather
     ds = synth.make_config("tiny")

@@ -322,6 +322,89 @@ def test_walk_overflow_reruns(ctx):
     pd, _ = _walk_both(c2, dg, og, capi.METRIC_ES, None, mc=False)
 
 
+@pytest.mark.parametrize("arena_bytes,path_capacity", [(4096, 0), (4096, 8), (64 * 8, 0)])
+def test_walk_arena_overflow_reruns(ctx, arena_bytes, path_capacity):
+    """A tiny arena forces ST_ARENA_OVF: the paths that did fit are kept, the arena grows, the units that did not fit
+    are re-run -- alone and mixed with the path-buffer overflow.  Results must not change (MC and DET, two metrics in
+    one launch included)."""
+    ds = synth.make_config("toy")
+    fp = capi.FilterParams.default()
+    og = H.oracle_graph(ds, H.to_oracle_fp(fp))
+    c2 = capi.Context(0)
+    c2.set_walk_tuning(waves_per_cu=4, path_capacity=path_capacity)
+    c2.set_arena_limit(arena_bytes)
+    dg = H.device_graph(c2, ds, fp)
+    wp = capi.WalkParams.default(rb_att=40)
+    ps, _ = _walk_both(c2, dg, og, capi.METRIC_ES, wp, mc=True)
+    assert ps.n_paths > 0 and ps.n_nodes_total * 8 > arena_bytes      # the arena really was too small
+    assert ps.counters.kernel_launches >= 2
+    _walk_both(c2, dg, og, capi.METRIC_OS, None, mc=False)
+    a, b = dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp)
+    for got, metric in ((a, capi.METRIC_ES), (b, capi.METRIC_OS)):
+        ops, _, ostats = og.walk_mc(metric, H.to_oracle_wp(wp), po.SEED_PER_WALK)
+        H.assert_stats_equal(got.unit_stats(), ostats)
+        H.assert_paths_equal(got.to_host(), ops)
+    # the workspace has grown: the same call now fits in one launch, same result
+    c2.set_arena_limit(0)
+    again = dg.walk_mc(capi.METRIC_ES, wp)
+    H.assert_paths_equal(again.to_host(), ps.to_host())
+
+
+def test_layout_limits_are_refused(ctx):
+    """TLM_ELIMIT: 2^31 records, 2^32 adjacency entries, degree 2^24 -- refused, never truncated."""
+    import ctypes as C
+    L = capi.lib()
+    # records: checked from the sizes alone, before any column is touched
+    dummy = torch.zeros(16, dtype=torch.int32, device="cuda")
+    rs = capi._Records(1 << 31, *([dummy.data_ptr()] * 9), dummy.data_ptr(), 0)
+    arr = (capi._Records * 1)(rs)
+    h = C.c_void_p()
+    fp = capi.FilterParams.default()
+    rc = L.tlm_graph_build(ctx._h, C.byref(fp), arr, 1, 4, dummy.data_ptr(), C.byref(h))
+    assert rc == -3 and b"2^31" in L.tlm_last_error(), L.tlm_last_error()
+    # adjacency entries of an adopted CSR
+    one = np.zeros(4, np.uint64)
+    rc = L.tlm_graph_from_csr(ctx._h, 2, (1 << 32) - 64, *([one.ctypes.data] * 12), C.byref(h))
+    assert rc == -3, L.tlm_last_error()
+    # degree: a star whose hub holds 2^24 entries
+    d = 1 << 24
+    row_ptr = np.array([0, d, d + 1], np.uint64)
+    nbr = np.ones(d + 1, np.uint32)
+    nbr[d] = 0
+    z = np.zeros(d + 1, np.uint32)
+    f = np.ones(d + 1, np.float32)
+    with pytest.raises(capi.TlmError, match="2\\^24"):
+        ctx.graph_from_csr(row_ptr, nbr, z, z, f, f, np.array([1000, 1000], np.uint32), np.array([1, 0], np.uint8))
+    # one entry less is accepted
+    row_ptr = np.array([0, d - 1, d], np.uint64)
+    g = ctx.graph_from_csr(row_ptr, nbr[:d].copy(), z[:d], z[:d], f[:d], f[:d], np.array([1000, 1000], np.uint32),
+                           np.array([1, 0], np.uint8))
+    assert g.info().max_degree == d - 1
+
+
+def test_memory_is_reused_and_trimmed(ctx):
+    """The library's device cache: a second build of the same input allocates nothing new; trim gives the cache back."""
+    ds = synth.make_config("toy")
+    fp = capi.FilterParams.default()
+    c2 = capi.Context(0)
+    g = H.device_graph(c2, ds, fp)
+    first = g.info()
+    del g
+    m0 = c2.memory_info()
+    g = H.device_graph(c2, ds, fp)
+    m1 = c2.memory_info()
+    assert m1.driver_allocs == m0.driver_allocs, "the rebuild went to hipMalloc"
+    assert m1.reuses > m0.reuses
+    gi = g.info()
+    assert gi.build_alloc_ms == 0.0 and gi.host_syncs <= first.host_syncs
+    assert abs(sum(gi.phases().values()) - gi.build_ms) < 0.25 * gi.build_ms + 1.0     # the phases cover the build
+    del g
+    assert c2.memory_info().cached_bytes > 0
+    c2.trim()
+    m2 = c2.memory_info()
+    assert m2.cached_bytes == 0
+
+
 def _synthetic_csr(n_reads=400, deg=90, seed=0, wild=False):
     """A random graph handed over as CSR (tlm_graph_from_csr): degrees above one 64-lane chunk,
     optionally metrics whose double sums are NOT exact (forces the in-order serial summation)."""
