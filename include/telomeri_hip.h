@@ -195,6 +195,29 @@ int tlm_graph_download(const tlm_graph *g, uint64_t *row_ptr, uint32_t *nbr, uin
                        uint32_t *t_start, uint32_t *t_end, float *os, float *si, float *es, uint8_t *strand,
                        uint32_t *node_len, uint8_t *node_anchor, int32_t *node_name_id);
 
+/* OverlapGraph::Edge (include/OverlapGraph.hpp:27-43) of given adjacency entries: entry slots[k] of nodes[k]'s list.
+ * For hosts that do not materialise nodes_[..].edges (233 M entries at the A. thaliana size) and need the Edge records of
+ * a few paths only (Scaffolder, Scaffolder.cpp:63-99).  HOST buffers of n entries; the CSR layout of tlm_graph_download. */
+typedef struct {
+    uint32_t q_index, t_index;     /* in node X's list: t_index == X, q_index = neighbour */
+    uint32_t q_start, q_end, t_start, t_end;
+    float overlap_score, sequence_identity, extension_score;
+    uint8_t relative_strand;
+} tlm_edge;
+int tlm_graph_edges(const tlm_graph *g, uint64_t n, const uint32_t *nodes_host, const uint32_t *slots_host,
+                    tlm_edge *out_host);
+/* What OverlapGraph::stats (OverlapGraph.cpp:24-95) reports, reduced on the device: the per-record extrema equal the
+ * per-entry ones (both entries of a record carry its scores; the overlap length is symmetric under the swap). */
+typedef struct {
+    uint64_t anchors, reads;
+    uint64_t min_len, max_len;     /* node lengths */
+    uint64_t min_con, max_con;     /* list lengths */
+    uint64_t edges;                /* edges_.size() = kept records */
+    uint64_t min_ol, max_ol;       /* max(q_end - q_start, t_end - t_start) as the reference computes it (:65) */
+    float min_os, max_os, min_es, max_es, min_si, max_si;
+} tlm_graph_stats;
+int tlm_graph_get_stats(const tlm_graph *g, tlm_graph_stats *out);
+
 /* ---- a7 / a8: walks ------------------------------------------------------------------------- */
 /* Walk units.  MC: unit = anchor_rank * rebuild_attempts + r, anchors in node
  * order.  DET: units enumerate, anchor by anchor, the first-edge positions the reference's loop
@@ -241,6 +264,15 @@ int tlm_pathset_sizes(const tlm_pathset *ps, uint64_t *n_paths, uint64_t *n_node
  * unit/length/off: uint64/int64/uint64 [n_paths], off has n_paths+1; nodes/slots: uint32 [n_nodes_total]. */
 int tlm_pathset_export(const tlm_pathset *ps, int dst_is_device, uint64_t *unit, int64_t *length, uint64_t *off,
                        uint32_t *nodes, uint32_t *slots);
+/* What grouping and bucketing need of every path, without its node list (HOST buffers of n_paths entries, any may be
+ * NULL): first and last node (PathManager.cpp:633), node count, and a 64-bit hash of the node sequence -- two paths
+ * with different (n_nodes, hash) differ; equal ones are compared node by node (Path::operator==, Path.cpp:46-49). */
+int tlm_pathset_summary(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *front, uint32_t *back, uint32_t *n_nodes,
+                        uint64_t *hash);
+/* The node and slot lists of the paths index[0..n) (HOST), concatenated in that order into HOST buffers of
+ * sum(n_nodes[index[k]]) entries. */
+int tlm_pathset_fetch(tlm_ctx *ctx, const tlm_pathset *ps, uint64_t n, const uint64_t *index, uint32_t *nodes,
+                      uint32_t *slots);
 /* Per-unit outcomes, HOST buffer of n_units entries. */
 int tlm_pathset_unit_stats(const tlm_pathset *ps, tlm_unit_stat *stats_host);
 void tlm_pathset_destroy(tlm_pathset *ps);

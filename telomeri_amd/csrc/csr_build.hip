@@ -465,6 +465,84 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
     }
 }
 
+// OverlapGraph::Edge records of given (node, slot) pairs (tlm_graph_edges)
+__global__ void edges_kernel(uint64_t n, uint32_t n_nodes, const uint32_t *__restrict__ nodes, const uint32_t *__restrict__ slots,
+                             const uint32_t *__restrict__ row_ptr, const uint2 *__restrict__ ent_es,
+                             const uint2 *__restrict__ ent_os, const uint32_t *__restrict__ q_start,
+                             const uint32_t *__restrict__ q_end, const uint32_t *__restrict__ t_start,
+                             const uint32_t *__restrict__ t_end, const float *__restrict__ si,
+                             const uint8_t *__restrict__ strand, tlm_edge *__restrict__ out, uint32_t *__restrict__ bad) {
+    const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t node = nodes[k];
+    if (node >= n_nodes || slots[k] >= row_ptr[node + 1] - row_ptr[node]) {
+        atomicAdd(bad, 1u);
+        return;
+    }
+    const uint64_t e = (uint64_t) row_ptr[node] + slots[k];
+    tlm_edge o;
+    o.q_index = ent_es[e].x & 0x7FFFFFFFu;
+    o.t_index = node;
+    o.q_start = q_start[e]; o.q_end = q_end[e]; o.t_start = t_start[e]; o.t_end = t_end[e];
+    o.overlap_score = __uint_as_float(ent_os[e].y);
+    o.sequence_identity = si[e];
+    o.extension_score = __uint_as_float(ent_es[e].y);
+    o.relative_strand = strand[e];
+    out[k] = o;
+}
+
+// OverlapGraph::stats (OverlapGraph.cpp:24-95): extrema over nodes and adjacency entries.  Floats are compared through
+// an order-preserving u32 image; NaNs never replace an extremum in the reference's `if (min > x)` / `if (max < x)`
+// form and are skipped here.  slots: 0 min_len 1 max_len 2 min_con 3 max_con 4 min_ol 5 max_ol 6..11 min/max OS, ES, SI
+// (u32 images), 12 anchors
+__device__ __forceinline__ uint32_t f32_ord(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void stats_nodes_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                                          const uint32_t *__restrict__ node_len,
+                                                          const uint8_t *__restrict__ node_anchor,
+                                                          unsigned long long *__restrict__ acc) {
+    unsigned long long mn_l = ~0ull, mx_l = 0, mn_c = ~0ull, mx_c = 0, an = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t) gridDim.x * blockDim.x) {
+        const unsigned long long l = node_len[i], c = row_ptr[i + 1] - row_ptr[i];
+        mn_l = min(mn_l, l); mx_l = max(mx_l, l); mn_c = min(mn_c, c); mx_c = max(mx_c, c);
+        an += node_anchor[i] != 0;
+    }
+    atomicMin(&acc[0], mn_l); atomicMax(&acc[1], mx_l); atomicMin(&acc[2], mn_c); atomicMax(&acc[3], mx_c);
+    atomicAdd(&acc[12], an);
+}
+
+__global__ __launch_bounds__(256) void stats_edges_kernel(uint64_t n_adj, const uint2 *__restrict__ ent_es,
+                                                          const uint2 *__restrict__ ent_os, const uint32_t *__restrict__ q_start,
+                                                          const uint32_t *__restrict__ q_end, const uint32_t *__restrict__ t_start,
+                                                          const uint32_t *__restrict__ t_end, const float *__restrict__ si,
+                                                          unsigned long long *__restrict__ acc) {
+    unsigned long long mn_ol = ~0ull, mx_ol = 0;
+    uint32_t mn[3] = {~0u, ~0u, ~0u}, mx[3] = {0u, 0u, 0u};
+    for (uint64_t e = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; e < n_adj; e += (uint64_t) gridDim.x * blockDim.x) {
+        // int ol = std::max(unsigned, unsigned); compared with and stored into ulong extrema (:65-71)
+        const int ol = (int) max(q_end[e] - q_start[e], t_end[e] - t_start[e]);
+        const unsigned long long olu = (unsigned long long) (long long) ol;
+        mn_ol = min(mn_ol, olu); mx_ol = max(mx_ol, olu);
+        const float v[3] = {__uint_as_float(ent_os[e].y), __uint_as_float(ent_es[e].y), si[e]};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (v[k] == v[k]) {
+                const uint32_t o = f32_ord(v[k] == 0.0f ? 0.0f : v[k]);
+                mn[k] = min(mn[k], o);
+                mx[k] = max(mx[k], o);
+            }
+    }
+    atomicMin(&acc[4], mn_ol); atomicMax(&acc[5], mx_ol);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        atomicMin(&acc[6 + 2 * k], (unsigned long long) mn[k]);
+        atomicMax(&acc[7 + 2 * k], (unsigned long long) mx[k]);
+    }
+}
+
 unsigned grid_for(uint64_t n) {
     uint64_t b = (n + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -855,5 +933,82 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     TLM_HIP(hipGetLastError());
     guard.g = nullptr;
     *out = g;
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_edges(const tlm_graph *g, uint64_t n, const uint32_t *nodes_host, const uint32_t *slots_host,
+                               tlm_edge *out_host) {
+    TLM_CHECK(g && (n == 0 || (nodes_host && slots_host && out_host)), TLM_EINVAL, "tlm_graph_edges: null argument");
+    if (!n) return TLM_OK;
+    TLM_HIP(hipSetDevice(g->device));
+    hipStream_t s = g->ctx->stream;
+    t_build_stream = s;
+    DevBuf dn, dsl, out, bad;
+    if (int rc = dev_alloc(dn, n * 4)) return rc;
+    if (int rc = dev_alloc(dsl, n * 4)) return rc;
+    if (int rc = dev_alloc(out, n * sizeof(tlm_edge))) return rc;
+    if (int rc = dev_alloc(bad, 4)) return rc;
+    TLM_HIP(hipMemcpyAsync(dn.p, nodes_host, n * 4, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipMemcpyAsync(dsl.p, slots_host, n * 4, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    hipLaunchKernelGGL(edges_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, g->n_nodes, dn.as<uint32_t>(),
+                       dsl.as<uint32_t>(), g->row_ptr, g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start, g->t_end, g->si,
+                       g->strand, out.as<tlm_edge>(), bad.as<uint32_t>());
+    uint32_t h_bad = 0;
+    TLM_HIP(hipMemcpyAsync(out_host, out.p, n * sizeof(tlm_edge), hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    TLM_CHECK(h_bad == 0, TLM_EINVAL, "tlm_graph_edges: %u (node, slot) pairs lie outside the graph", h_bad);
+    return TLM_OK;
+}
+
+extern "C" int tlm_graph_get_stats(const tlm_graph *g, tlm_graph_stats *out) {
+    TLM_CHECK(g && out, TLM_EINVAL, "tlm_graph_get_stats: null argument");
+    TLM_HIP(hipSetDevice(g->device));
+    hipStream_t s = g->ctx->stream;
+    t_build_stream = s;
+    DevBuf acc;
+    if (int rc = dev_alloc(acc, 16 * 8)) return rc;
+    unsigned long long h[16];
+    for (int i = 0; i < 16; i++) h[i] = 0;
+    h[0] = h[2] = h[4] = ~0ull;
+    h[6] = h[8] = h[10] = 0xFFFFFFFFull;
+    TLM_HIP(hipMemcpyAsync(acc.p, h, sizeof(h), hipMemcpyHostToDevice, s));
+    if (g->n_nodes)
+        hipLaunchKernelGGL(stats_nodes_kernel, dim3(grid_for(g->n_nodes)), dim3(256), 0, s, g->n_nodes, g->row_ptr, g->node_len,
+                           g->node_anchor, acc.as<unsigned long long>());
+    if (g->n_adj)
+        hipLaunchKernelGGL(stats_edges_kernel, dim3(grid_for(g->n_adj)), dim3(256), 0, s, g->n_adj, g->ent_es, g->ent_os,
+                           g->q_start, g->q_end, g->t_start, g->t_end, g->si, acc.as<unsigned long long>());
+    TLM_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    auto unord = [](unsigned long long o) {
+        uint32_t b = (uint32_t) o;
+        b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+        float f;
+        std::memcpy(&f, &b, 4);
+        return f;
+    };
+    out->anchors = h[12];
+    out->reads = g->n_nodes - h[12];
+    out->min_len = g->n_nodes ? h[0] : ~0ull;
+    out->max_len = h[1];
+    out->min_con = g->n_nodes ? h[2] : ~0ull;
+    out->max_con = h[3];
+    out->edges = g->info.n_kept;
+    out->min_ol = h[4];
+    out->max_ol = h[5];
+    // the reference starts its minima at FLT_MAX and its maxima at 0 (:40-43): a maximum never drops below 0
+    const bool any[3] = {h[6] != 0xFFFFFFFFull, h[8] != 0xFFFFFFFFull, h[10] != 0xFFFFFFFFull};
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; k++) {
+        mn[k] = any[k] ? std::min(unord(h[6 + 2 * k]), 3.402823466e+38f) : 3.402823466e+38f;
+        mx[k] = any[k] ? std::max(unord(h[7 + 2 * k]), 0.0f) : 0.0f;
+    }
+    out->min_os = mn[0]; out->max_os = mx[0];
+    out->min_es = mn[1]; out->max_es = mx[1];
+    out->min_si = mn[2]; out->max_si = mx[2];
     return TLM_OK;
 }

@@ -11,6 +11,7 @@
 // host receives the Path set already deduplicated.  HBM-bound streaming passes over the packed arrays.
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "tlm_common.h"
 
@@ -142,6 +143,51 @@ __global__ void pair_key_kernel(uint64_t n_paths, const uint64_t *__restrict__ o
     }
 }
 
+// one wave per path: front, back, node count and a hash of the node sequence.  The hash is position-dependent (a sum of
+// per-position mixes, so lanes combine in any order): equal sequences hash equally, which is all the host relies on.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void summary_kernel(uint64_t n_paths, const uint64_t *__restrict__ off,
+                                                      const uint32_t *__restrict__ nodes, uint32_t *__restrict__ front,
+                                                      uint32_t *__restrict__ back, uint32_t *__restrict__ n_nodes,
+                                                      uint64_t *__restrict__ hash) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n_paths; i += n_waves) {
+        const uint64_t a = off[i], n = off[i + 1] - a;
+        uint64_t h = 0;
+        for (uint64_t k = lane; k < n; k += 64) h += mix64(((uint64_t) nodes[a + k] << 32 | (k & 0xFFFFFFFFull)) + 0x9E3779B97F4A7C15ull);
+        for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d);
+        if (lane == 0) {
+            front[i] = n ? nodes[a] : 0xFFFFFFFFu;
+            back[i] = n ? nodes[a + n - 1] : 0xFFFFFFFFu;
+            n_nodes[i] = (uint32_t) n;
+            hash[i] = mix64(h ^ n);
+        }
+    }
+}
+
+// path index[k] -> staging[dst_off[k] ...), one wave per requested path
+__global__ __launch_bounds__(256) void fetch_kernel(uint64_t n, const uint64_t *__restrict__ index,
+                                                    const uint64_t *__restrict__ dst_off, const uint64_t *__restrict__ off,
+                                                    const uint32_t *__restrict__ nodes, const uint32_t *__restrict__ slots,
+                                                    uint32_t *__restrict__ o_nodes, uint32_t *__restrict__ o_slots) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t k = wave; k < n; k += n_waves) {
+        const uint64_t a = off[index[k]], len = off[index[k] + 1] - a, d = dst_off[k];
+        for (uint64_t j = lane; j < len; j += 64) {
+            o_nodes[d + j] = nodes[a + j];
+            o_slots[d + j] = slots[a + j];
+        }
+    }
+}
+
 unsigned blocks_for(uint64_t n, unsigned per) {
     uint64_t b = (n + per - 1) / per;
     return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(b, 256u * 16u));
@@ -237,6 +283,62 @@ extern "C" int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uin
                                       (uint32_t *) idx2.p, (size_t) n, 0, 64, s));      // stable: paths_ order inside a bucket
     if (order_host) TLM_HIP(hipMemcpyAsync(order_host, idx2.p, n * 4, hipMemcpyDeviceToHost, s));
     if (key_host) TLM_HIP(hipMemcpyAsync(key_host, key2.p, n * 8, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_summary(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *front, uint32_t *back, uint32_t *n_nodes,
+                                   uint64_t *hash) {
+    TLM_CHECK(ctx && ps && ps->ctx == ctx, TLM_EINVAL, "tlm_pathset_summary: bad argument");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = ps->n_paths;
+    if (!n) return TLM_OK;
+    Tmp f, b, c, h;
+    if (int rc = tlm_pool_alloc(&f.p, n * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&b.p, n * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&c.p, n * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&h.p, n * 8, s)) return rc;
+    hipLaunchKernelGGL(summary_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, ps->off, ps->nodes, (uint32_t *) f.p,
+                       (uint32_t *) b.p, (uint32_t *) c.p, (uint64_t *) h.p);
+    if (front) TLM_HIP(hipMemcpyAsync(front, f.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (back) TLM_HIP(hipMemcpyAsync(back, b.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (n_nodes) TLM_HIP(hipMemcpyAsync(n_nodes, c.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (hash) TLM_HIP(hipMemcpyAsync(hash, h.p, n * 8, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_fetch(tlm_ctx *ctx, const tlm_pathset *ps, uint64_t n, const uint64_t *index, uint32_t *nodes,
+                                 uint32_t *slots) {
+    TLM_CHECK(ctx && ps && ps->ctx == ctx && (n == 0 || index), TLM_EINVAL, "tlm_pathset_fetch: bad argument");
+    if (!n) return TLM_OK;
+    for (uint64_t k = 0; k < n; k++)
+        TLM_CHECK(index[k] < ps->n_paths, TLM_EINVAL, "tlm_pathset_fetch: path %llu of %llu", (unsigned long long) index[k],
+                  (unsigned long long) ps->n_paths);
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // sizes of the requested paths: their off[] pairs, gathered on the host from two small copies per path would be
+    // slow for many paths; the whole off[] array is 8 bytes per path
+    std::vector<uint64_t> h_off(ps->n_paths + 1);
+    TLM_HIP(hipMemcpyAsync(h_off.data(), ps->off, (ps->n_paths + 1) * 8, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    std::vector<uint64_t> dst(n + 1, 0);
+    for (uint64_t k = 0; k < n; k++) dst[k + 1] = dst[k] + (h_off[index[k] + 1] - h_off[index[k]]);
+    const uint64_t total = dst[n];
+    Tmp d_idx, d_dst, o_n, o_s;
+    if (int rc = tlm_pool_alloc(&d_idx.p, n * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&d_dst.p, (n + 1) * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&o_n.p, (total ? total : 1) * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&o_s.p, (total ? total : 1) * 4, s)) return rc;
+    TLM_HIP(hipMemcpyAsync(d_idx.p, index, n * 8, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipMemcpyAsync(d_dst.p, dst.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(fetch_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, (const uint64_t *) d_idx.p,
+                       (const uint64_t *) d_dst.p, ps->off, ps->nodes, ps->slots, (uint32_t *) o_n.p, (uint32_t *) o_s.p);
+    if (nodes && total) TLM_HIP(hipMemcpyAsync(nodes, o_n.p, total * 4, hipMemcpyDeviceToHost, s));
+    if (slots && total) TLM_HIP(hipMemcpyAsync(slots, o_s.p, total * 4, hipMemcpyDeviceToHost, s));
     TLM_HIP(hipStreamSynchronize(s));
     TLM_HIP(hipGetLastError());
     return TLM_OK;

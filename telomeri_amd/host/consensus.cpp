@@ -5,6 +5,7 @@
 #include <iostream>
 #include <numeric>
 #include <set>
+#include <stdexcept>
 
 #include "telomeri_host.hpp"
 
@@ -88,53 +89,93 @@ void PathGroup::calculateValidPathNumber() {            // PathGroup.cpp:83-93
 }
 
 // ---- PathManager: groups (src/PathManager.cpp:505-624) ------------------------------------------------
-static std::vector<ulong> getBorderPathLengths(const std::vector<PathWindow> &pws, float ratio_threshold) {
-    std::vector<ulong> dividing;
-    // (the reference's loop bound `i < n - 1` on size_t would run wild for n == 0; a window always exists)
-    for (size_t i = 1, n = pws.size(); n >= 2 && i < n - 1; i++) {
-        const PathWindow &l = pws[i - 1], &c = pws[i], &r = pws[i + 1];
-        auto less = [](const PathWindow &a, const PathWindow &b) { return a.getSumFreqs() < b.getSumFreqs(); };
-        const PathWindow &valley = std::min({l, c, r}, less);       // leftmost smallest
-        const PathWindow &peak = std::max({l, c, r}, less);         // leftmost largest
-        const std::pair<ulong, int> valley_pair = valley.getLowestFrequencyEntry();
-        const std::pair<ulong, int> peak_pair = peak.getHighestFrequencyEntry();
-        if (valley_pair.second < ratio_threshold * peak_pair.second) dividing.push_back(valley_pair.first);
+// Written from the behaviour, not from the reference's text.  The reference cuts the sorted
+// lengths into windows of `window_size`, rebuilding a frequency map per window by rescanning all paths; here ONE pass
+// over the sorted lengths yields the length histogram and, per non-empty window, the three numbers the rule uses.
+namespace {
+
+struct LengthRun {          // a run of equal lengths in the sorted list
+    ulong length;
+    int count;
+};
+
+struct WindowSummary {      // a non-empty window [lower, lower + window_size)
+    int paths = 0;                          // PathWindow::getSumFreqs
+    LengthRun rarest{0, 0}, commonest{0, 0};   // first minimum / first maximum of the frequencies in length order
+};
+
+// Windows are anchored at the shortest length; window k covers [min + k*w, min + (k+1)*w).  Empty windows do not exist
+// for the rule below (the reference drops them, PathManager.cpp:531-533).
+std::vector<WindowSummary> summarise_windows(const std::vector<LengthRun> &runs, ulong window_size) {
+    std::vector<WindowSummary> out;
+    ulong current = 0;
+    for (const LengthRun &r : runs) {
+        const ulong k = (r.length - runs.front().length) / window_size;
+        if (out.empty() || k != current) {
+            out.emplace_back();
+            out.back().rarest = out.back().commonest = r;
+            current = k;
+        }
+        WindowSummary &w = out.back();
+        w.paths += r.count;
+        if (r.count < w.rarest.count) w.rarest = r;
+        if (r.count > w.commonest.count) w.commonest = r;
     }
-    std::set<ulong> s(dividing.begin(), dividing.end());
-    dividing.assign(s.begin(), s.end());
-    return dividing;
+    return out;
 }
+
+// A border is the rarest length of the emptiest of three neighbouring windows, if that frequency is "significantly"
+// below the commonest frequency of the fullest of the three (valley < ratio * peak, an int against a float product).
+// Ties go to the leftmost window, as std::min / std::max over an initializer_list return the first extremum.
+std::vector<ulong> border_lengths(const std::vector<WindowSummary> &w, float ratio_threshold) {
+    std::set<ulong> borders;
+    for (size_t mid = 1; mid + 1 < w.size(); mid++) {
+        size_t valley = mid - 1, peak = mid - 1;
+        for (size_t j = mid; j <= mid + 1; j++) {
+            if (w[j].paths < w[valley].paths) valley = j;
+            if (w[j].paths > w[peak].paths) peak = j;
+        }
+        if (w[valley].rarest.count < ratio_threshold * w[peak].commonest.count) borders.insert(w[valley].rarest.length);
+    }
+    return std::vector<ulong>(borders.begin(), borders.end());
+}
+
+}   // namespace
 
 std::vector<PathGroup> PathManager::constructGroups(std::vector<const Path *> &v, Parameters params) {
     // QUIRK: std::sort is not stable; tie order among equal lengths is libstdc++'s introsort result on this input
     // order, and the group consensus ("first path with length >= average") depends on it.  Same call, same library.
     std::sort(v.begin(), v.end(), [](const Path *a, const Path *b) { return a->length() < b->length(); });
-    const ulong min_len = (ulong) v.front()->length(), max_len = (ulong) v.back()->length();
-    std::vector<PathGroup> pgs;
-    if (max_len - min_len < (ulong) params.len_threshold) {
-        pgs.emplace_back(v.begin(), v.end());
-        return pgs;
+    // lengths are compared as ulong from here on (the reference stores Path::length() into ulong variables)
+    const ulong shortest = (ulong) v.front()->length(), longest = (ulong) v.back()->length();
+    std::vector<PathGroup> groups;
+    auto one_group = [&]() {
+        groups.emplace_back(v.cbegin(), v.cend());
+        return groups;
+    };
+    if (longest - shortest < (ulong) params.len_threshold) return one_group();
+    // (a negative length next to a positive one makes `shortest` the larger number: the reference then builds no window
+    // at all and reads past an empty vector; here that input simply stays one group)
+    if (shortest > longest || params.window_size == 0) return one_group();
+    std::vector<LengthRun> runs;
+    for (const Path *p : v) {
+        const ulong len = (ulong) p->length();
+        if (!runs.empty() && runs.back().length == len) runs.back().count++;
+        else runs.push_back(LengthRun{len, 1});
     }
-    std::vector<PathWindow> pws;
-    for (ulong lower = min_len, upper = lower + params.window_size; lower <= max_len;
-         lower = upper, upper += params.window_size) {
-        pws.emplace_back(lower, upper, v);
-        if (pws.back().getSumFreqs() == 0) pws.pop_back();
+    const std::vector<ulong> borders = border_lengths(summarise_windows(runs, params.window_size), params.ratio_threshold);
+    if (borders.empty()) return one_group();
+    // group k = [first path not yet used, first path at or beyond border k) -- but never empty: a group takes at least
+    // the first unused path even when that one already lies beyond the border (PathManager.cpp:568-572)
+    auto first = v.cbegin();
+    for (ulong border : borders) {
+        if (first == v.cend()) break;       // (the reference would scan past the end here; a border is a length of `v`)
+        auto last = std::partition_point(first + 1, v.cend(), [&](const Path *p) { return (ulong) p->length() < border; });
+        groups.emplace_back(first, last);
+        first = last;
     }
-    const std::vector<ulong> bs = getBorderPathLengths(pws, params.ratio_threshold);
-    if (bs.empty()) {
-        pgs.emplace_back(v.begin(), v.end());
-        return pgs;
-    }
-    std::vector<const Path *>::const_iterator begin = v.begin(), end;
-    for (ulong cur_border : bs) {
-        // the reference scans without a bound; a border is the length of a path in `v`, so the scan stops
-        for (end = begin + 1; end != v.end() && (ulong) (*end)->length() < cur_border; end++) {}
-        pgs.emplace_back(begin, end);
-        begin = end;
-    }
-    pgs.emplace_back(begin, v.cend());
-    return pgs;
+    if (first != v.cend()) groups.emplace_back(first, v.cend());
+    return groups;
 }
 
 std::pair<ulong, ulong> PathManager::getMinMaxPathLength(std::vector<const Path *> &v) {
@@ -204,69 +245,91 @@ long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>
 }
 
 // ---- PathManager::constructConsensusPath (src/PathManager.cpp:664-767) --------------------------------
+// Written from the behaviour.  Candidates are the anchor pairs that have a consensus and at least `min_path_num`
+// paths; the pair with the most paths seeds the scaffold, which then grows by the best-supported candidate that
+// continues it on the left (X -> current left end) or on the right (current right end -> X).
+namespace {
+
+struct Candidate {
+    const Path *consensus;
+    ulong support;              // number of paths between the two anchors
+};
+
+typedef const OverlapGraph::Node *Anchor;
+
+}   // namespace
+
 Path PathManager::constructConsensusPath(const std::map<AnchorPair, std::vector<const Path *>> &paths_between_contigs,
                                          std::map<AnchorPair, const Path *> &consensus_paths, ulong min_path_num) {
-    std::map<AnchorPair, std::pair<const Path *, ulong>> filtered;
-    std::vector<const OverlapGraph::Node *> nodes;
-    auto contains = [](const std::vector<const OverlapGraph::Node *> &v, const OverlapGraph::Node *n) {
-        return std::find(v.begin(), v.end(), n) != v.end();
+    std::map<AnchorPair, Candidate> open;       // candidates not yet built into the scaffold
+    std::vector<Anchor> anchors;                // every anchor of a candidate, in order of first appearance
+    auto remember = [&](Anchor a) {
+        if (std::find(anchors.begin(), anchors.end(), a) == anchors.end()) anchors.push_back(a);
     };
-    ulong max_path_num = 0;
-    AnchorPair max_path_key{nullptr, nullptr};
-    for (const auto &pair : paths_between_contigs) {
-        if (!consensus_paths.at(pair.first)) continue;
-        const ulong path_num = pair.second.size();
-        if (path_num >= min_path_num) {
-            if (!contains(nodes, pair.first.first)) nodes.push_back(pair.first.first);
-            if (!contains(nodes, pair.first.second)) nodes.push_back(pair.first.second);
-            filtered[pair.first] = {consensus_paths[pair.first], path_num};
-            if (max_path_num < path_num) {
-                max_path_num = path_num;
-                max_path_key = pair.first;
-            }
+    const AnchorPair *seed = nullptr;
+    ulong seed_support = 0;
+    for (const auto &entry : paths_between_contigs) {
+        const Path *consensus = consensus_paths.at(entry.first);
+        const ulong support = entry.second.size();
+        if (!consensus || support < min_path_num) continue;
+        remember(entry.first.first);
+        remember(entry.first.second);
+        open[entry.first] = Candidate{consensus, support};
+        if (support > seed_support) {           // the first of equally supported pairs, in map order
+            seed_support = support;
+            seed = &entry.first;
         }
     }
-    // the reference throws std::out_of_range here when no pair passed the filter
-    Path scaffold = *consensus_paths.at(max_path_key);
-    const OverlapGraph::Node *left_anchor = max_path_key.first, *right_anchor = max_path_key.second;
-    std::vector<const OverlapGraph::Node *> visited{left_anchor, right_anchor};    // QUIRK: never extended below
-    AnchorPair pair;
-    while (!filtered.empty()) {             // QUIRK: the seed's own entry is still in `filtered`
-        bool left = false, found = false;
-        max_path_num = 0;
-        for (const OverlapGraph::Node *n : nodes) {
-            if (contains(visited, n)) continue;
-            pair = {n, left_anchor};
-            if (filtered.count(pair) > 0 && max_path_num < filtered[pair].second) {
-                max_path_num = filtered[pair].second;
-                max_path_key = pair;
-                left = true;
-                found = true;
-                left_anchor = n;            // QUIRK: the anchors move DURING the scan over the candidates
+    if (!seed) throw std::out_of_range("map::at");      // what the reference's consensus_paths.at() throws here
+
+    const Path *seed_path = open.at(*seed).consensus;
+    if (!seed_path->materialised()) materialise(*seed_path);
+    Path scaffold;                              // a plain Path: node and edge lists only
+    scaffold.nodes_ = seed_path->nodes_;
+    scaffold.edges_ = seed_path->edges_;
+    scaffold.setLength(seed_path->length());
+    Anchor left_end = seed->first, right_end = seed->second;
+    // QUIRK: only the seed's two anchors are ever excluded from the search; the seed's own candidate stays open
+    const Anchor excluded[2] = {left_end, right_end};
+
+    while (!open.empty()) {
+        const AnchorPair *best = nullptr;
+        AnchorPair best_key;
+        ulong best_support = 0;
+        bool grow_left = false;
+        for (Anchor x : anchors) {
+            if (x == excluded[0] || x == excluded[1]) continue;
+            // QUIRK: an end moves as soon as a better candidate shows up DURING the scan, so later anchors are tested
+            // against the moved end -- and an end moved for a candidate that is then beaten stays moved
+            auto l = open.find(AnchorPair{x, left_end});
+            if (l != open.end() && l->second.support > best_support) {
+                best_support = l->second.support;
+                best_key = l->first;
+                best = &best_key;
+                grow_left = true;
+                left_end = x;
             }
-            pair = {right_anchor, n};
-            if (filtered.count(pair) > 0 && max_path_num < filtered[pair].second) {
-                max_path_num = filtered[pair].second;
-                max_path_key = pair;
-                left = false;
-                found = true;
-                right_anchor = n;
-            }
-        }
-        if (!found) break;
-        const Path *p = filtered[max_path_key].first;
-        if (!left) {
-            for (long i = 0; i < (long) p->edges_.size(); i++) {
-                scaffold.nodes_.push_back(p->nodes_[(size_t) i + 1]);
-                scaffold.edges_.push_back(p->edges_[(size_t) i]);
-            }
-        } else {
-            for (long i = (long) p->edges_.size() - 1; i >= 0; i--) {
-                scaffold.nodes_.insert(scaffold.nodes_.begin(), p->nodes_[(size_t) i]);
-                scaffold.edges_.insert(scaffold.edges_.begin(), p->edges_[(size_t) i]);
+            auto r = open.find(AnchorPair{right_end, x});
+            if (r != open.end() && r->second.support > best_support) {
+                best_support = r->second.support;
+                best_key = r->first;
+                best = &best_key;
+                grow_left = false;
+                right_end = x;
             }
         }
-        filtered.erase(max_path_key);
+        if (!best) break;
+        const Path *piece = open.at(*best).consensus;
+        if (!piece->materialised()) materialise(*piece);
+        const size_t m = piece->edges_.size();
+        if (grow_left) {        // nodes 0..m-1 and all edges go in front; node m is the scaffold's current first node
+            scaffold.nodes_.insert(scaffold.nodes_.begin(), piece->nodes_.begin(), piece->nodes_.begin() + (long) m);
+            scaffold.edges_.insert(scaffold.edges_.begin(), piece->edges_.begin(), piece->edges_.end());
+        } else {                // node 0 is the scaffold's current last node
+            scaffold.nodes_.insert(scaffold.nodes_.end(), piece->nodes_.begin() + 1, piece->nodes_.begin() + 1 + (long) m);
+            scaffold.edges_.insert(scaffold.edges_.end(), piece->edges_.begin(), piece->edges_.end());
+        }
+        open.erase(*best);
     }
     return scaffold;
 }

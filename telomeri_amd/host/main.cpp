@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
     PathManager pm;
     const char *mode_string = "AVG";
     std::string dump;
-    bool parse_only = false, no_scaffold = false;
+    bool parse_only = false, no_scaffold = false, materialise = false;
     std::vector<char *> pos;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
         else if (a == "--r-thr") { if (!parse_perc(need("--r-thr"), f)) return 1; pm.params_.ratio_threshold = f; }
         else if (a == "--dump") dump = need("--dump");
         else if (a == "--parse-only") parse_only = true;
+        else if (a == "--materialise") materialise = true;     // fill every nodes_[..].edges, edges_ and Path list, as the reference does
         else if (a == "--no-scaffold") no_scaffold = true;      // stop after getPathsBetweenAnchors (hot path only)
         else if (a == "--test-load-num") { if (!parse_ulong(need("--test-load-num"), u)) return 1; graph.test_load_num_ = (uint) u; }
         else pos.push_back(argv[i]);
@@ -105,6 +106,12 @@ int main(int argc, char **argv) {
     };
     std::cout << "\nLoading overlaps..." << std::endl;
     double parse_ms = 0, build_ms = 0, dl_ms = 0;
+    // By default the adjacency and the paths' node lists stay on the device (lean graph, packed paths): the host stages
+    // need lengths, end nodes and equality of paths, and the Edge records of the scaffold's paths only.  --dump and
+    // --materialise fill every public member of the reference's classes.
+    if (!dump.empty()) materialise = true;
+    graph.set_lean(!materialise);
+    pm.set_packed(!materialise);
     graph.begin_loads();            // one device build + one materialisation for both files
     for (int k = 0; k < 2; k++) {                                                     // Main.cpp:223
         if (!graph.load(pos[k], k == 1)) return 1;

@@ -415,6 +415,26 @@ bool OverlapGraph::rebuild() {
     // download and materialise the reference's data members
     const auto t_dl = std::chrono::steady_clock::now();
     const size_t N = gi.n_nodes, A = (size_t) gi.n_adj;
+    if (lean_) {        // nodes_ without their edge lists; edges_ stays empty (see set_lean)
+        std::vector<uint32_t> node_len(N);
+        std::vector<uint8_t> anchor(N);
+        std::vector<int32_t> name_id(N);
+        if (tlm_graph_download(dev_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               node_len.data(), anchor.data(), name_id.data()) != TLM_OK)
+            die("tlm_graph_download");
+        nodes_.clear();
+        nodes_.resize(N);
+        edges_.clear();
+        for (size_t i = 0; i < N; i++) {
+            Node &n = nodes_[i];
+            n.anchor = anchor[i] != 0;
+            n.index = (uint) i;
+            n.length = node_len[i];
+            n.name = names_[(size_t) name_id[i]];
+        }
+        download_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count();
+        return true;
+    }
     std::vector<uint64_t> row_ptr(N + 1);
     std::vector<uint32_t> nbr(A), qs(A), qe(A), ts(A), te(A), node_len(N), kept(gi.n_kept);
     std::vector<float> os(A), si(A), es(A);
@@ -510,7 +530,30 @@ void OverlapGraph::Edge::to_stream(std::ostream &s) const {
       << "  SI: " << sequence_identity << std::endl;
 }
 
+static std::string stats_text(ulong anchors, ulong reads, ulong total, ulong min_len, ulong max_len, ulong min_con, ulong max_con,
+                              ulong n_edges, ulong min_OL, ulong max_OL, float min_OS, float max_OS, float min_ES, float max_ES,
+                              float min_SI, float max_SI) {
+    std::stringstream str;
+    str << "Nodes" << '\n'
+        << "-  anchor: " << anchors << '\n' << "-    read: " << reads << '\n' << "-   total: " << total << '\n'
+        << "- min_len: " << min_len << '\n' << "- max_len: " << max_len << '\n'
+        << "- min_con: " << min_con << '\n' << "- max_con: " << max_con << '\n'
+        << "Edges" << '\n'
+        << "-   total: " << n_edges << '\n' << "-  min_OL: " << min_OL << '\n' << "-  max_OL: " << max_OL << '\n'
+        << "-  min_OS: " << min_OS << '\n' << "-  max_OS: " << max_OS << '\n'
+        << "-  min_ES: " << min_ES << '\n' << "-  max_ES: " << max_ES << '\n'
+        << "-  min_SI: " << min_SI << '\n' << "-  max_SI: " << max_SI << '\n' << std::endl;
+    return str.str();
+}
+
 std::string OverlapGraph::stats() {     // the report of OverlapGraph.cpp:24-95, same text
+    if (lean_ && dev_) {                // the same extrema, reduced on the device over the resident adjacency
+        tlm_graph_stats st;
+        if (tlm_graph_get_stats(dev_, &st) != TLM_OK) die("tlm_graph_get_stats");
+        return stats_text(st.anchors, st.reads, nodes_.size(), st.min_len, st.max_len, st.min_con, st.max_con, st.edges,
+                          st.edges ? st.min_ol : ULONG_MAX, st.max_ol, st.min_os, st.max_os, st.min_es, st.max_es, st.min_si,
+                          st.max_si);
+    }
     ulong min_len = (ulong) -1, max_len = 0, min_con = (ulong) -1, max_con = 0, anchors = 0, reads = 0;
     for (const Node &n : nodes_) {
         (n.anchor ? anchors : reads)++;
@@ -532,17 +575,8 @@ std::string OverlapGraph::stats() {     // the report of OverlapGraph.cpp:24-95,
         if (min_OL > (ulong) ol) min_OL = (ulong) ol;
         if (max_OL < (ulong) ol) max_OL = (ulong) ol;
     }
-    std::stringstream str;
-    str << "Nodes" << '\n'
-        << "-  anchor: " << anchors << '\n' << "-    read: " << reads << '\n' << "-   total: " << nodes_.size() << '\n'
-        << "- min_len: " << min_len << '\n' << "- max_len: " << max_len << '\n'
-        << "- min_con: " << min_con << '\n' << "- max_con: " << max_con << '\n'
-        << "Edges" << '\n'
-        << "-   total: " << edges_.size() << '\n' << "-  min_OL: " << min_OL << '\n' << "-  max_OL: " << max_OL << '\n'
-        << "-  min_OS: " << min_OS << '\n' << "-  max_OS: " << max_OS << '\n'
-        << "-  min_ES: " << min_ES << '\n' << "-  max_ES: " << max_ES << '\n'
-        << "-  min_SI: " << min_SI << '\n' << "-  max_SI: " << max_SI << '\n' << std::endl;
-    return str.str();
+    return stats_text(anchors, reads, nodes_.size(), min_len, max_len, min_con, max_con, edges_.size(), min_OL, max_OL, min_OS,
+                      max_OS, min_ES, max_ES, min_SI, max_SI);
 }
 
 // --- Utils ---------------------------------------------------------------------------------------

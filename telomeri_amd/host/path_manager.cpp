@@ -20,11 +20,17 @@ void Path::updateLength() {             // Path.cpp:6-16: first node's length + 
     for (size_t i = 1; i < edges_.size(); i++) length_ += (long) edges_[i - 1]->q_start - (long) edges_[i - 1]->t_start;
 }
 
-bool Path::operator==(const Path &o) const {
-    return nodes_.size() == o.nodes_.size() && std::equal(nodes_.begin(), nodes_.end(), o.nodes_.begin());
+bool Path::operator==(const Path &o) const {       // Path.cpp:46-49: the node sequences are equal (edges are not compared)
+    if (node_count() != o.node_count()) return false;
+    // two paths of device sets: a different hash of the node sequence settles it without fetching either list
+    if (owner_ && o.owner_ && hash_ != o.hash_) return false;
+    if (!have_nodes_) owner_->materialise(*this);
+    if (!o.have_nodes_) o.owner_->materialise(o);
+    return std::equal(nodes_.begin(), nodes_.end(), o.nodes_.begin());
 }
 
 std::ostream &operator<<(std::ostream &s, const Path &p) {      // "*n3-n17-...": Path.cpp:24-43
+    if (!p.have_nodes_) p.owner_->materialise(p);
     for (size_t i = 0; i < p.nodes_.size(); i++) {
         if (i) s << "-";
         if (p.nodes_[i]->anchor) s << '*';
@@ -56,7 +62,8 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
     uint64_t n_paths = 0;
     tlm_pathset_sizes(ps, &n_paths, nullptr, nullptr);
     append_from(g, ps);
-    dev_sets_.push_back(ps);             // stays on the device for filterUnique / getPathsBetweenAnchors
+    dev_sets_.push_back(ps);             // stays on the device: filterUnique, getPathsBetweenAnchors, materialise
+    if (!packed_) materialiseAll();
     last_counters = Counters{c.units, c.steps, c.evals, c.draws, c.accepted, c.kernel_ms};
     std::cout << "Found " << n_paths << " paths." << std::endl;      // PathManager.cpp:172,387
 }
@@ -65,39 +72,125 @@ PathManager::~PathManager() {
     for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
 }
 
+static void die_tlm(const char *what) {
+    std::cerr << "telomeri_hip: " << what << " failed: " << tlm_last_error() << std::endl;
+    std::exit(1);
+}
+
 void PathManager::append_from(const OverlapGraph &g, tlm_pathset *ps) {
-    uint64_t n_paths = 0, n_nodes = 0;
-    tlm_pathset_sizes(ps, &n_paths, &n_nodes, nullptr);
-    std::vector<uint64_t> off(n_paths + 1);
+    // Path objects in set order = the reference's append order (PathManager.cpp:154,226,382).  Only the per-path
+    // summary crosses PCIe here (36 bytes a path); the node and slot lists stay in the device set.
+    uint64_t n_paths = 0;
+    tlm_pathset_sizes(ps, &n_paths, nullptr, nullptr);
     std::vector<int64_t> length(n_paths);
-    std::vector<uint32_t> nodes(n_nodes), slots(n_nodes);
-    if (tlm_pathset_export(ps, 0, nullptr, length.data(), off.data(), nodes.data(), slots.data()) != TLM_OK) {
-        std::cerr << "telomeri_hip: export failed: " << tlm_last_error() << std::endl;
-        std::exit(1);
-    }
-    // Path objects in set order = the reference's append order (PathManager.cpp:154,226,382); the pointer chasing
-    // into nodes_[..].edges is spread over the host cores
+    std::vector<uint32_t> front(n_paths), back(n_paths), count(n_paths);
+    std::vector<uint64_t> hash(n_paths);
+    if (tlm_pathset_export(ps, 0, nullptr, length.data(), nullptr, nullptr, nullptr) != TLM_OK) die_tlm("export");
+    if (tlm_pathset_summary(OverlapGraph::context(), ps, front.data(), back.data(), count.data(), hash.data()) != TLM_OK)
+        die_tlm("summary");
     const size_t base = paths_.size();
     paths_.resize(base + n_paths);
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    if (n_paths < 256) nt = 1;
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&, t] {
-            for (uint64_t i = n_paths * t / nt; i < n_paths * (t + 1) / nt; i++) {
-                Path &p = paths_[base + i];
-                const uint64_t a = off[i], b = off[i + 1];
-                p.nodes_.resize(b - a);
-                p.edges_.resize(b - a - 1);
-                for (uint64_t k = a; k < b; k++) {
-                    const OverlapGraph::Node *n = &g.nodes_[nodes[k]];
-                    p.nodes_[k - a] = n;
-                    if (k + 1 < b) p.edges_[k - a] = &n->edges[slots[k]];
+    for (uint64_t i = 0; i < n_paths; i++) {
+        Path &p = paths_[base + i];
+        p.owner_ = this;
+        p.index_ = base + i;
+        p.hash_ = hash[i];
+        p.front_ = front[i];
+        p.back_ = back[i];
+        p.n_nodes_ = count[i];
+        p.have_nodes_ = false;
+        p.setLength((long) length[i]);
+    }
+    (void) g;
+}
+
+void PathManager::materialise(const Path &p) const { materialise(std::vector<const Path *>{&p}); }
+
+void PathManager::materialise(const std::vector<const Path *> &want) const {
+    // requested paths by device set (paths_ = the sets one after the other), one fetch per set
+    std::vector<uint64_t> set_end;
+    uint64_t acc = 0;
+    for (tlm_pathset *ps : dev_sets_) {
+        uint64_t n = 0;
+        tlm_pathset_sizes(ps, &n, nullptr, nullptr);
+        set_end.push_back(acc += n);
+    }
+    std::vector<std::vector<const Path *>> by_set(dev_sets_.size());
+    for (const Path *p : want) {
+        if (p->have_nodes_ || p->owner_ != this) continue;
+        const size_t k = std::upper_bound(set_end.begin(), set_end.end(), p->index_) - set_end.begin();
+        if (k >= dev_sets_.size()) {
+            std::cerr << "PathManager: path " << p->index_ << " is not in a device set" << std::endl;
+            std::exit(1);
+        }
+        by_set[k].push_back(p);
+    }
+    const bool lean = graph_->lean();
+    for (size_t k = 0; k < by_set.size(); k++) {
+        const std::vector<const Path *> &v = by_set[k];
+        if (v.empty()) continue;
+        const uint64_t first = k ? set_end[k - 1] : 0;
+        std::vector<uint64_t> idx(v.size());
+        uint64_t total = 0;
+        for (size_t j = 0; j < v.size(); j++) {
+            idx[j] = v[j]->index_ - first;
+            total += v[j]->n_nodes_;
+        }
+        std::vector<uint32_t> nodes(total), slots(total);
+        if (tlm_pathset_fetch(OverlapGraph::context(), dev_sets_[k], idx.size(), idx.data(), nodes.data(), slots.data()) != TLM_OK)
+            die_tlm("fetch");
+        std::vector<tlm_edge> fetched;
+        if (lean) {         // the Edge records of these paths, from the device CSR (nodes_[..].edges is empty)
+            std::vector<uint32_t> en, es;
+            en.reserve(total);
+            es.reserve(total);
+            uint64_t a = 0;
+            for (const Path *p : v) {
+                for (uint64_t j = 0; j + 1 < p->n_nodes_; j++) {
+                    en.push_back(nodes[a + j]);
+                    es.push_back(slots[a + j]);
                 }
-                p.setLength((long) length[i]);
+                a += p->n_nodes_;
             }
-        });
-    for (auto &x : th) x.join();
+            fetched.resize(en.size());
+            if (tlm_graph_edges(graph_->device_graph(), en.size(), en.data(), es.data(), fetched.data()) != TLM_OK)
+                die_tlm("edge fetch");
+        }
+        uint64_t a = 0, fe = 0;
+        for (const Path *cp : v) {
+            Path &p = const_cast<Path &>(*cp);          // paths_ elements are ours; filling the lazy members is not a change
+            const uint64_t n = p.n_nodes_;
+            p.nodes_.resize(n);
+            p.edges_.resize(n ? n - 1 : 0);
+            for (uint64_t j = 0; j < n; j++) {
+                const OverlapGraph::Node *node = &graph_->nodes_[nodes[a + j]];
+                p.nodes_[j] = node;
+                if (j + 1 < n) {
+                    if (lean) {
+                        const tlm_edge &e = fetched[fe++];
+                        edge_pool_.push_back(OverlapGraph::Edge{e.q_index, e.t_index, e.q_start, e.q_end, e.t_start, e.t_end,
+                                                                e.overlap_score, e.sequence_identity, e.extension_score,
+                                                                e.relative_strand != 0});
+                        p.edges_[j] = &edge_pool_.back();
+                    } else {
+                        p.edges_[j] = &node->edges[slots[a + j]];
+                    }
+                }
+            }
+            a += n;
+            p.have_nodes_ = true;
+        }
+    }
+}
+
+void PathManager::materialiseAll() {
+    // in slices: the staging buffers of one fetch hold the node lists of the slice
+    const size_t step = 4096;
+    for (size_t i = 0; i < paths_.size(); i += step) {
+        std::vector<const Path *> v;
+        for (size_t j = i; j < std::min(paths_.size(), i + step); j++) v.push_back(&paths_[j]);
+        materialise(v);
+    }
 }
 
 tlm_pathset *PathManager::single_set() {
@@ -135,7 +228,9 @@ void PathManager::filterUnique() {      // PathManager.cpp:432-438: ADJACENT dup
     tlm_pathset_destroy(all);
     dev_sets_.assign(1, uniq);
     paths_.clear();
+    edge_pool_.clear();
     append_from(*graph_, uniq);
+    if (!packed_) materialiseAll();
 }
 
 std::tuple<ulong, ulong, ulong> PathManager::getMinMaxSumPathLength() {
@@ -176,7 +271,7 @@ PathManager::getPathsBetweenAnchors() {  // PathManager.cpp:626-645: buckets by 
     }
     for (size_t j = 0; j < order.size(); j++) {      // keys ascending = the map's (Node*, Node*) order
         const Path &p = paths_[order[j]];
-        out[{p.nodes_.front(), p.nodes_.back()}].push_back(&p);
+        out[{&graph_->nodes_[p.front_], &graph_->nodes_[p.back_]}].push_back(&p);
     }
     return out;
 }

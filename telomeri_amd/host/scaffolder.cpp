@@ -7,6 +7,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <vector>
 
 #include "telomeri_host.hpp"
 
@@ -63,49 +64,91 @@ void Scaffolder::swapBases(std::string &str) {          // :129-147
     }
 }
 
-static std::string reversed(std::string s) {
-    std::reverse(s.begin(), s.end());
-    return s;
-}
+// ---- Scaffolder::write (Scaffolder.cpp:43-102), written from its behaviour ---------------------------------
+// The scaffold runs from the LAST node of the path to the first.  The reference appends the reverse of every piece to one
+// string and reverses that string at the end; the same text comes out when the pieces are kept as they are cut and
+// written in the opposite order, which is what happens here.  Pieces, for a path of nodes n_0..n_m and edges e_0..e_m-1
+// (e_k joins n_k and n_k+1; coordinates with INCLUSIVE ends, clamped at the end of the string like std::string::substr):
+//   n_0        : seq[e_0.t_end + 1 ..]
+//   n_k, 0<k<m : with a = e_k.t_end, b = e_k-1.q_end:   a < b  -> seq[a + 1 .. b], complemented (NOT reversed) when
+//                e_k-1 lies on the '-' strand; a == b -> nothing; a > b -> the scaffold loses the a - b characters
+//                appended last (the read is skipped and does not appear in the printed name chain either)
+//   n_m        : seq[0 .. e_m-1.q_end]
+namespace {
 
-bool Scaffolder::write(const char *filename) {          // Scaffolder.cpp:43-102
+class PieceStack {          // the pieces cut so far, oldest first
+    std::vector<std::string> pieces_;
+    size_t total_ = 0;
+
+public:
+    void push(std::string piece) {
+        total_ += piece.size();
+        pieces_.push_back(std::move(piece));
+    }
+    // Drop the `count` characters appended last.  In the reference's reversed string those are its tail; here they are
+    // the HEAD of the newest piece, then of the one before it, and so on.
+    // QUIRK (unsigned arithmetic of Scaffolder.cpp:90): asking for more than there is leaves everything in place.
+    void drop_last(ulong count) {
+        if (count > total_) return;
+        total_ -= count;
+        while (count > 0) {
+            std::string &newest = pieces_.back();
+            if (newest.size() <= count) {
+                count -= newest.size();
+                pieces_.pop_back();
+            } else {
+                newest.erase(0, count);
+                count = 0;
+            }
+        }
+    }
+    void write_newest_first(std::ostream &out) const {
+        for (auto it = pieces_.rbegin(); it != pieces_.rend(); ++it) out << *it;
+    }
+};
+
+}   // namespace
+
+bool Scaffolder::write(const char *filename) {
     std::ofstream out(filename);
     if (!out) {
         std::cerr << "Cannot write file: " << filename << std::endl;
         return false;
     }
     out << ">Resulting_HERA_scaffold" << std::endl;
-    std::string sequence, tmp;
-    if (p_.nodes_.empty()) {
+    const size_t n_nodes = p_.nodes_.size(), n_edges = p_.edges_.size();
+    if (n_nodes == 0) {
         std::cerr << "Scaffold is empty!" << std::endl;
         return false;
     }
-    if (p_.nodes_.size() == 1) {                        // single node: the sequence reversed, no trailing newline
-        std::cout << p_.nodes_[0]->name << std::endl;
-        out << reversed(getSequenceFrom(p_.nodes_[0]->name));
+    auto name_of = [&](size_t k) -> const std::string & { return p_.nodes_[k]->name; };
+    if (n_nodes == 1) {         // QUIRK: the sequence comes out REVERSED here, and without a newline after it
+        std::cout << name_of(0) << std::endl;
+        const std::string &seq = getSequenceFrom(name_of(0));
+        out << std::string(seq.rbegin(), seq.rend());
         return true;
     }
-    std::cout << p_.nodes_[0]->name;
-    tmp = getSequenceFrom(p_.nodes_[0]->name);
-    sequence += reversed(substring(tmp, (ulong) p_.edges_[0]->t_end + 1, tmp.size()));
-    for (ulong i = 1; i < p_.edges_.size(); i++) {
-        const OverlapGraph::Edge *e = p_.edges_[i - 1], *e_next = p_.edges_[i];
-        const ulong start = e_next->t_end, end = e->q_end;
-        if (start < end) {
-            tmp = getSequenceFrom(p_.nodes_[i]->name);
-            if (e->relative_strand) swapBases(tmp);
-            std::cout << '-' << p_.nodes_[i]->name;
-            sequence += reversed(substring(tmp, start + 1, end));
-        } else if (start == end) {
-            continue;
-        } else {                                        // going backwards: drop the afflicted tail
-            sequence = substring(sequence, 0, sequence.length() - 1 - (start - end));
+    PieceStack scaffold;
+    std::cout << name_of(0);
+    {
+        std::string &seq = getSequenceFrom(name_of(0));
+        scaffold.push(substring(seq, (ulong) p_.edges_[0]->t_end + 1, seq.size()));
+    }
+    for (size_t k = 1; k < n_edges; k++) {
+        const OverlapGraph::Edge &arriving = *p_.edges_[k - 1], &leaving = *p_.edges_[k];
+        const ulong from = leaving.t_end, to = arriving.q_end;
+        if (from < to) {
+            std::string piece = substring(getSequenceFrom(name_of(k)), from + 1, to);
+            if (arriving.relative_strand) swapBases(piece);
+            std::cout << '-' << name_of(k);
+            scaffold.push(std::move(piece));
+        } else if (from > to) {
+            scaffold.drop_last(from - to);
         }
     }
-    std::cout << '-' << p_.nodes_.back()->name << std::endl;
-    tmp = getSequenceFrom(p_.nodes_.back()->name);
-    sequence += reversed(substring(tmp, 0, p_.edges_.back()->q_end));
-    std::reverse(sequence.begin(), sequence.end());
-    out << sequence << std::endl;
+    std::cout << '-' << name_of(n_nodes - 1) << std::endl;
+    scaffold.push(substring(getSequenceFrom(name_of(n_nodes - 1)), 0, p_.edges_[n_edges - 1]->q_end));
+    scaffold.write_newest_first(out);
+    out << std::endl;
     return true;
 }

@@ -20,6 +20,7 @@
 
 #include <climits>
 #include <cstdint>
+#include <deque>
 #include <map>
 #include <ostream>
 #include <string>
@@ -79,6 +80,12 @@ public:
      *  Calls accumulate into one graph (Main.cpp:223 loads rr then cr). */
     bool load(char *filepath, bool anchors);
     std::string stats();                // OverlapGraph.cpp:24-95
+    /** Not in the reference.  A lean graph keeps nodes_ (name, index, length, anchor) but leaves nodes_[i].edges and
+     *  edges_ EMPTY: the adjacency stays on the device, where the walks read it (233 M entries = 9 GB of Edge structs at
+     *  the A. thaliana size), stats() is reduced there, and the few Edge records the Scaffolder needs are fetched per path
+     *  (PathManager::materialise).  Default off: every public member is filled as in the reference. */
+    void set_lean(bool on) { lean_ = on; }
+    bool lean() const { return lean_; }
     /** Not in the reference.  Between begin_loads() and end_loads(), load() only tokenises its file; the device graph
      *  is built and the public members are filled ONCE, by end_loads(), which then prints the "Loaded K/R edges" line
      *  of every file.  Without the pair every load() rebuilds everything loaded so far (same final state). */
@@ -110,12 +117,24 @@ private:
     double build_ms_ = 0, parse_ms_ = 0, download_ms_ = 0;
     bool parsed_parallel_ = false;
     bool deferred_ = false;
+    bool lean_ = false;
     std::vector<std::pair<std::string, ulong>> pending_;   // (path, records read) of the loads since begin_loads()
     bool rebuild();                     // device build over all files loaded so far + download into nodes_/edges_
 };
 
+class PathManager;
+
 class Path {                            // Path.hpp:7-21
     long length_ = 0;
+    // A path that lives in a device Path set (PathManager) carries what grouping and bucketing need -- length, end
+    // nodes, node count, a hash of the node sequence -- and gets its nodes_ / edges_ only when somebody asks for them
+    // (PathManager::materialise): 372 k paths x 3500 nodes would be 20 GB of pointers at the A. thaliana size, of which
+    // the scaffold uses a few hundred paths.
+    friend class PathManager;
+    const PathManager *owner_ = nullptr;
+    uint64_t index_ = 0, hash_ = 0;
+    uint32_t front_ = 0, back_ = 0, n_nodes_ = 0;
+    mutable bool have_nodes_ = true;    // false: nodes_ / edges_ are still on the device
 
 public:
     std::vector<const OverlapGraph::Node *> nodes_;
@@ -124,6 +143,8 @@ public:
     long length() const { return length_; }
     void setLength(long l) { length_ = l; }   // the device reports Path::length(); updateLength() recomputes it
     bool operator==(const Path &o) const;     // Path.cpp:46-49: node sequence only
+    bool materialised() const { return have_nodes_; }
+    size_t node_count() const { return have_nodes_ ? nodes_.size() : n_nodes_; }
     friend std::ostream &operator<<(std::ostream &s, const Path &p);
 };
 
@@ -209,6 +230,13 @@ public:
                                 std::map<AnchorPair, const Path *> &consensus_for_anchors, const Parameters &params);
 
     const std::vector<Path> &paths() const { return paths_; }   // not in the reference (paths_ is private there)
+    /** Not in the reference.  Packed mode (default on): builders leave the node / edge lists of their paths on the
+     *  device; materialise() fills nodes_ / edges_ of one path (or of all) from there.  Off: every path is materialised
+     *  as it is built, as the reference does. */
+    void set_packed(bool on) { packed_ = on; }
+    void materialise(const Path &p) const;
+    void materialise(const std::vector<const Path *> &ps) const;
+    void materialiseAll();
     /** Test hook (CPU-only validation of the host stages): take paths produced elsewhere. */
     void adoptPaths(std::vector<Path> &&p) { paths_ = std::move(p); }
     struct Counters { uint64_t units, steps, evals, draws, accepted; double kernel_ms; };
@@ -216,8 +244,12 @@ public:
 
 private:
     void build(const OverlapGraph &g, const Utils::Metrics &metric, bool mc);
-    void append_from(const OverlapGraph &g, tlm_pathset *ps);   // materialise Path objects from a device set
+    void append_from(const OverlapGraph &g, tlm_pathset *ps);   // Path objects (packed views) of a device set
     tlm_pathset *single_set();                                   // concatenation of dev_sets_ (owned by dev_sets_)
+    bool packed_ = true;
+    // paths_ is the concatenation of dev_sets_ in order (Path::index_ = position in paths_); Edge records fetched for
+    // the paths of a lean graph live here (a deque: pointers into it stay valid)
+    mutable std::deque<OverlapGraph::Edge> edge_pool_;
 };
 
 class Scaffolder {                      // Scaffolder.hpp:11-34

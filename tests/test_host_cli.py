@@ -151,3 +151,29 @@ def test_bundled_fixture_through_cli(binary):
             assert "Loaded %d/24127 edges" % known[key]["kept"] in res.stdout
             assert "-  anchor: 3" in res.stdout
             assert "- max_con: %d" % known[key]["max_con"] in res.stdout
+
+
+@pytest.mark.parametrize("name", ["tiny", "quirks"])
+def test_lean_host_equals_materialised_host(binary, name):
+    """Default mode (adjacency and path node lists stay on the device: stats() reduced there, Edge records fetched for the
+    scaffold's paths only) writes the same report and the same scaffold as --materialise (every nodes_[..].edges, edges_
+    and Path list filled as the reference does)."""
+    from telomeri_amd import synth
+    import helpers as H
+    meta = G.load_json(name + ".json")
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
+        reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
+        synth.write_fasta(ds, reads, contigs)
+        outs = []
+        for extra in ([], ["--materialise"]):
+            out = os.path.join(tmp, "o%d.fa" % len(outs))
+            res = subprocess.run([binary] + _flags(meta["args"]) + extra + [rr, cr, reads, contigs, out], capture_output=True,
+                                 text=True, timeout=300)
+            body = open(out, "rb").read() if os.path.exists(out) else b""
+            keep = [ln for ln in res.stdout.splitlines() if ln.startswith(("-", "Nodes", "Edges", "Paths", "Found", "Consensus",
+                                                                           "Final", "ctg", "read", "Anchor pairs"))]
+            outs.append((res.returncode, body, keep))
+        assert outs[0] == outs[1]
+        assert any(ln.startswith("-  min_OS") for ln in outs[0][2])
