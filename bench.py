@@ -77,6 +77,13 @@ def main() -> None:
     ctx = capi.Context(local_rank)
     if args.waves_per_cu:
         ctx.set_walk_tuning(args.waves_per_cu, 0)
+    # the product's exchange: an RCCL communicator owned by the library context (tlm_dist_init); torch.distributed only
+    # carries the 128-byte unique id to the other ranks and the final max / sum of the timing
+    use_abi_exchange = world > 1 and args.dist_backend == "nccl" and os.environ.get("TLM_EXCHANGE", "abi") == "abi"
+    if use_abi_exchange:
+        box = [capi.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.dist_init(rank, world, box[0])
     ds = synth.make_config(args.config, device=str(dev))
     torch.cuda.synchronize(dev)
     t_gen = time.time() - t0
@@ -129,13 +136,22 @@ def main() -> None:
             else:
                 a, b = g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
                 sets += [a, b]; ctrs += [("det", a.counters), ("det", b.counters)]
-        if world > 1:
+        if use_abi_exchange:            # ONE grouped RCCL exchange of the packed device buffers (tlm_pathset_allgather)
+            gathered, xi = capi.PathSet.allgather(sets)
+            n_total = gathered.n_paths
+            exch["bytes_sent"] = int(xi.bytes_sent); exch["bytes_received"] = int(xi.bytes_received)
+            exch["ms"] = exch.get("ms", 0.0) + float(xi.device_ms); exch["calls"] = exch.get("calls", 0) + 1
+            exch["slot_bits"] = int(xi.slot_bits)
+            del gathered
+        elif world > 1:                 # rehearsal over torch.distributed (gloo on a 1-GPU box)
             packed = [pathgather.PackedPaths(*ps.to_device_tensors(dev)) for ps in sets]
             gathered = pathgather.allgather_paths(packed)
             n_total = sum(p.n_paths for p in gathered)
         else:
             n_total = sum(ps.n_paths for ps in sets)
         return ctrs, n_total
+
+    exch = {}
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -146,6 +162,7 @@ def main() -> None:
     for _ in range(args.warmup):
         one_step()
     sync()
+    exch.pop("ms", None); exch.pop("calls", None)
     t0 = time.time()
     evals = 0
     mc_ms = mc_evals = mc_launches = 0.0
@@ -208,7 +225,7 @@ def main() -> None:
                                                                          apg, args.rb_att),
                    "anchors_total": n_anchors, "anchors_walked": min(apg * world, n_anchors), "anchors_per_gpu": apg, "rebuild_attempts": args.rb_att, "backtrack_attempts": args.bt_att,
                    "len_threshold": args.len_thr, "seed_policy": "per-walk mt19937",
-                   "partition": "anchor bundles per rank, CSR replicated, one all-gather of Paths"},
+                   "partition": "anchor bundles per rank, CSR replicated, one all-gather of Paths (inside the timed step)"},
         "roofline": {"bound": "hbm", "kernel": "walk_mc_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                      "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                      "achieved_is": "algorithmic bytes (8 B per eval) per second, not HBM traffic",
@@ -222,6 +239,13 @@ def main() -> None:
                     "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
         "paths_per_step": paths_total,
     }
+    if world > 1:
+        out["exchange"] = {"transport": "tlm_pathset_allgather (RCCL send/recv, library-owned communicator)" if use_abi_exchange
+                           else "telomeri_amd.pathgather over torch.distributed/%s" % args.dist_backend,
+                           "allgather_bytes_sent_per_rank": exch.get("bytes_sent"),
+                           "allgather_bytes_received_per_rank": exch.get("bytes_received"),
+                           "slot_bits_on_the_wire": exch.get("slot_bits"),
+                           "ms_per_step_rank0": exch["ms"] / max(exch.get("calls", 1), 1) if "ms" in exch else None}
 
     # SURVEY.md §8f row 1, outside the timed region: paths_ = concat of the four sets, filterUnique,
     # getPathsBetweenAnchors on the device

@@ -289,6 +289,40 @@ int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tlm_pathset *
  * (front Node*, back Node*)), inside one key in path order.  A bucket is a run of equal keys. */
 int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *order_host, uint64_t *key_host);
 
+/* ---- multi-GPU: one process per GPU, ONE exchange ---------------------------------------- */
+/* The graph is replicated (every rank builds it from the same files); rank r of `world` walks the units of the anchors
+ * tlm_dist_anchor_range gives it (contiguous bundles of ceil(n_anchors / world) anchors: MC units
+ * [a0 * rebuild_attempts, a1 * rebuild_attempts), DET units [det_off[a0], det_off[a1]) of tlm_graph_anchor_table) with no
+ * collective in between; then every rank calls tlm_pathset_allgather once and holds paths_ as one PathManager would
+ * after the reference's builder calls (Main.cpp:237-243), element for element.  The transport is RCCL (grouped
+ * ncclSend / ncclRecv between every pair of ranks, each block received in its final place), loaded on first use. */
+#define TLM_UNIQUE_ID_BYTES 128
+#define TLM_EXCHANGE_MAX_BLOCKS 64
+/* Rank 0 makes the id (ncclGetUniqueId); the host hands the 128 bytes to the other ranks (a file, a socket, the
+ * launcher); then every rank calls tlm_dist_init with the same bytes.  One communicator per context. */
+int tlm_dist_unique_id(uint8_t id_out[TLM_UNIQUE_ID_BYTES]);
+int tlm_dist_init(tlm_ctx *ctx, int rank, int world, const uint8_t id[TLM_UNIQUE_ID_BYTES]);
+void tlm_dist_finalize(tlm_ctx *ctx);
+int tlm_dist_rank(const tlm_ctx *ctx);          /* 0 without tlm_dist_init */
+int tlm_dist_world(const tlm_ctx *ctx);         /* 1 without tlm_dist_init */
+int tlm_dist_anchor_range(const tlm_graph *g, int rank, int world, uint32_t *anchor_begin, uint32_t *anchor_end);
+
+typedef struct {
+    uint64_t bytes_sent;           /* by this rank, to all peers together */
+    uint64_t bytes_received;
+    uint32_t slot_bits;            /* 16, or 32 if some neighbour list has 65 535 entries or more */
+    double device_ms;              /* HIP events around the exchange on the context's stream */
+    double wall_ms;
+} tlm_exchange_info;
+/* sets[0..n_sets): this rank's Path sets, one per builder call, in call order (the same n_sets on every rank).
+ * *out: the sets of all ranks, builder by builder, inside a builder in rank order (= unit order); unit[i] carries the
+ * builder in its top byte as tlm_pathset_concat does.  With world == 1 this IS tlm_pathset_concat. */
+int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *const *sets, tlm_pathset **out, tlm_exchange_info *info);
+/* The placement rule of that exchange, as host arithmetic: counts[(r * n_sets + b) * 2 + {0, 1}] = paths, nodes of rank
+ * r's set b -> where that block starts in the result (same (r, b) indexing), and the result's totals[2]. */
+int tlm_exchange_layout(int world, int n_sets, const uint64_t *counts, uint64_t *path_base, uint64_t *node_base,
+                        uint64_t *totals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,9 +70,27 @@ class GraphInfo(C.Structure):
         return {lib().tlm_build_phase_name(i).decode(): float(self.phase_ms[i]) for i in range(12)}
 
 
+class GraphStats(C.Structure):
+    _fields_ = [("anchors", C.c_uint64), ("reads", C.c_uint64), ("min_len", C.c_uint64), ("max_len", C.c_uint64),
+                ("min_con", C.c_uint64), ("max_con", C.c_uint64), ("edges", C.c_uint64), ("min_ol", C.c_uint64),
+                ("max_ol", C.c_uint64), ("min_os", C.c_float), ("max_os", C.c_float), ("min_es", C.c_float),
+                ("max_es", C.c_float), ("min_si", C.c_float), ("max_si", C.c_float)]
+
+
+EDGE_DTYPE = np.dtype([("q_index", np.uint32), ("t_index", np.uint32), ("q_start", np.uint32), ("q_end", np.uint32),
+                       ("t_start", np.uint32), ("t_end", np.uint32), ("overlap_score", np.float32),
+                       ("sequence_identity", np.float32), ("extension_score", np.float32), ("relative_strand", np.uint8)],
+                      align=True)
+
+
 class MemoryInfo(C.Structure):
     _fields_ = [("live_bytes", C.c_uint64), ("cached_bytes", C.c_uint64), ("peak_live_bytes", C.c_uint64),
                 ("driver_allocs", C.c_uint64), ("reuses", C.c_uint64), ("driver_alloc_ms", C.c_double)]
+
+
+class ExchangeInfo(C.Structure):
+    _fields_ = [("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("slot_bits", C.c_uint32),
+                ("device_ms", C.c_double), ("wall_ms", C.c_double)]
 
 
 UNIT_STAT_DTYPE = np.dtype([("status", np.uint8), ("n_nodes", np.uint32), ("steps", np.uint32), ("evals", np.uint64),
@@ -137,6 +155,19 @@ def lib() -> C.CDLL:
     L.tlm_pathset_concat.argtypes = [V, C.c_int, P(V), P(V)]
     L.tlm_pathset_filter_unique.argtypes = [V, V, P(V)]
     L.tlm_pathset_anchor_pairs.argtypes = [V, V, V, V]
+    L.tlm_pathset_summary.argtypes = [V, V, V, V, V, V]
+    L.tlm_pathset_fetch.argtypes = [V, V, C.c_uint64, V, V, V]
+    L.tlm_graph_edges.argtypes = [V, C.c_uint64, V, V, V]
+    L.tlm_graph_get_stats.argtypes = [V, P(GraphStats)]
+    L.tlm_dist_unique_id.argtypes = [V]
+    L.tlm_dist_init.argtypes = [V, C.c_int, C.c_int, V]
+    L.tlm_dist_finalize.argtypes = [V]
+    L.tlm_dist_finalize.restype = None
+    L.tlm_dist_rank.argtypes = [V]
+    L.tlm_dist_world.argtypes = [V]
+    L.tlm_dist_anchor_range.argtypes = [V, C.c_int, C.c_int, P(C.c_uint32), P(C.c_uint32)]
+    L.tlm_pathset_allgather.argtypes = [V, C.c_int, P(V), P(V), P(ExchangeInfo)]
+    L.tlm_exchange_layout.argtypes = [C.c_int, C.c_int, V, V, V, V]
     _lib = L
     return L
 
@@ -225,6 +256,35 @@ class PathSet:
                 out.append((int(k >> np.uint64(32)), int(k & np.uint64(0xFFFFFFFF)), seg.tolist()))
         return out
 
+    def summary(self):
+        """-> (front, back, n_nodes uint32, hash uint64) per path (tlm_pathset_summary)."""
+        front = np.zeros(self.n_paths, np.uint32)
+        back = np.zeros(self.n_paths, np.uint32)
+        count = np.zeros(self.n_paths, np.uint32)
+        h = np.zeros(self.n_paths, np.uint64)
+        _check(lib().tlm_pathset_summary(self._ctx._h, self._h, _np_ptr(front), _np_ptr(back), _np_ptr(count), _np_ptr(h)),
+               "tlm_pathset_summary")
+        return front, back, count, h
+
+    def fetch(self, index, n_nodes):
+        """Node and slot lists of the paths `index`, concatenated (n_nodes: the summary's counts)."""
+        index = np.ascontiguousarray(index, np.uint64)
+        total = int(np.asarray(n_nodes)[index.astype(np.int64)].sum()) if index.size else 0
+        nodes = np.zeros(total, np.uint32)
+        slots = np.zeros(total, np.uint32)
+        _check(lib().tlm_pathset_fetch(self._ctx._h, self._h, index.shape[0], _np_ptr(index), _np_ptr(nodes), _np_ptr(slots)),
+               "tlm_pathset_fetch")
+        return nodes, slots
+
+    @staticmethod
+    def allgather(sets):
+        """tlm_pathset_allgather: the one exchange of the multi-GPU build -> (PathSet of all ranks, ExchangeInfo)."""
+        arr = (C.c_void_p * len(sets))(*[s._h for s in sets])
+        h = C.c_void_p()
+        info = ExchangeInfo()
+        _check(lib().tlm_pathset_allgather(sets[0]._ctx._h, len(sets), arr, C.byref(h), C.byref(info)), "tlm_pathset_allgather")
+        return PathSet(h, sets[0].counters, sets[0]._ctx), info
+
     @staticmethod
     def concat(sets) -> "PathSet":
         """paths_ after several builder calls (Main.cpp:237-243)."""
@@ -296,6 +356,24 @@ class Graph:
                                         _np_ptr(te), _np_ptr(os_), _np_ptr(si), _np_ptr(es), _np_ptr(strand),
                                         _np_ptr(node_len), _np_ptr(node_anchor), _np_ptr(name_id)), "tlm_graph_download")
         return HostCsr(n, a, row_ptr, nbr, qs, qe, ts, te, os_, si, es, strand, node_len, node_anchor, name_id)
+
+    def edges(self, nodes, slots) -> np.ndarray:
+        """OverlapGraph::Edge records of the (node, slot) pairs (tlm_graph_edges) as a structured array."""
+        nodes = np.ascontiguousarray(nodes, np.uint32)
+        slots = np.ascontiguousarray(slots, np.uint32)
+        out = np.zeros(nodes.shape[0], EDGE_DTYPE)
+        _check(lib().tlm_graph_edges(self._h, nodes.shape[0], _np_ptr(nodes), _np_ptr(slots), _np_ptr(out)), "tlm_graph_edges")
+        return out
+
+    def stats(self) -> GraphStats:
+        st = GraphStats()
+        _check(lib().tlm_graph_get_stats(self._h, C.byref(st)), "tlm_graph_get_stats")
+        return st
+
+    def anchor_range(self, rank: int, world: int):
+        a0, a1 = C.c_uint32(), C.c_uint32()
+        _check(lib().tlm_dist_anchor_range(self._h, rank, world, C.byref(a0), C.byref(a1)), "tlm_dist_anchor_range")
+        return int(a0.value), int(a1.value)
 
     def kept_records(self) -> np.ndarray:
         out = np.zeros(int(self.info().n_kept), np.uint32)
@@ -397,6 +475,14 @@ class Context:
     def set_walk_tuning(self, waves_per_cu: int = 0, path_capacity: int = 0) -> None:
         _check(lib().tlm_ctx_set_walk_tuning(self._h, waves_per_cu, path_capacity), "tlm_ctx_set_walk_tuning")
 
+    def dist_init(self, rank: int, world: int, unique_id: bytes) -> None:
+        """One RCCL communicator per context; `unique_id` = the 128 bytes rank 0 got from dist_unique_id()."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib().tlm_dist_init(self._h, rank, world, buf), "tlm_dist_init")
+
+    def dist_finalize(self) -> None:
+        lib().tlm_dist_finalize(self._h)
+
     def set_arena_limit(self, nbytes: int) -> None:
         _check(lib().tlm_ctx_set_arena_limit(self._h, nbytes), "tlm_ctx_set_arena_limit")
 
@@ -471,6 +557,23 @@ class Context:
                                         _np_ptr(si), _np_ptr(es), _np_ptr(strand), _np_ptr(node_len), _np_ptr(node_anchor),
                                         C.byref(h)), "tlm_graph_from_csr")
         return Graph(self, h)
+
+
+def dist_unique_id() -> bytes:
+    buf = (C.c_uint8 * 128)()
+    _check(lib().tlm_dist_unique_id(buf), "tlm_dist_unique_id")
+    return bytes(buf)
+
+
+def exchange_layout(counts: np.ndarray):
+    """counts[world, n_sets, 2] (paths, nodes) -> path_base[world, n_sets], node_base[world, n_sets], (paths, nodes) totals."""
+    counts = np.ascontiguousarray(counts, np.uint64)
+    world, n_sets, _ = counts.shape
+    pb = np.zeros((world, n_sets), np.uint64)
+    nb = np.zeros((world, n_sets), np.uint64)
+    tot = np.zeros(2, np.uint64)
+    _check(lib().tlm_exchange_layout(world, n_sets, _np_ptr(counts), _np_ptr(pb), _np_ptr(nb), _np_ptr(tot)), "tlm_exchange_layout")
+    return pb, nb, (int(tot[0]), int(tot[1]))
 
 
 def walk_seed(metric: int, anchor_node: int, r: int) -> int:

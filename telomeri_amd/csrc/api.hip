@@ -96,6 +96,7 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     if (!ctx) return;
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     (void) hipSetDevice(c->device);
+    tlm_dist_finalize(ctx);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->side.stream) (void) hipStreamSynchronize(c->side.stream);
     c->ws.release_scratch();
@@ -192,7 +193,8 @@ extern "C" void tlm_graph_destroy(tlm_graph *g) {
     (void) hipDeviceSynchronize();      // kernels of either walk lane may still read the graph
     void *bufs[] = {g->row_ptr, g->ent_es, g->ent_os, g->q_start, g->t_start, g->q_end, g->t_end, g->si, g->strand,
                     g->node_len, g->node_anchor, g->node_flags, g->node_name_id, g->anchors, g->det_off, g->w_row,
-                    g->w_ent_es, g->w_ent_os, g->w_qt, g->kept_rec, g->w_old_of_new, g->w_anchors};
+                    g->w_ent_es, g->w_ent_os, g->w_qt, g->kept_rec, g->w_old_of_new, g->w_anchors, g->w_m_es, g->w_m_os,
+                    g->w_d16};
     for (void *b : bufs) tlm_pool_free(b, true);
     delete g;
 }
@@ -491,7 +493,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
 
     if (n_units) {
         const uint32_t N = g->n_nodes;
-        const uint32_t full_cap = N + 2;
+        // a walk pushes at most N nodes and logs at most N marks + one band move per step or backtrack
+        const uint32_t full_cap = (uint32_t) std::min<uint64_t>(2ull * N + 64u, 0xFFFFFFF0ull);
         uint32_t cap = ctx->path_capacity ? ctx->path_capacity : 16384u;
         cap = std::max<uint32_t>(8u, std::min(cap, full_cap));
         const uint32_t bm_words = (N + 31) / 32 + 1 + WALK_RNG_WORDS;
@@ -525,6 +528,10 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         a.ents = ents_of(metrics[0]);
         a.flag_bit = 1u << metrics[0];
         a.metric = metrics[0];
+        auto mets_of = [&](int m) { return (m == TLM_METRIC_ES || m == TLM_METRIC_ES_SQRT) ? g->w_m_es : g->w_m_os; };
+        a.met = mets_of(metrics[0]);
+        a.met1 = mets_of(metrics[n_slots - 1]);
+        a.d16 = g->w_d16;
         a.ents1 = ents_of(metrics[n_slots - 1]);
         a.flag_bit1 = 1u << metrics[n_slots - 1];
         a.metric1 = metrics[n_slots - 1];

@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
                                                           const uint32_t *__restrict__ q_start,
                                                           const uint32_t *__restrict__ t_start, uint2 *__restrict__ w_row,
                                                           uint2 *__restrict__ w_ent_es, uint2 *__restrict__ w_ent_os,
-                                                          uint2 *__restrict__ w_qt) {
+                                                          uint2 *__restrict__ w_qt, uint32_t *__restrict__ w_m_es,
+                                                          uint32_t *__restrict__ w_m_os, uint16_t *__restrict__ w_d16) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -443,8 +444,17 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
         const uint32_t r0 = row_ptr[o], deg = row_ptr[o + 1] - r0, w0 = w_start[node];
         const uint32_t pdeg = tlm_padded_degree(deg);
         bool anchor_nbr = false;        // does the list hold an anchor?  (bit 28: the forced-anchor test can be skipped)
-        for (uint32_t j = lane; j < deg; j += 64) anchor_nbr |= (ent_es[r0 + j].x >> 31) != 0;
-        const uint32_t fl = (uint32_t) node_flags[o] | (__ballot(anchor_nbr) ? 16u : 0u);
+        bool far_nbr = false;           // a neighbour further than 32767 ids away (walk order): no 16-bit relative id
+        for (uint32_t j = lane; j < deg; j += 64) {
+            const uint32_t x = ent_es[r0 + j].x;
+            anchor_nbr |= (x >> 31) != 0;
+            const uint32_t rel = new_of_old[x & 0x7FFFFFFFu] - node + 32768u;
+            far_nbr |= rel > 65535u;
+        }
+        // bit 29: the row may be read in its compact form (metric + 16-bit relative id, no anchor among the neighbours)
+        // (a node without a list has no row of its own: a lane would read its successor's relative ids against the wrong node)
+        const bool compact = deg != 0 && !__ballot(anchor_nbr) && !__ballot(far_nbr);
+        const uint32_t fl = (uint32_t) node_flags[o] | (__ballot(anchor_nbr) ? 16u : 0u) | (compact ? 32u : 0u);
         if (lane == 0) w_row[node] = make_uint2(w0, deg | (fl << 24));
         for (uint32_t j = lane; j < pdeg; j += 64) {
             const bool real = j < deg;
@@ -460,6 +470,9 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
             }
             w_ent_es[w0 + j] = es;
             w_ent_os[w0 + j] = os;
+            w_m_es[w0 + j] = es.y;
+            w_m_os[w0 + j] = os.y;
+            w_d16[w0 + j] = (uint16_t) (compact ? (es.x & 0x7FFFFFFFu) - node + 32768u : 32768u);
             w_qt[w0 + j] = real ? make_uint2(q_start[r0 + j], t_start[r0 + j]) : make_uint2(0u, 0u);
         }
     }
@@ -697,6 +710,13 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         if (int rc = tlm_pool_alloc((void **) &g->w_ent_es, (apad + 256) * sizeof(uint2), s)) return rc;
         if (int rc = tlm_pool_alloc((void **) &g->w_ent_os, (apad + 256) * sizeof(uint2), s)) return rc;
         if (int rc = tlm_pool_alloc((void **) &g->w_qt, (apad + 256) * sizeof(uint2), s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &g->w_m_es, (apad + 256) * 4, s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &g->w_m_os, (apad + 256) * 4, s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &g->w_d16, (apad + 256) * 2, s)) return rc;
+        TLM_HIP(hipMemsetAsync(g->w_m_es + apad, 0, 256 * 4, s));
+        TLM_HIP(hipMemsetAsync(g->w_m_os + apad, 0, 256 * 4, s));
+        // relative id 32768 = "the row's own node": whatever a lane reads past the last row stays a valid node id
+        TLM_HIP(hipMemsetD16Async((hipDeviceptr_t) (g->w_d16 + apad), 0x8000, 256, s));
         // 256 zero entries of slack after the last row: a lane's 8-entry read never leaves the buffer
         TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
         TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));
@@ -704,7 +724,8 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         if (N) {
             hipLaunchKernelGGL(walk_layout_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
                                g->w_old_of_new, new_of_old.as<uint32_t>(), ws.as<uint32_t>(), g->node_flags, g->ent_es,
-                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt);
+                               g->ent_os, g->q_start, g->t_start, g->w_row, g->w_ent_es, g->w_ent_os, g->w_qt, g->w_m_es,
+                               g->w_m_os, g->w_d16);
         }
         ph.mark(PH_LAYOUT);
     }

@@ -38,6 +38,8 @@ struct tlm_ctx {
     uint32_t path_capacity = 0;    // 0 = default
     uint64_t arena_limit = 0;      // bytes; 0 = default (tlm_ctx_set_arena_limit)
     std::vector<hipEvent_t> phase_ev;   // graph-build phase marks, created on first use
+    void *comm = nullptr;          // ncclComm_t (exchange.hip); rank / world of the one-process-per-GPU job
+    int rank = 0, world = 1;
 };
 
 // Device-resident graph.  HBM layout:
@@ -67,6 +69,10 @@ struct tlm_graph {
     uint2 *w_row = nullptr;            // [N] {padded row start, degree | order-safety flags << 24}
     uint2 *w_ent_es = nullptr, *w_ent_os = nullptr;   // [n_adj_pad]
     uint2 *w_qt = nullptr;             // [n_adj_pad] {q_start, t_start}
+    // compact copy of the same rows, same index space: 4-byte metric + 2-byte neighbour id relative to the
+    // row's own node = 6 bytes per eval instead of 8; read by the walk kernel for every row whose flag bit 5 is set
+    uint32_t *w_m_es = nullptr, *w_m_os = nullptr;   // [n_adj_pad] fp32 bits
+    uint16_t *w_d16 = nullptr;         // [n_adj_pad] neighbour - owner + 32768 (walk-order ids)
     uint32_t *w_old_of_new = nullptr;  // [N] reference node index of each walk-order node
     uint32_t *w_anchors = nullptr;     // [n_anchors] walk-order index of each anchor
     int32_t *node_name_id = nullptr;

@@ -32,6 +32,9 @@ struct WalkArgs {
     const uint2 *rows;              // per node {row start, degree | order-safety flags << 24}
     const uint2 *ents;              // w_ent_es or w_ent_os
     const uint2 *qt;                // per entry {q_start, t_start}: the length increment of Path::updateLength
+    const uint32_t *met;            // compact rows: fp32 bits of the metric per entry (w_m_es or w_m_os) ...
+    const uint16_t *d16;            // ... and neighbour - owner + 32768 per entry; same index space as `ents`
+    const uint32_t *met1;           // slot 1
     const uint32_t *node_len;       // reference order
     const uint32_t *old_of_new;     // reference node index of a walk-order node (results are reported in those)
     uint32_t n_nodes;

@@ -68,6 +68,8 @@ struct HotArgs {
     const uint2 *rows;
     const uint2 *ents;
     const uint2 *qt;
+    const uint32_t *met;       // compact rows: metric bits ...
+    const uint16_t *d16;       // ... and 16-bit relative neighbour ids
     uint32_t cap;
     uint32_t flag_bit;
     int32_t backtrack_attempts;
@@ -289,7 +291,21 @@ __device__ inline void finish_unit(const WaveScratch &ws, int lane, uint32_t ui,
         u.status = status;
         ca->units[ui] = u;
     }
-    for (uint32_t i = lane; i < nlog; i += 64) ws.bm[ws.lg[i] >> 5] = 0u;
+    // the wave's HBM map goes back to all-zero: single marks by node id, flushed bands (band_slide) by their first word
+    const uint32_t n_words = ca->bm_words - WALK_RNG_WORDS;
+    for (uint32_t base = 0; base < nlog; base += 64) {
+        const bool valid = base + lane < nlog;
+        const uint32_t e = valid ? ws.lg[base + lane] : 0u;
+        if (valid && !(e >> 31)) ws.bm[e >> 5] = 0u;
+        uint64_t bands = __ballot(valid && (e >> 31));
+        while (bands) {
+            const int j = __ffsll((unsigned long long) bands) - 1;
+            bands &= bands - 1;
+            const uint32_t first = readlane_u32(e, j) & 0x7FFFFFFFu;
+            for (uint32_t k = lane; k < WIN_WORDS; k += 64)
+                if (first + k < n_words) ws.bm[first + k] = 0u;
+        }
+    }
     wave_sync();
 }
 
@@ -370,6 +386,61 @@ __device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint3
     return act;
 }
 
+// The same K entries of a COMPACT row (row flag bit 29): 4-byte metric + 2-byte neighbour id relative to the row's own
+// node -- 6 bytes per eval instead of 8, 11 instead of 15 cache lines for a list of 236 entries.  The kernel runs at
+// the rate at which gathered rows leave HBM / the Infinity Cache, so bytes are time.  Ids come out
+// relative to the visited band (`d` = id - band base), which is what the probe wants anyway: id = d + lo.
+template <int K>
+__device__ __forceinline__ bool lane_load_c(const uint32_t *met, const uint16_t *d16, uint32_t row, uint32_t deg, int lane,
+                                            uint32_t rel_base, uint32_t (&d)[K], uint32_t (&mb)[K]) {
+    const uint32_t first = (uint32_t) K * (uint32_t) lane;
+    const bool act = first < deg;
+    const uint32_t off = row + (act ? first : 0u);      // rows start at multiples of 8 entries: 32-byte / 16-byte aligned
+    struct alignas(K == 6 ? 8 : 16) Met { uint32_t v[K]; };
+    struct alignas(K == 6 ? 4 : 2 * K) Ids { uint32_t v[K / 2]; };
+    const Met m = *reinterpret_cast<const Met *>(met + off);
+    const Ids w = *reinterpret_cast<const Ids *>(d16 + off);
+#pragma unroll
+    for (int k = 0; k < K; k++) mb[k] = m.v[k];
+#pragma unroll
+    for (int j = 0; j < K / 2; j++) {
+        d[2 * j] = (w.v[j] & 0xFFFFu) + rel_base;       // (v_add_u32 with an SDWA word select)
+        d[2 * j + 1] = (w.v[j] >> 16) + rel_base;
+    }
+    return act;
+}
+
+// visited masks for band-relative ids (compact rows hold no anchors: every id is a plain node id)
+template <int K>
+__device__ __forceinline__ void lane_probe_rel(const Visited &vs, const uint32_t (&d)[K], uint32_t (&vis)[K]) {
+    uint32_t any = 0u;
+#ifdef TLM_ABLATE_NOBM
+#pragma unroll
+    for (int k = 0; k < K; k++) vis[k] = 0u;
+    (void) any;
+#else
+    const uint32_t wb = lds_addr(vs.win);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        any |= d[k];
+        static_assert(WIN_WORDS == 512u, "the bit-field width below is log2(WIN_WORDS)");
+        uint32_t addr;
+        asm("v_bfe_u32 %0, %1, 5, 9\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=v"(addr) : "v"(d[k]), "s"(wb));
+        vis[k] = *(__attribute__((address_space(3))) const uint32_t *) (uintptr_t) addr;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) vis[k] = (uint32_t) __builtin_amdgcn_sbfe((int) vis[k], d[k], 1u);   // lo is a multiple of 32
+    if (__builtin_expect(__ballot(any >= WIN_BITS) != 0, 0)) {    // rare: a neighbour outside the band
+#ifdef TLM_TIMING
+        if ((threadIdx.x & 63) == 0) atomicAdd(&tlm_timing[6], 1ull);
+#endif
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (d[k] >= WIN_BITS) vis[k] = bm_test(vs.bm, d[k] + vs.lo) ? ~0u : 0u;
+    }
+#endif
+}
+
 // forced anchor edge: the first entry, in list order, whose neighbour is an anchor other than `start` (:57-60).
 // Returns its position relative to the chunk (lane*K+k) or -1.  Padding entries carry no anchor bit; an inactive
 // lane repeats lane 0's entries, and lane 0 wins the find-first.
@@ -418,6 +489,9 @@ __device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&n
 #pragma unroll
     for (int k = 0; k < K; k++) vis[k] = (uint32_t) __builtin_amdgcn_sbfe((int) vis[k], nb[k], 1u);
     if (__builtin_expect(__ballot(any >= WIN_BITS) != 0, 0)) {    // rare: an anchor neighbour, or a neighbour outside the band
+#ifdef TLM_TIMING
+        if ((threadIdx.x & 63) == 0) atomicAdd(&tlm_timing[7], 1ull);
+#endif
 #pragma unroll
         for (int k = 0; k < K; k++)
             if (nb[k] - vs.lo >= WIN_BITS) vis[k] = visited_test(vs, nb[k] & 0x7FFFFFFFu) ? ~0u : 0u;
@@ -427,7 +501,8 @@ __device__ __forceinline__ void lane_probe(const Visited &vs, const uint32_t (&n
 
 // Selection among the K*64 entries held in registers.  `mb` arrives masked (0 where the entry is not a candidate),
 // `va` is the AND of the lane's visited masks (all ones = no candidate in this lane).
-template <int K, bool SQRT>
+// REL: `nb` holds band-relative ids of a compact row (no anchor bits): neighbour = nb + vs.lo.
+template <int K, bool SQRT, bool REL = false>
 __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, Rng &rng, int lane,
                                                uint32_t base, bool act, const uint32_t (&nb)[K], const uint32_t (&mb)[K],
                                                uint32_t va, uint32_t &draws) {
@@ -459,7 +534,8 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
             nb2[k] = nb[k];
             asm volatile("" : "+v"(nb2[k]));
         }
-        lane_probe<K>(vs, nb2, vis);
+        if (REL) lane_probe_rel<K>(vs, nb2, vis);
+        else lane_probe<K>(vs, nb2, vis);
 #pragma unroll
         for (int k = K - 2; k >= 0; k--)
             if (vis[k] == 0u) {
@@ -489,8 +565,8 @@ __device__ __forceinline__ void select_in_regs(Selection &s, const Visited &vs, 
     const int k = __builtin_amdgcn_readlane(myk, hl);
     const uint32_t e = readlane_u32(mynb, hl);
     s.pick = (int) base + hl * K + k;
-    s.nbr = e & 0x7FFFFFFFu;
-    s.anchor = e >> 31;
+    s.nbr = REL ? e + vs.lo : e & 0x7FFFFFFFu;
+    s.anchor = REL ? 0u : e >> 31;
 }
 
 // A list of at most 64*K entries: one load, one visited probe, ONE scan (it yields the total and every lane's
@@ -522,6 +598,25 @@ __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visite
         va &= vis[k];
     }
     select_in_regs<K, SQRT>(s, vs, rng, lane, 0u, act, nb, mb, va, draws);
+    return s;
+}
+
+// The same on a compact row (no anchor in the list, so no forced-anchor test; `node` = the row's own node).
+template <int K, bool SQRT>
+__device__ __forceinline__ Selection select_short_c(const HotArgs &a, const Visited &vs, Rng &rng, int lane, uint32_t row,
+                                                    uint32_t deg, uint32_t node, uint32_t &draws, StepClock &clk) {
+    Selection s{-1, 0u, 0u, 0u, 0u, deg};
+    uint32_t d[K], mb[K], vis[K];
+    const bool act = lane_load_c<K>(a.met, a.d16, row, deg, lane, node - vs.lo - 32768u, d, mb);
+    clk.mark(CLK_LIST_WAIT, true);
+    lane_probe_rel<K>(vs, d, vis);
+    uint32_t va = ~0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        mb[k] &= ~vis[k];
+        va &= vis[k];
+    }
+    select_in_regs<K, SQRT, true>(s, vs, rng, lane, 0u, act, d, mb, va, draws);
     return s;
 }
 
@@ -684,6 +779,28 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
     return s;
 }
 
+// The LDS band FOLLOWS the walk.  Ids are walk-order indices: (nearest anchor, BFS level), so a walk is among nearby ids
+// while it stays in the neighbourhood of one anchor -- and jumps to another id range when it crosses into the next
+// anchor's neighbourhood, which every accepted walk does once (anchors are numbered in node order, not along the genome).
+// A band fixed at the start anchor left a third of all steps probing the HBM map (measured).  So: when the
+// current node is further than BAND_SLACK from the band's centre, the band's bits are OR-ed into the wave's HBM map
+// (the flushed range is logged, the map is cleared from the log when the walk ends) and the band is re-loaded around the
+// current node.  The set stays exact at every moment: band ids in LDS, all others in HBM.
+constexpr uint32_t BAND_SLACK = WIN_BITS / 2 - 1024;
+
+__device__ __forceinline__ uint32_t band_base_for(uint32_t n) { return n > WIN_BITS / 2 ? (n - WIN_BITS / 2) & ~31u : 0u; }
+
+__device__ __noinline__ void band_slide(lds_u32 *win, glb_u32 *bm, uint32_t n_words, uint32_t old_lo, uint32_t new_lo, int lane) {
+    const uint32_t ow = old_lo >> 5, nw = new_lo >> 5;
+    for (uint32_t i = lane; i < WIN_WORDS; i += 64) {
+        const uint32_t w = win[i];
+        if (w) bm[ow + i] |= w;             // a set bit is a real node id: the word exists
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the two ranges may overlap: stores first, then the loads
+    for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = nw + i < n_words ? bm[nw + i] : 0u;
+    wave_sync();
+}
+
 // The path under construction (edge i, node i + 1) goes to the wave's HBM scratch -- but not one store per step: on
 // gfx9 loads and stores share one outstanding-operation counter and return out of order with respect to each other,
 // so a wave with a store in flight has to wait for ALL its memory operations before it may touch a loaded value.
@@ -753,13 +870,34 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     StepClock clk;
     clk.start();
     for (;;) {                                          // :48
+        {   // keep the band around the walk (rare: about once per walk)
+            const uint32_t want = band_base_for(n);
+            if (__builtin_expect(want - vs.lo + BAND_SLACK > 2u * BAND_SLACK, 0)) {
+                if (nlog + 1 > a.cap) {
+                    status = ST_SCRATCH_OVF;
+                    break;
+                }
+                if (lane == 0) ws.lg[nlog] = 0x80000000u | (vs.lo >> 5);
+                nlog++;
+                band_slide((lds_u32 *) win, (glb_u32 *) ws.bm, cold_args()->bm_words - WALK_RNG_WORDS, vs.lo, want, lane);
+                vs.lo = want;
+#ifdef TLM_TIMING
+                if (lane == 0) atomicAdd(&tlm_timing[4], 1ull << 32);
+#endif
+            }
+        }
         clk.mark(CLK_ROW_WAIT, true);
         const uint32_t row = rfl(rec.x);
         const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
         const bool safe = ((rfl(rec.y) >> 24) & a.flag_bit) != 0;
         const bool anchor_nbr = ((rfl(rec.y) >> 28) & 1u) != 0;
+        const bool compact = ((rfl(rec.y) >> 29) & 1u) != 0;
         // ---- selection scan (:53-115)
         const Selection s = !safe        ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
+                            : __builtin_expect(compact && deg <= 512u, 1)
+                                ? (deg <= 256u   ? select_short_c<4, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                                   : deg <= 384u ? select_short_c<6, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                                                 : select_short_c<8, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk))
                             : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
                             : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
                             : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
@@ -1320,6 +1458,8 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
         h.rows = a.rows;
         h.ents = slot1 ? ca->ents1 : a.ents;
         h.qt = a.qt;
+        h.met = slot1 ? ca->met1 : a.met;
+        h.d16 = a.d16;
         h.cap = a.cap;
         h.flag_bit = slot1 ? ca->flag_bit1 : a.flag_bit;
         h.backtrack_attempts = a.backtrack_attempts;
@@ -1386,9 +1526,12 @@ void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const 
         (void) hipStreamSynchronize(s);
         (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(tlm_timing), sizeof(h));
         if (h[5])
-            fprintf(stderr, "[tlm timing] %llu steps (%.1f %% on rows that hold an anchor); cycles per step: row-record wait "
-                            "%.0f, list wait %.0f, selection %.0f, bookkeeping %.0f\n", h[5], 100.0 * h[4] / h[5],
-                    (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[3] / h[5]);
+            fprintf(stderr, "[tlm timing] %llu steps (%.1f %% on rows that hold an anchor; probes outside the LDS band on %.1f %% "
+                            "of the steps: %.1f %% compact rows + %.1f %% other rows); cycles per step: row-record wait "
+                            "%.0f, list wait %.0f, selection %.0f, bookkeeping %.0f; band moves %llu\n", h[5],
+                    100.0 * (h[4] & 0xFFFFFFFFull) / h[5],
+                    100.0 * (h[6] + h[7]) / h[5], 100.0 * h[6] / h[5], 100.0 * h[7] / h[5],
+                    (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[3] / h[5], h[4] >> 32);
     }
 #endif
 }

@@ -6,9 +6,12 @@ then one variable-length all-gather hands every rank the whole Path set, ordered
 `paths_` vector is: builder by builder ([MC/ES][MC/OS][DET/ES][DET/OS], Main.cpp:237-243), inside a
 builder by unit (anchor in node order, then trial / first-edge position).
 
-Backend: torch.distributed -- "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in the CPU tests.  The
-payload of all builders travels in ONE all_gather of a padded int64 buffer per rank; a second, tiny
-all_gather carries the sizes.  On a fully connected xGMI node each rank's shard crosses each link once.
+This module is the harness's rehearsal of that exchange over torch.distributed ("gloo" in the CPU tests): the
+payload of all builders travels in ONE all_gather of a padded int64 buffer per rank; a second, tiny all_gather
+carries the sizes.  The PRODUCT's exchange is tlm_pathset_allgather in the C ABI (telomeri_amd/csrc/exchange.hip:
+RCCL send/recv of the packed device buffers, every block received in its final place, 6 bytes per path node on the
+wire); bench.py uses that one on the GPUs, and both produce the same Path set (tests/test_pathgather_gloo.py checks
+this module against the ABI's placement rule, tlm_exchange_layout).
 """
 from __future__ import annotations
 
@@ -38,10 +41,9 @@ class PackedPaths:
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous, balanced split of n_items (anchors) over the ranks."""
-    base, rem = divmod(n_items, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous bundles of ceil(n_items / world) anchors: the rule of tlm_dist_anchor_range."""
+    per = (n_items + world - 1) // world
+    return min(n_items, rank * per), min(n_items, rank * per + per)
 
 
 def _pad64(n32: int) -> int:
@@ -112,9 +114,11 @@ def allgather_paths(local: Sequence[PackedPaths], group=None) -> List[PackedPath
     # one receive buffer, rank r's shard at [r * max_len, (r + 1) * max_len): RCCL writes it in place
     recv = torch.empty(world * padded.shape[0], dtype=torch.int64, device=payload.device)
     bufs = list(recv.chunk(world))
-    try:
+    # the variant is chosen from the backend, up front and identically on every rank: a rank that fell back to another
+    # collective after an error would leave the others waiting in the first one
+    if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(recv, padded, group=group)      # the single exchange of the data path
-    except (RuntimeError, NotImplementedError):                      # backends without the flat variant
+    else:
         dist.all_gather(bufs, padded, group=group)
     per_rank = [unpack(m[:-1], b[:int(m[-1])]) for m, b in zip(metas, bufs)]
     return [concat([per_rank[r][b] for r in range(world)]) for b in range(len(local))]

@@ -405,6 +405,94 @@ def test_memory_is_reused_and_trimmed(ctx):
     assert m2.cached_bytes == 0
 
 
+def test_pathset_summary_and_fetch(ctx):
+    """What the packed host keeps of a path (front, back, node count, hash) and the on-demand fetch of node lists."""
+    ds = synth.make_config("toy")
+    dg = H.device_graph(ctx, ds, capi.FilterParams.default())
+    wp = capi.WalkParams.default(rb_att=30)
+    a, b = dg.walk_mc(capi.METRIC_ES, wp), dg.walk_det(capi.METRIC_OS)
+    both = capi.PathSet.concat([a, b, a])           # every path of `a` occurs twice: equal sequences, equal hashes
+    h = both.to_host()
+    front, back, count, hsh = both.summary()
+    off = h.off.astype(np.int64)
+    np.testing.assert_array_equal(front, h.nodes[off[:-1]])
+    np.testing.assert_array_equal(back, h.nodes[off[1:] - 1])
+    np.testing.assert_array_equal(count, np.diff(off))
+    seqs = [h.nodes[off[i]:off[i + 1]].tobytes() for i in range(len(h))]
+    by_hash = {}
+    for i, x in enumerate(hsh):
+        by_hash.setdefault(int(x), set()).add(seqs[i])
+    assert all(len(v) == 1 for v in by_hash.values()), "two different node sequences share a hash"
+    assert len(by_hash) == len(set(seqs))
+    np.testing.assert_array_equal(hsh[:a.n_paths], hsh[a.n_paths + b.n_paths:])
+    pick = np.array([len(h) - 1, 0, 3, 3, a.n_paths], np.uint64)
+    nodes, slots = both.fetch(pick, count)
+    want_n = np.concatenate([h.nodes[off[i]:off[i + 1]] for i in pick.astype(np.int64)])
+    want_s = np.concatenate([h.slots[off[i]:off[i + 1]] for i in pick.astype(np.int64)])
+    np.testing.assert_array_equal(nodes, want_n)
+    np.testing.assert_array_equal(slots, want_s)
+    with pytest.raises(capi.TlmError):
+        both.fetch(np.array([len(h)], np.uint64), np.append(count, 0))
+
+
+@pytest.mark.parametrize("name", ["toy", "quirks"])
+def test_graph_edges_and_stats(ctx, name):
+    """tlm_graph_edges / tlm_graph_get_stats (lean hosts) against the downloaded CSR."""
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    dg = H.device_graph(ctx, ds, capi.FilterParams.default("min" if name == "quirks" else "avg"))
+    c = dg.download(cold=True)
+    deg = np.diff(c.row_ptr.astype(np.int64))
+    rng = np.random.default_rng(3)
+    nodes = rng.integers(0, c.n_nodes, size=500).astype(np.uint32)
+    slots = (rng.random(500) * deg[nodes]).astype(np.uint32)
+    e = dg.edges(nodes, slots)
+    k = c.row_ptr[nodes].astype(np.int64) + slots
+    np.testing.assert_array_equal(e["q_index"], c.nbr[k])
+    np.testing.assert_array_equal(e["t_index"], nodes)
+    for f, col in (("q_start", c.q_start), ("q_end", c.q_end), ("t_start", c.t_start), ("t_end", c.t_end)):
+        np.testing.assert_array_equal(e[f], col[k])
+    for f, col in (("overlap_score", c.os), ("sequence_identity", c.si), ("extension_score", c.es)):
+        np.testing.assert_array_equal(e[f].view(np.uint32), col[k].view(np.uint32))
+    np.testing.assert_array_equal(e["relative_strand"], c.strand[k])
+    with pytest.raises(capi.TlmError):
+        dg.edges(np.array([0], np.uint32), np.array([deg[0]], np.uint32))
+    st = dg.stats()
+    assert (st.anchors, st.reads) == (int(c.node_anchor.sum()), c.n_nodes - int(c.node_anchor.sum()))
+    assert (st.min_len, st.max_len, st.min_con, st.max_con) == (int(c.node_len.min()), int(c.node_len.max()), int(deg.min()), int(deg.max()))
+    ol = np.maximum(c.q_end - c.q_start, c.t_end - c.t_start).astype(np.int32).astype(np.int64).astype(np.uint64)
+    assert (st.min_ol, st.max_ol, st.edges) == (int(ol.min()), int(ol.max()), c.n_adj // 2)
+    for got, col, fn in ((st.min_os, c.os, np.min), (st.max_os, c.os, np.max), (st.min_es, c.es, np.min), (st.max_es, c.es, np.max),
+                         (st.min_si, c.si, np.min), (st.max_si, c.si, np.max)):
+        want = np.float32(fn(col))
+        want = np.float32(max(want, 0)) if fn is np.max else want      # the reference's maxima start at 0
+        assert np.float32(got) == want
+
+
+def test_exchange_single_rank(ctx, monkeypatch):
+    """The ABI's exchange on one GPU: world 1 is tlm_pathset_concat; with a one-rank RCCL communicator and
+    TLM_EXCHANGE_SELFTEST the whole exchange path runs (RCCL loaded, sizes collective, placement, fix-up kernels)."""
+    ds = synth.make_config("toy")
+    c2 = capi.Context(0)
+    dg = H.device_graph(c2, ds, capi.FilterParams.default())
+    wp = capi.WalkParams.default(rb_att=30)
+    sets = list(dg.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp))
+    want = capi.PathSet.concat(sets).to_host()
+    got, info = capi.PathSet.allgather(sets)
+    H.assert_paths_equal(got.to_host(), want)
+    assert info.bytes_sent == 0
+    assert dg.anchor_range(0, 1) == (0, 3) and [dg.anchor_range(r, 2) for r in range(2)] == [(0, 2), (2, 3)]
+    assert [dg.anchor_range(r, 8) for r in (0, 2, 3, 7)] == [(0, 1), (2, 3), (3, 3), (3, 3)]
+    c2.dist_init(0, 1, capi.dist_unique_id())
+    monkeypatch.setenv("TLM_EXCHANGE_SELFTEST", "1")
+    got, info = capi.PathSet.allgather(sets)
+    H.assert_paths_equal(got.to_host(), want)
+    assert info.slot_bits == 16 and info.bytes_sent == 0 and info.device_ms > 0
+    with pytest.raises(capi.TlmError):
+        c2.dist_init(0, 1, capi.dist_unique_id())       # one communicator per context
+    c2.dist_finalize()
+    c2.dist_finalize()
+
+
 def _synthetic_csr(n_reads=400, deg=90, seed=0, wild=False):
     """A random graph handed over as CSR (tlm_graph_from_csr): degrees above one 64-lane chunk,
     optionally metrics whose double sums are NOT exact (forces the in-order serial summation)."""

@@ -96,5 +96,47 @@ def test_pack_unpack_roundtrip_and_empty():
             assert torch.equal(getattr(x, f), getattr(y, f)), f
     c = concat([a, e, a])
     assert c.off.tolist() == [0, 3, 5, 8, 10] and c.n_paths == 4
-    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert [shard_range(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def test_exchange_layout_of_the_abi_matches_the_gather_order():
+    """tlm_exchange_layout (host arithmetic of the product's RCCL exchange, telomeri_amd/csrc/exchange.hip): placing
+    every (rank, builder) block where it says yields the same Path set as this module's gather + per-builder concat,
+    concatenated builder by builder (tlm_pathset_concat order).  World sizes 1..8, empty blocks included."""
+    sys.path.insert(0, ROOT)
+    from telomeri_amd import capi
+    from telomeri_amd.pathgather import PackedPaths, concat
+    rng = np.random.default_rng(7)
+    for world in (1, 2, 3, 8):
+        n_sets = 4
+        blocks = {}
+        counts = np.zeros((world, n_sets, 2), np.uint64)
+        for r in range(world):
+            for b in range(n_sets):
+                n_p = int(rng.integers(0, 5)) if (r + b) % 3 else 0
+                lens = rng.integers(2, 9, size=n_p)
+                off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                nodes = rng.integers(0, 1000, size=int(off[-1])).astype(np.int32)
+                slots = rng.integers(0, 300, size=int(off[-1])).astype(np.int32)
+                unit = (np.arange(n_p) + 1000 * r).astype(np.int64)
+                blocks[r, b] = PackedPaths(torch.from_numpy(unit), torch.from_numpy(unit * 7), torch.from_numpy(off),
+                                           torch.from_numpy(nodes), torch.from_numpy(slots))
+                counts[r, b] = (n_p, int(off[-1]))
+        pb, nb, (tot_p, tot_n) = capi.exchange_layout(counts)
+        unit = np.full(tot_p, -1, np.int64)
+        off = np.full(tot_p + 1, -1, np.int64)
+        nodes = np.full(tot_n, -1, np.int32)
+        for (r, b), blk in blocks.items():
+            p0, n0 = int(pb[r, b]), int(nb[r, b])
+            unit[p0:p0 + blk.n_paths] = blk.unit.numpy() | (b << 56)
+            off[p0:p0 + blk.n_paths] = blk.off.numpy()[:-1] + n0
+            nodes[n0:n0 + blk.n_nodes] = blk.nodes.numpy()
+        off[tot_p] = tot_n
+        per_builder = [concat([blocks[r, b] for r in range(world)]) for b in range(n_sets)]
+        want = concat(per_builder)
+        want_unit = np.concatenate([pbk.unit.numpy() | (b << 56) for b, pbk in enumerate(per_builder)])
+        assert tot_p == want.n_paths and tot_n == want.n_nodes
+        np.testing.assert_array_equal(unit, want_unit)
+        np.testing.assert_array_equal(off, want.off.numpy())
+        np.testing.assert_array_equal(nodes, want.nodes.numpy())
