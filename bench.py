@@ -272,6 +272,24 @@ def main() -> None:
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, g, wp, g.download(cold=False), mc_range, capi)
+    if world == 1 and not args.no_scaffold:
+        # the metric's second half: PAF + FASTA TEXT in -> scaffold FASTA out through the C++ host program, on the same
+        # config, reference argv and defaults (profiles/probes/scaffold_bench.py; outside the timed region above)
+        del g
+        ctx.trim()
+        torch.cuda.empty_cache()
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("scaffold_bench", os.path.join(ROOT, "profiles", "probes", "scaffold_bench.py"))
+            sb = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(sb)
+            cfg = args.scaffold_config or args.config
+            sc = sb.run(cfg, device=str(dev))
+            out["scaffold_wall_s"] = sc.get("scaffold_wall_s")
+            out["scaffold"] = sc
+        except Exception as e:      # reported, never fatal for the metric line
+            out["scaffold_wall_s"] = None
+            out["scaffold"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,66 +1,143 @@
 #!/usr/bin/env python3
-"""The second half of BASELINE.json's metric -- scaffold wall-clock, PAF + FASTA in, scaffold FASTA out -- for the C++
-host program `telomeri_hip` (reference argv, reference defaults: 2000 trials per anchor, 60 backtracks) on a synthetic
-dataset of the given shape.  Run on the GPU box:  python profiles/probes/scaffold_bench.py [config]   (default ecoli)
-Writes one JSON line: wall-clock of the whole program, its own per-stage times, output size."""
+"""The second half of BASELINE.json's metric -- scaffold wall-clock, PAF + FASTA text in, scaffold FASTA out -- for the
+C++ host program `telomeri_hip` (reference argv, reference defaults: 2000 trials per anchor, 60 backtracks) on a synthetic
+dataset of the given shape (reference surface: run.sh:27-47, Main.cpp:212-388).
+
+  python profiles/probes/scaffold_bench.py [config]          (default athaliana; run on the GPU box)
+
+bench.py imports run() for its `scaffold_wall_s` block.  The input text (for A. thaliana: 150 M PAF lines = 15 GB, reads
+FASTA 10 GB) is rendered by profiles/probes/synth_writer.c on all cores into /dev/shm (or $TLM_SCRATCH) and deleted
+afterwards; writing it is NOT part of the measured wall-clock, reading it is."""
+import ctypes as C
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
 
-from telomeri_amd import synth
-from load_bench import write_paf
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WRITER_SRC = os.path.join(HERE, "synth_writer.c")
+WRITER_LIB = os.path.join(HERE, "libsynth_writer.so")
 
 
-def main():
-    config = sys.argv[1] if len(sys.argv) > 1 else "ecoli"
+def build_writer() -> str:
+    if not os.path.exists(WRITER_LIB) or os.path.getmtime(WRITER_LIB) < os.path.getmtime(WRITER_SRC):
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", WRITER_LIB, WRITER_SRC], check=True)
+    return WRITER_LIB
+
+
+def _writer():
+    L = C.CDLL(build_writer())
+    L.synth_write_paf.restype = C.c_int64
+    L.synth_write_paf.argtypes = [C.c_char_p, C.c_uint64] + [C.c_void_p] * 10 + [C.c_int64, C.c_int]
+    L.synth_write_fasta.restype = C.c_int64
+    L.synth_write_fasta.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    return L
+
+
+def write_paf(ds, rec, path: str, threads: int = 16) -> int:
+    """Same text as telomeri_amd.synth.write_paf."""
+    cols = [np.ascontiguousarray(getattr(rec, c).cpu().numpy(), np.int32) for c in
+            ("q_id", "t_id", "q_len", "q_start", "q_end", "t_len", "t_start", "t_end", "matches", "strand")]
+    n = _writer().synth_write_paf(path.encode(), len(rec), *[c.ctypes.data for c in cols], ds.n_reads, threads)
+    if n < 0:
+        raise OSError("synth_write_paf(%s) failed" % path)
+    return int(n)
+
+
+def write_fasta(ds, reads_path: str, contigs_path: str, seed: int = 0) -> int:
+    """Same text as telomeri_amd.synth.write_fasta."""
+    rng = np.random.default_rng(seed + 977)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=ds.genome_len)]
+    genome = np.ascontiguousarray(genome)
+    L = _writer()
+    total = 0
+    for path, start, length, first in ((reads_path, ds.read_start, ds.read_len, 0),
+                                       (contigs_path, ds.contig_start, ds.contig_len, ds.n_reads)):
+        s = np.ascontiguousarray(start.cpu().numpy(), np.int64)
+        ln = np.ascontiguousarray(length.cpu().numpy(), np.int64)
+        n = L.synth_write_fasta(path.encode(), genome.ctypes.data, s.shape[0], s.ctypes.data, ln.ctypes.data, first, ds.n_reads)
+        if n < 0:
+            raise OSError("synth_write_fasta(%s) failed" % path)
+        total += int(n)
+    return total
+
+
+def scratch_dir(need_bytes: int) -> str:
+    for base in (os.environ.get("TLM_SCRATCH"), "/dev/shm", tempfile.gettempdir()):
+        if base and os.path.isdir(base):
+            try:
+                if shutil.disk_usage(base).free > need_bytes * 1.2:
+                    return tempfile.mkdtemp(prefix="tlm_scaffold_", dir=base)
+            except OSError:
+                pass
+    raise OSError("no scratch directory with %.0f GB free" % (need_bytes / 1e9))
+
+
+def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(), keep: bool = False) -> dict:
+    """Render `config` as text, run telomeri_hip on it, return the timing block.  `ds`: an already generated
+    telomeri_amd.synth.Dataset of that config (bench.py has one on the GPU)."""
+    from telomeri_amd import synth
     binary = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_hip")
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "telomeri_amd", "host")], check=True)
+    if not os.path.exists(binary):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "telomeri_amd", "host")], check=True)
     t0 = time.time()
-    ds = synth.make_config(config)
-    out = {"config": config, "records": len(ds.rr) + len(ds.cr), "reads": ds.n_reads, "contigs": ds.n_contigs}
-    with tempfile.TemporaryDirectory() as tmp:
-        rr, cr = os.path.join(tmp, "rr.paf"), os.path.join(tmp, "cr.paf")
-        reads, contigs, fasta = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "scaffold.fa")
-        write_paf(ds, ds.rr, rr)
-        write_paf(ds, ds.cr, cr)
-        synth.write_fasta(ds, reads, contigs)
-        out["input_bytes"] = sum(os.path.getsize(p) for p in (rr, cr, reads, contigs))
-        out["dataset_written_s"] = time.time() - t0
+    if ds is None:
+        ds = synth.make_config(config, device=device)
+    n_rec = len(ds.rr) + len(ds.cr)
+    est = n_rec * 110 + int(ds.read_len.sum().item()) + int(ds.contig_len.sum().item()) + 32 * ds.n_reads
+    tmp = scratch_dir(est)
+    out = {"config": config, "records": n_rec, "reads": ds.n_reads, "contigs": ds.n_contigs,
+           "program": "telomeri_amd/bin/telomeri_hip <rr.paf> <cr.paf> <reads.fasta> <contigs.fasta> <out.fasta> (reference "
+                      "argv and defaults; lean graph + packed paths)"}
+    try:
+        rr, cr = os.path.join(tmp, "rr_overlaps.paf"), os.path.join(tmp, "cr_overlaps.paf")
+        reads, contigs, fasta = os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "contigs.fasta"), os.path.join(tmp, "HERA_result.fasta")
+        nb = write_paf(ds, ds.rr, rr) + write_paf(ds, ds.cr, cr)
+        nb += write_fasta(ds, reads, contigs)
+        out["input_bytes"] = nb
+        out["input_written_s"] = round(time.time() - t0, 2)
         t0 = time.time()
-        res = subprocess.run([binary, rr, cr, reads, contigs, fasta], capture_output=True, text=True, env=dict(os.environ, TLM_HOST_TIMING="1"))
-        out["host_timing"] = [ln for ln in res.stderr.splitlines() if ln.startswith("[host timing]")]
-        out["wall_s"] = time.time() - t0
+        res = subprocess.run([binary] + list(extra_args) + [rr, cr, reads, contigs, fasta], capture_output=True, text=True,
+                             env=dict(os.environ, TLM_HOST_TIMING="1"))
+        out["scaffold_wall_s"] = round(time.time() - t0, 3)
         out["exit"] = res.returncode
         done = [float(x) for x in re.findall(r"Done \(([0-9.e+-]+)s\)", res.stdout)]
-        if len(done) >= 2:
-            out["load_s"], out["paths_s"] = done[0], done[1]
+        names = ["load_s", "path_build_s", "consensus_s", "fasta_load_s", "scaffold_write_s"]
+        out["stages_s"] = {k: v for k, v in zip(names, done)}
         m = re.search(r"load breakdown: tokenise\+intern ([0-9.e+-]+) ms \((\w+)\), device graph build ([0-9.e+-]+) ms, "
                       r"download\+materialise ([0-9.e+-]+) ms", res.stdout)
         if m:
-            out["load_breakdown_ms"] = {"tokenise": float(m.group(1)), "device_build": float(m.group(3)),
+            out["load_breakdown_ms"] = {"tokenise": float(m.group(1)), "tokeniser": m.group(2), "device_graph_build": float(m.group(3)),
                                         "download_materialise": float(m.group(4))}
         m = re.search(r"edge-extension evals: (\d+) in ([0-9.e+-]+) ms of walk kernels", res.stdout)
         if m:
             out["evals"], out["walk_kernel_ms"] = int(m.group(1)), float(m.group(2))
-        m = re.search(r"Host stages after the path build: ([0-9.e+-]+)s", res.stdout)
+        m = re.search(r"- total_num: (\d+)", res.stdout)
         if m:
-            out["post_stages_s"] = float(m.group(1))
+            out["paths"] = int(m.group(1))
         if res.returncode == 0:
             out["scaffold_bytes"] = os.path.getsize(fasta)
             chain = [ln for ln in res.stdout.splitlines() if ln.startswith("ctg") and "-" in ln]
             out["scaffold_nodes"] = chain[-1].count("-") + 1 if chain else 0
         else:
-            out["stderr_tail"] = res.stderr[-300:]
-    print(json.dumps(out))
+            out["stderr_tail"] = res.stderr[-400:]
+        if keep:
+            out["dir"] = tmp
+    finally:
+        if not keep:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(sys.argv[1] if len(sys.argv) > 1 else "athaliana")))
