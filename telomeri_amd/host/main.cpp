@@ -14,6 +14,7 @@
 #include <string>
 
 #include "telomeri_host.hpp"
+#include "../../include/telomeri_hip.h"
 
 int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vector<const Path *>> &paths_between_anchors,
                     const char *reads_file, const char *contigs_file, const char *output_file);
@@ -166,6 +167,8 @@ int main(int argc, char **argv) {
             }
         }
     }
+    pm.gather();                    // multi-GPU jobs: the one exchange (nothing happens in a one-process job)
+    if (tlm_dist_rank(OverlapGraph::context()) != 0) return 0;     // every rank holds all paths now; rank 0 finishes the job
     pm.filterUnique();                                                                // Main.cpp:247
     auto pba = pm.getPathsBetweenAnchors();                                           // Main.cpp:251-252
     if (out) {

@@ -75,11 +75,52 @@ struct Reader {
 
 }   // namespace
 
+// One process per GPU.  A multi-GPU job is N copies of this program started with
+//   TLM_WORLD=N TLM_RANK=r (or torchrun's WORLD_SIZE / RANK / LOCAL_RANK) and TLM_RENDEZVOUS=<path on a shared
+//   filesystem>: rank 0 writes the 128-byte RCCL id there, the others wait for the file.
+// Device: TLM_DEVICE, else LOCAL_RANK, else the rank, else 0.
+static int env_int(const char *a, const char *b, int dflt) {
+    const char *v = std::getenv(a);
+    if (!v && b) v = std::getenv(b);
+    return v ? std::atoi(v) : dflt;
+}
+
 tlm_ctx *OverlapGraph::context() {
     static tlm_ctx *ctx = nullptr;
-    if (!ctx) {
-        const char *d = std::getenv("TLM_DEVICE");
-        if (tlm_ctx_create(d ? std::atoi(d) : 0, &ctx) != TLM_OK) die("no usable gfx950 device (there is no CPU fallback)");
+    if (ctx) return ctx;
+    const int world = env_int("TLM_WORLD", "WORLD_SIZE", 1), rank = env_int("TLM_RANK", "RANK", 0);
+    const int device = env_int("TLM_DEVICE", "LOCAL_RANK", world > 1 ? rank : 0);
+    if (tlm_ctx_create(device, &ctx) != TLM_OK) die("no usable gfx950 device (there is no CPU fallback)");
+    if (world > 1) {
+        const char *rv = std::getenv("TLM_RENDEZVOUS");
+        if (!rv) {
+            std::cerr << "telomeri_hip: TLM_WORLD=" << world << " needs TLM_RENDEZVOUS=<file shared by the ranks>" << std::endl;
+            std::exit(1);
+        }
+        uint8_t id[TLM_UNIQUE_ID_BYTES];
+        if (rank == 0) {
+            if (tlm_dist_unique_id(id) != TLM_OK) die("tlm_dist_unique_id");
+            const std::string tmp = std::string(rv) + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 || std::rename(tmp.c_str(), rv) != 0) {
+                std::perror(rv);
+                std::exit(1);
+            }
+        } else {
+            size_t got = 0;
+            for (int tries = 0; tries < 6000 && got != sizeof(id); tries++) {       // up to 10 minutes
+                if (FILE *f = std::fopen(rv, "rb")) {
+                    got = std::fread(id, 1, sizeof(id), f);
+                    std::fclose(f);
+                }
+                if (got != sizeof(id)) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            if (got != sizeof(id)) {
+                std::cerr << "telomeri_hip: rank " << rank << " found no RCCL id at " << rv << std::endl;
+                std::exit(1);
+            }
+        }
+        if (tlm_dist_init(ctx, rank, world, id) != TLM_OK) die("tlm_dist_init");
     }
     return ctx;
 }

@@ -41,6 +41,29 @@ std::ostream &operator<<(std::ostream &s, const Path &p) {      // "*n3-n17-..."
 
 // ---- PathManager ----------------------------------------------------------------------------------
 
+static void die_tlm(const char *what) {
+    std::cerr << "telomeri_hip: " << what << " failed: " << tlm_last_error() << std::endl;
+    std::exit(1);
+}
+
+// The one exchange of a multi-GPU job (no-op in a one-process job): every rank's builder sets -> paths_ of the whole
+// job on every rank, in the reference's order (tlm_pathset_allgather).  Call after the builders, before filterUnique.
+void PathManager::gather() {
+    tlm_ctx *ctx = OverlapGraph::context();
+    if (tlm_dist_world(ctx) <= 1 || dev_sets_.empty()) return;
+    tlm_pathset *all = nullptr;
+    tlm_exchange_info xi{};
+    if (tlm_pathset_allgather(ctx, (int) dev_sets_.size(), dev_sets_.data(), &all, &xi) != TLM_OK) die_tlm("allgather");
+    for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
+    dev_sets_.assign(1, all);
+    paths_.clear();
+    edge_pool_.clear();
+    append_from(*graph_, all);
+    if (!packed_) materialiseAll();
+    std::cout << "Gathered " << paths_.size() << " paths from " << tlm_dist_world(ctx) << " ranks (" << xi.bytes_sent
+              << " bytes sent, " << xi.device_ms << " ms)." << std::endl;
+}
+
 void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, bool mc) {
     tlm_ctx *ctx = OverlapGraph::context();
     tlm_graph *dg = g.device_graph();
@@ -52,8 +75,25 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
     tlm_walk_params wp{params_.rebuild_attempts, params_.backtrack_attempts, params_.len_threshold};
     tlm_pathset *ps = nullptr;
     tlm_counters c{};
-    const int rc = mc ? tlm_walk_mc(ctx, dg, m, &wp, 0, tlm_mc_units(dg, &wp), &ps, &c)
-                      : tlm_walk_det(ctx, dg, m, 0, tlm_det_units(dg), &ps, &c);
+    // this rank's share of the units: the anchors of its bundle (all of them in a one-process job)
+    uint64_t u0 = 0, u1 = mc ? tlm_mc_units(dg, &wp) : tlm_det_units(dg);
+    if (tlm_dist_world(ctx) > 1) {
+        uint32_t a0 = 0, a1 = 0;
+        if (tlm_dist_anchor_range(dg, tlm_dist_rank(ctx), tlm_dist_world(ctx), &a0, &a1) != TLM_OK) die_tlm("anchor range");
+        if (mc) {
+            u0 = (uint64_t) a0 * (uint64_t) std::max(params_.rebuild_attempts, 0);
+            u1 = (uint64_t) a1 * (uint64_t) std::max(params_.rebuild_attempts, 0);
+        } else {
+            std::vector<uint64_t> det_off((size_t) g.nodes_.size() + 2);
+            tlm_graph_info gi;
+            tlm_graph_get_info(dg, &gi);
+            det_off.resize((size_t) gi.n_anchors + 1);
+            if (tlm_graph_anchor_table(dg, nullptr, det_off.data()) != TLM_OK) die_tlm("anchor table");
+            u0 = det_off[a0];
+            u1 = det_off[a1];
+        }
+    }
+    const int rc = mc ? tlm_walk_mc(ctx, dg, m, &wp, u0, u1, &ps, &c) : tlm_walk_det(ctx, dg, m, u0, u1, &ps, &c);
     if (rc != TLM_OK) {
         std::cerr << "telomeri_hip: walk failed: " << tlm_last_error() << std::endl;
         std::exit(1);
@@ -70,11 +110,6 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
 
 PathManager::~PathManager() {
     for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
-}
-
-static void die_tlm(const char *what) {
-    std::cerr << "telomeri_hip: " << what << " failed: " << tlm_last_error() << std::endl;
-    std::exit(1);
 }
 
 void PathManager::append_from(const OverlapGraph &g, tlm_pathset *ps) {

@@ -210,6 +210,9 @@ public:
     void buildMonteCarlo(const OverlapGraph &g, const Utils::Metrics &metric);
     /** PathManager.cpp:179-386 on the device. */
     void buildDeterministic(const OverlapGraph &g, const Utils::Metrics &metric);
+    /** Not in the reference: the single exchange of a one-process-per-GPU job (every rank's paths -> every rank, in the
+     *  order one PathManager would hold them); a no-op without TLM_WORLD > 1.  Between the builders and filterUnique. */
+    void gather();
     void filterUnique();                // PathManager.cpp:432-438
     std::tuple<ulong, ulong, ulong> getMinMaxSumPathLength();   // PathManager.cpp:467-502
     std::string stats();                // PathManager.cpp:440-465

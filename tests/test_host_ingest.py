@@ -216,3 +216,23 @@ def test_test_load_num(binary):
         assert "parsed 4 records" in res.stdout and "(sequential)" in res.stdout     # OverlapGraph.cpp:145: breaks after 3 < ctr
         g = po.Graph()
         assert g.load_paf(p, False, po.FilterParams.default(), test_load_num=3) and g.records == [4]
+
+
+def test_run_sh_contract(tmp_path):
+    """reference run.sh:14-47: usage text without an argument; overlap files are reused when at least one exists; the
+    program gets <dir>/rr_overlaps.paf, cr_overlaps.paf, reads.fast?, contigs.fast?, HERA_result.fasta."""
+    import subprocess
+    run = os.path.join(ROOT, "run.sh")
+    res = subprocess.run(["bash", run], capture_output=True, text=True)
+    assert res.returncode == 1 and "Please provide the dataset directory path!" in res.stdout
+    assert "Usage: ./run.sh <dataset-dir>" in res.stdout
+    d = tmp_path / "ds"
+    d.mkdir()
+    res = subprocess.run(["bash", run, str(d)], capture_output=True, text=True)
+    assert res.returncode == 1 and "no ./minimap2/minimap2" in res.stderr          # both PAFs missing: would be built
+    (d / "rr_overlaps.paf").write_text("")
+    (d / "reads.fasta").write_text(">r\nA\n")
+    (d / "contigs.fastq").write_text("@c\nA\n+\nI\n")
+    res = subprocess.run(["bash", run, str(d)], capture_output=True, text=True)
+    assert "Using existing overlap files!" in res.stdout                           # one of the two exists: reused as is
+    assert res.returncode == 1 and "Cannot open file: %s" % (d / "cr_overlaps.paf") in res.stderr
