@@ -7,11 +7,13 @@
 #include "telomeri_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <thread>
 #include <unordered_map>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -127,9 +129,6 @@ tlm_ctx *OverlapGraph::context() {
 
 OverlapGraph::OverlapGraph() = default;
 
-OverlapGraph::~OverlapGraph() {
-    if (dev_) tlm_graph_destroy(dev_);
-}
 
 // ---- PAF ingestion ---------------------------------------------------------
 // The reference reads the file as ONE token stream with operator>> (OverlapGraph.cpp:109-127): 12 typed tokens,
@@ -143,54 +142,82 @@ OverlapGraph::~OverlapGraph() {
 //     reader below, which reproduces operator>> exactly, including where the reference silently stops.
 namespace {
 
-struct Chunk {
-    std::vector<int32_t> q_loc, t_loc, q_len, q_start, q_end, t_len, t_start, t_end, matches;
-    std::vector<uint8_t> strand;
+struct Chunk {       // one thread's byte range of a file
+    const char *begin = nullptr, *end = nullptr;
+    size_t lines = 0;                // non-blank lines = records of a clean range (pass 1)
+    size_t base = 0;                 // first record of the range in the file's columns
+    size_t records = 0;              // records written (pass 2)
     std::vector<std::pair<const char *, uint32_t>> names;      // local name table, first-seen order
+    std::vector<uint64_t> name_hash;                            // FNV-1a of each local name
     bool clean = true;
 };
 
 struct NameHash {
-    // open addressing over (ptr, len) keys; values are local ids
-    std::vector<int32_t> slot;
-    std::vector<uint64_t> hash;
-    const std::vector<std::pair<const char *, uint32_t>> *names = nullptr;
-    size_t mask = 0, used = 0;
     static uint64_t fnv(const char *s, size_t n) {
         uint64_t h = 1469598103934665603ull;
         for (size_t i = 0; i < n; i++) { h ^= (unsigned char) s[i]; h *= 1099511628211ull; }
         return h;
     }
+    // open addressing; an entry carries the first 16 bytes of its name, so a lookup touches one cache line and the text
+    // of the file only for longer names
+    struct Entry {
+        uint64_t hash;
+        int32_t id;         // -1 = empty
+        uint32_t len;
+        char head[16];
+    };
+    std::vector<Entry> tab;
+    const std::vector<std::pair<const char *, uint32_t>> *names = nullptr;
+    size_t mask = 0, used = 0;
     void init(const std::vector<std::pair<const char *, uint32_t>> *nm, size_t cap = 1 << 12) {
-        names = nm; slot.assign(cap, -1); hash.assign(cap, 0); mask = cap - 1; used = 0;
+        names = nm;
+        tab.assign(cap, Entry{0, -1, 0, {0}});
+        mask = cap - 1;
+        used = 0;
     }
     void grow() {
-        std::vector<int32_t> os; std::vector<uint64_t> oh;
-        os.swap(slot); oh.swap(hash);
-        slot.assign(os.size() * 2, -1); hash.assign(os.size() * 2, 0); mask = slot.size() - 1;
-        for (size_t i = 0; i < os.size(); i++)
-            if (os[i] >= 0) {
-                size_t j = oh[i] & mask;
-                while (slot[j] >= 0) j = (j + 1) & mask;
-                slot[j] = os[i]; hash[j] = oh[i];
+        std::vector<Entry> old;
+        old.swap(tab);
+        tab.assign(old.size() * 2, Entry{0, -1, 0, {0}});
+        mask = tab.size() - 1;
+        for (const Entry &e : old)
+            if (e.id >= 0) {
+                size_t j = e.hash & mask;
+                while (tab[j].id >= 0) j = (j + 1) & mask;
+                tab[j] = e;
             }
     }
     // returns the id of (s, n); *fresh = true if it was not present (the caller appends it to `names` first)
-    int32_t find_or_add(const char *s, size_t n, int32_t next_id, bool *fresh) {
+    int32_t find_or_add(const char *s, size_t n, int32_t next_id, bool *fresh, uint64_t *hash_out) {
         const uint64_t h = fnv(s, n);
+        *hash_out = h;
         size_t j = h & mask;
-        while (slot[j] >= 0) {
-            const auto &nm = (*names)[(size_t) slot[j]];
-            if (hash[j] == h && nm.second == n && std::memcmp(nm.first, s, n) == 0) { *fresh = false; return slot[j]; }
+        const size_t hn = n < 16 ? n : 16;
+        while (tab[j].id >= 0) {
+            const Entry &e = tab[j];
+            if (e.hash == h && e.len == n && std::memcmp(e.head, s, hn) == 0
+                && (n <= 16 || std::memcmp((*names)[(size_t) e.id].first + 16, s + 16, n - 16) == 0)) {
+                *fresh = false;
+                return e.id;
+            }
             j = (j + 1) & mask;
         }
-        slot[j] = next_id; hash[j] = h; *fresh = true;
-        if (++used * 2 > slot.size()) grow();
+        Entry &e = tab[j];
+        e.hash = h;
+        e.id = next_id;
+        e.len = (uint32_t) n;
+        std::memcpy(e.head, s, hn);
+        *fresh = true;
+        if (++used * 2 > tab.size()) grow();
         return next_id;
     }
 };
 
-inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+// whitespace inside a line, as operator>> sees it (the newline is handled by the line loop): every such character is
+// <= ' ', so one compare settles the common case
+inline bool is_ws(char c) {
+    return (unsigned char) c <= ' ' && (c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f');
+}
 
 // strict integer: the whole token must be [+-]digits and fit an int
 inline bool strict_int(const char *s, const char *e, int32_t &v) {
@@ -209,11 +236,35 @@ inline bool strict_int(const char *s, const char *e, int32_t &v) {
     return true;
 }
 
-void parse_range(const char *p, const char *end, Chunk &c) {
+// pass 1: lines with at least one token
+size_t count_records(const char *p, const char *end) {
+    size_t n = 0;
+    while (p < end) {
+        const char *eol = (const char *) std::memchr(p, '\n', (size_t) (end - p));
+        if (!eol) eol = end;
+        while (p < eol && is_ws(*p)) p++;
+        n += p < eol;
+        p = eol + 1;
+    }
+    return n;
+}
+
+struct Columns {            // where a range writes its records (the file's columns, from the range's base on)
+    int32_t *q_loc, *t_loc, *q_len, *q_start, *q_end, *t_len, *t_start, *t_end, *matches;
+    uint8_t *strand;
+};
+
+// pass 2: record i of the range goes to out.*[i]; q_loc / t_loc hold LOCAL name ids until the merge
+void parse_range(Chunk &c, const Columns &out) {
     NameHash nh;
     nh.init(&c.names);
+    const char *p = c.begin, *end = c.end;
     const char *tok[16];
     const char *tend[16];
+    size_t r = 0;
+    const char *last_q = nullptr;       // files come grouped by query: the previous record's name is the usual hit
+    size_t last_q_n = 0;
+    int32_t last_q_id = -1;
     while (p < end) {
         const char *eol = (const char *) std::memchr(p, '\n', (size_t) (end - p));
         if (!eol) eol = end;
@@ -231,23 +282,186 @@ void parse_range(const char *p, const char *end, Chunk &c) {
         if (nt == 0) continue;                       // blank line: no tokens, the stream just moves on
         int32_t v[9];
         static const int num_idx[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
-        bool ok = nt == 16 && tend[4] - tok[4] == 1;
+        bool ok = nt == 16 && tend[4] - tok[4] == 1 && r < c.lines;
         for (int k = 0; ok && k < 9; k++) ok = strict_int(tok[num_idx[k]], tend[num_idx[k]], v[k]);
         if (!ok) { c.clean = false; return; }
         bool fresh;
-        int32_t qi = nh.find_or_add(tok[0], (size_t) (tend[0] - tok[0]), (int32_t) c.names.size(), &fresh);
-        if (fresh) c.names.emplace_back(tok[0], (uint32_t) (tend[0] - tok[0]));
-        int32_t ti = nh.find_or_add(tok[5], (size_t) (tend[5] - tok[5]), (int32_t) c.names.size(), &fresh);
-        if (fresh) c.names.emplace_back(tok[5], (uint32_t) (tend[5] - tok[5]));
-        c.q_loc.push_back(qi); c.t_loc.push_back(ti);
-        c.q_len.push_back(v[0]); c.q_start.push_back(v[1]); c.q_end.push_back(v[2]);
-        c.t_len.push_back(v[3]); c.t_start.push_back(v[4]); c.t_end.push_back(v[5]);
-        c.matches.push_back(v[6]);
-        c.strand.push_back(*tok[4] == '-');
+        uint64_t h;
+        const size_t qn = (size_t) (tend[0] - tok[0]);
+        int32_t qi;
+        if (last_q && qn == last_q_n && std::memcmp(last_q, tok[0], qn) == 0) {
+            qi = last_q_id;
+        } else {
+            qi = nh.find_or_add(tok[0], qn, (int32_t) c.names.size(), &fresh, &h);
+            if (fresh) { c.names.emplace_back(tok[0], (uint32_t) qn); c.name_hash.push_back(h); }
+            last_q = tok[0];
+            last_q_n = qn;
+            last_q_id = qi;
+        }
+        int32_t ti = nh.find_or_add(tok[5], (size_t) (tend[5] - tok[5]), (int32_t) c.names.size(), &fresh, &h);
+        if (fresh) { c.names.emplace_back(tok[5], (uint32_t) (tend[5] - tok[5])); c.name_hash.push_back(h); }
+        out.q_loc[r] = qi; out.t_loc[r] = ti;
+        out.q_len[r] = v[0]; out.q_start[r] = v[1]; out.q_end[r] = v[2];
+        out.t_len[r] = v[3]; out.t_start[r] = v[4]; out.t_end[r] = v[5];
+        out.matches[r] = v[6];
+        out.strand[r] = *tok[4] == '-';
+        r++;
     }
+    c.records = r;
+}
+
+unsigned host_threads() {
+    unsigned nt = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = std::min<unsigned>(nt ? nt : 1, (unsigned) CPU_COUNT(&set));
+    return std::max(1u, std::min(nt, 64u));
 }
 
 }   // namespace
+
+// The name table of a graph (all its files), sharded by hash so that the per-thread name tables of a parsed file are
+// merged by all cores: shard s owns the names with hash % SHARDS == s.  Ids are FIRST-SEEN order over the files (query
+// before target inside a record), exactly what one sequential reader assigns, whatever the number of threads.
+struct OverlapGraph::NameIndex {
+    static constexpr unsigned SHARDS = 64;
+    struct Pending {            // a name first seen in the file being merged
+        const char *p;
+        uint32_t n;
+        uint64_t first;         // (chunk << 32) | local index: where the file mentions it first
+        int32_t id;             // global id, assigned once all shards are through
+    };
+    struct Shard {
+        std::vector<uint64_t> hash;
+        std::vector<int32_t> id;            // -1 empty, >= 0 global id, <= -2 pending number -(id + 2)
+        size_t used = 0;
+        std::vector<Pending> pending;
+        Shard() : hash(1024, 0), id(1024, -1) {}
+        void grow() {
+            std::vector<uint64_t> oh;
+            std::vector<int32_t> oi;
+            oh.swap(hash);
+            oi.swap(id);
+            hash.assign(oh.size() * 2, 0);
+            id.assign(oi.size() * 2, -1);
+            const size_t mask = id.size() - 1;
+            for (size_t i = 0; i < oi.size(); i++)
+                if (oi[i] != -1) {
+                    size_t j = (oh[i] / SHARDS) & mask;
+                    while (id[j] != -1) j = (j + 1) & mask;
+                    id[j] = oi[i];
+                    hash[j] = oh[i];
+                }
+        }
+        // slot of (s, n) -- or of the empty slot where it belongs
+        size_t probe(const char *s, size_t n, uint64_t h, const std::vector<std::string> &names) const {
+            const size_t mask = id.size() - 1;
+            size_t j = (h / SHARDS) & mask;
+            for (; id[j] != -1; j = (j + 1) & mask) {
+                if (hash[j] != h) continue;
+                if (id[j] >= 0) {
+                    const std::string &nm = names[(size_t) id[j]];
+                    if (nm.size() == n && std::memcmp(nm.data(), s, n) == 0) return j;
+                } else {
+                    const Pending &pd = pending[(size_t) (-(id[j] + 2))];
+                    if (pd.n == n && std::memcmp(pd.p, s, n) == 0) return j;
+                }
+            }
+            return j;
+        }
+    };
+    Shard shards[SHARDS];
+
+    // one name at a time (the sequential token-stream reader)
+    int32_t intern(const char *s, size_t n, std::vector<std::string> &names) {
+        const uint64_t h = NameHash::fnv(s, n);
+        Shard &sh = shards[h % SHARDS];
+        const size_t j = sh.probe(s, n, h, names);
+        if (sh.id[j] >= 0) return sh.id[j];
+        const int32_t gid = (int32_t) names.size();
+        names.emplace_back(s, n);
+        sh.id[j] = gid;
+        sh.hash[j] = h;
+        if (++sh.used * 2 > sh.id.size()) sh.grow();
+        return gid;
+    }
+
+    // the local name tables of one file's chunks -> global ids (glob[t][i] for local name i of chunk t)
+    void merge(const std::vector<Chunk> &chunks, std::vector<std::string> &names, std::vector<std::vector<int32_t>> &glob,
+               unsigned threads) {
+        glob.resize(chunks.size());
+        for (size_t t = 0; t < chunks.size(); t++) glob[t].assign(chunks[t].names.size(), -1);
+        // 1. every shard looks at the names that are its own, in file order
+        std::atomic<unsigned> next{0};
+        auto work = [&] {
+            for (unsigned s = next++; s < SHARDS; s = next++) {
+                Shard &sh = shards[s];
+                for (size_t t = 0; t < chunks.size(); t++) {
+                    const Chunk &c = chunks[t];
+                    for (size_t i = 0; i < c.names.size(); i++) {
+                        const uint64_t h = c.name_hash[i];
+                        if (h % SHARDS != s) continue;
+                        const size_t j = sh.probe(c.names[i].first, c.names[i].second, h, names);
+                        if (sh.id[j] == -1) {
+                            sh.pending.push_back(Pending{c.names[i].first, c.names[i].second, ((uint64_t) t << 32) | i, -1});
+                            const int32_t provisional = -(int32_t) sh.pending.size() - 1;     // pending number k -> -(k + 2)
+                            sh.id[j] = provisional;
+                            sh.hash[j] = h;
+                            if (++sh.used * 2 > sh.id.size()) sh.grow();
+                            glob[t][i] = provisional;
+                        } else {
+                            glob[t][i] = sh.id[j];
+                        }
+                    }
+                }
+            }
+        };
+        run_threads(threads, work);
+        // 2. new names in the order the file mentions them first
+        std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> fresh;
+        for (unsigned s = 0; s < SHARDS; s++)
+            for (size_t k = 0; k < shards[s].pending.size(); k++) fresh.push_back({shards[s].pending[k].first, {s, (uint32_t) k}});
+        std::sort(fresh.begin(), fresh.end());
+        const size_t base = names.size();
+        names.resize(base + fresh.size());
+        for (size_t r = 0; r < fresh.size(); r++) shards[fresh[r].second.first].pending[fresh[r].second.second].id = (int32_t) (base + r);
+        // 3. names_ entries, table slots and the chunks' maps get the final ids
+        next = 0;
+        auto finish = [&] {
+            for (unsigned s = next++; s < SHARDS; s = next++) {
+                Shard &sh = shards[s];
+                for (const Pending &pd : sh.pending) names[(size_t) pd.id].assign(pd.p, pd.n);
+                for (size_t j = 0; j < sh.id.size(); j++)
+                    if (sh.id[j] <= -2) sh.id[j] = sh.pending[(size_t) (-(sh.id[j] + 2))].id;
+            }
+        };
+        run_threads(threads, finish);
+        next = 0;
+        auto remap = [&] {
+            for (unsigned t = next++; t < chunks.size(); t = next++) {
+                const Chunk &c = chunks[t];
+                for (size_t i = 0; i < glob[t].size(); i++)
+                    if (glob[t][i] <= -2) glob[t][i] = shards[c.name_hash[i] % SHARDS].pending[(size_t) (-(glob[t][i] + 2))].id;
+            }
+        };
+        run_threads(threads, remap);
+        for (Shard &sh : shards) {
+            sh.pending.clear();
+            sh.pending.shrink_to_fit();
+        }
+    }
+
+    template <class F> static void run_threads(unsigned n, F &f) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < n; t++) th.emplace_back([&f] { f(); });
+        f();
+        for (auto &x : th) x.join();
+    }
+};
+
+OverlapGraph::~OverlapGraph() {
+    if (dev_) tlm_graph_destroy(dev_);
+    delete index_;
+}
 
 bool OverlapGraph::load(char *filepath, bool anchors) {
     ulong ctr = 0;
@@ -320,8 +534,8 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
 
     // ---- parallel line-wise parse of clean input
     if (test_load_num_ == 0 && size) {
-        unsigned nt = std::thread::hardware_concurrency();
-        nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(nt ? nt : 1, 64u), size / (1 << 20) + 1));
+        unsigned nt = host_threads();
+        nt = (unsigned) std::max<size_t>(1, std::min<size_t>(nt, size / (1 << 20) + 1));
         if (const char *e = std::getenv("TLM_PARSE_THREADS")) nt = (unsigned) std::min(64, std::max(1, std::atoi(e)));
         std::vector<const char *> cut(nt + 1);
         cut[0] = data;
@@ -333,54 +547,61 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
         }
         std::vector<Chunk> chunks(nt);
         std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { parse_range(cut[t], cut[t + 1], chunks[t]); });
+        // pass 1: records per range -> every range knows where it writes
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                chunks[t].begin = cut[t];
+                chunks[t].end = cut[t + 1];
+                chunks[t].lines = count_records(cut[t], cut[t + 1]);
+            });
         for (auto &x : th) x.join();
+        th.clear();
+        size_t total = 0;
+        for (Chunk &c : chunks) { c.base = total; total += c.lines; }
+        for (auto *col : {&f.q_id, &f.t_id, &f.q_len, &f.q_start, &f.q_end, &f.t_len, &f.t_start, &f.t_end, &f.matches})
+            col->resize_uninitialised(total);
+        f.strand.resize_uninitialised(total);
+        // pass 2: parse straight into the file's columns
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                const size_t b = chunks[t].base;
+                parse_range(chunks[t], Columns{f.q_id.data() + b, f.t_id.data() + b, f.q_len.data() + b, f.q_start.data() + b,
+                                                f.q_end.data() + b, f.t_len.data() + b, f.t_start.data() + b, f.t_end.data() + b,
+                                                f.matches.data() + b, f.strand.data() + b});
+            });
+        for (auto &x : th) x.join();
+        th.clear();
+        const auto t_parsed = std::chrono::steady_clock::now();
         bool clean = true;
-        for (const Chunk &c : chunks) clean &= c.clean;
+        for (const Chunk &c : chunks) clean &= c.clean && c.records == c.lines;
         if (clean) {
-            // merge: global name ids in file order (any injective numbering would do for the device; first-seen
-            // order keeps names_ deterministic), then append the columns
-            size_t total = 0;
-            std::vector<size_t> base(nt + 1, 0);
-            for (unsigned t = 0; t < nt; t++) { total += chunks[t].q_loc.size(); base[t + 1] = total; }
-            // name tables: sequential (they are small), file order
-            std::vector<std::vector<int32_t>> glob(nt);
-            for (unsigned t = 0; t < nt; t++) {
-                const Chunk &c = chunks[t];
-                glob[t].resize(c.names.size());
-                for (size_t i = 0; i < c.names.size(); i++) {
-                    std::string key(c.names[i].first, c.names[i].second);
-                    auto it = name_id_.find(key);
-                    if (it == name_id_.end()) {
-                        it = name_id_.emplace(key, (int32_t) names_.size()).first;
-                        names_.push_back(std::move(key));
-                    }
-                    glob[t][i] = it->second;
-                }
-            }
-            // columns: every thread copies its chunk to its place
-            for (auto *col : {&f.q_id, &f.t_id, &f.q_len, &f.q_start, &f.q_end, &f.t_len, &f.t_start, &f.t_end, &f.matches})
-                col->resize(total);
-            f.strand.resize(total);
-            std::vector<std::thread> cp;
+            // name tables: merged by all cores (NameIndex), ids in first-seen order; then local -> global ids in place
+            std::vector<std::vector<int32_t>> glob;
+            if (!index_) index_ = new NameIndex();
+            index_->merge(chunks, names_, glob, nt);
+            const auto t_merged = std::chrono::steady_clock::now();
             for (unsigned t = 0; t < nt; t++)
-                cp.emplace_back([&, t] {
+                th.emplace_back([&, t] {
                     const Chunk &c = chunks[t];
-                    const size_t b = base[t], n = c.q_loc.size();
-                    for (size_t i = 0; i < n; i++) {
-                        f.q_id[b + i] = glob[t][(size_t) c.q_loc[i]];
-                        f.t_id[b + i] = glob[t][(size_t) c.t_loc[i]];
+                    int32_t *q = f.q_id.data() + c.base, *tt = f.t_id.data() + c.base;
+                    for (size_t i = 0; i < c.records; i++) {
+                        q[i] = glob[t][(size_t) q[i]];
+                        tt[i] = glob[t][(size_t) tt[i]];
                     }
-                    auto put = [&](std::vector<int32_t> &d, const std::vector<int32_t> &src) {
-                        if (n) std::memcpy(d.data() + b, src.data(), n * 4);
-                    };
-                    put(f.q_len, c.q_len); put(f.q_start, c.q_start); put(f.q_end, c.q_end);
-                    put(f.t_len, c.t_len); put(f.t_start, c.t_start); put(f.t_end, c.t_end); put(f.matches, c.matches);
-                    if (n) std::memcpy(f.strand.data() + b, c.strand.data(), n);
                 });
-            for (auto &x : cp) x.join();
+            for (auto &x : th) x.join();
             ctr = total;
             parsed = true;
+            if (getenv("TLM_HOST_TIMING")) {
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                std::cerr << "[host timing] tokenise " << filepath << ": " << nt << " threads, count + parse " << ms(t_begin, t_parsed)
+                          << " ms, name merge " << ms(t_parsed, t_merged) << " ms, id remap "
+                          << ms(t_merged, std::chrono::steady_clock::now()) << " ms" << std::endl;
+            }
+        } else {
+            for (auto *col : {&f.q_id, &f.t_id, &f.q_len, &f.q_start, &f.q_end, &f.t_len, &f.t_start, &f.t_end, &f.matches})
+                col->resize_uninitialised(0);
+            f.strand.resize_uninitialised(0);
         }
     }
 
@@ -398,15 +619,8 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
                 break;
             for (int k = 0; k < 4; k++) r.token(dummy, dn);                  // :124-127: exactly 4 more tokens
             ++ctr;
-            auto intern = [&](const char *s, size_t n) -> int32_t {
-                std::string key(s, n);
-                auto it = name_id_.find(key);
-                if (it != name_id_.end()) return it->second;
-                const int32_t id = (int32_t) names_.size();
-                names_.push_back(key);
-                name_id_.emplace(std::move(key), id);
-                return id;
-            };
+            if (!index_) index_ = new NameIndex();
+            auto intern = [&](const char *s, size_t n) -> int32_t { return index_->intern(s, n, names_); };
             f.q_id.push_back(intern(qn, qn_n));
             f.t_id.push_back(intern(tn, tn_n));
             f.q_len.push_back(q_len); f.q_start.push_back(q_start); f.q_end.push_back(q_end);

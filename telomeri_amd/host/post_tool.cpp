@@ -37,6 +37,19 @@ int main(int argc, char **argv) {
             gp.ratio_threshold = std::strtof(argv[++i], nullptr);
         } else pos.push_back(argv[i]);
     }
+    if (!pos.empty() && std::string(pos[0]) == "--list-sequences") {      // Scaffolder::load alone: what it makes of the files
+        Path none;
+        Scaffolder sc(none);
+        for (size_t i = 1; i < pos.size(); i++)
+            if (!sc.load(pos[i])) return 1;
+        std::printf("names %zu sequences %zu\n", sc.names_.size(), sc.sequences_.size());
+        for (size_t i = 0; i < sc.names_.size(); i++) {
+            std::printf("%zu\t[%s]", i, sc.names_[i].c_str());
+            if (i < sc.sequences_.size()) std::printf("\t[%s]", sc.sequences_[i].c_str());
+            std::printf("\n");
+        }
+        return 0;
+    }
     if (pos.size() != 4) {
         std::cerr << "usage: telomeri_post [--len-thr N --w-size N --r-thr F] <dump> <reads.fa> <contigs.fa> <out.fa>" << std::endl;
         return 2;

@@ -3,38 +3,115 @@
 // its first character, inclusive substring ends, '-' strand complemented but not reversed, the whole sequence
 // reversed at the end, the node-name chain printed on stdout.
 #include <algorithm>
+#include <cctype>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "telomeri_host.hpp"
 
-bool Scaffolder::load(const char *filename) {           // Scaffolder.cpp:12-41
-    const bool fastq = filename[std::strlen(filename) - 1] == 'q';
-    std::ifstream in(filename);
-    if (!in) {
+// Scaffolder::load (Scaffolder.cpp:12-41).  The reference reads the file line by line and takes the lines in turns:
+// a name line (first whitespace-separated token minus its first character), a sequence line, and for a file name ending
+// in 'q' two more lines that are skipped.  Nothing is checked: the roles follow from the line NUMBER alone.  That makes
+// the file splittable: the bytes are cut into ranges at line ends, the ranges' line counts give every range the number
+// of its first line, and all cores fill names_ / sequences_ in place (the reads of the A. thaliana-shaped input are
+// 10 GB of text).
+namespace {
+
+const char *next_line(const char *p, const char *end, const char *&line_end) {
+    const char *nl = (const char *) std::memchr(p, '\n', (size_t) (end - p));
+    line_end = nl ? nl : end;
+    return nl ? nl + 1 : end;
+}
+
+// what `std::istringstream iss(line); iss >> line;` leaves in `line`, minus its first character
+std::string name_of_line(const char *b, const char *e) {
+    const char *p = b;
+    while (p < e && std::isspace((unsigned char) *p)) p++;
+    if (p == e) return e - b > 1 ? std::string(b + 1, e) : std::string();      // no token: the line as it is
+    const char *q = p;
+    while (q < e && !std::isspace((unsigned char) *q)) q++;
+    return std::string(p + 1, q);
+}
+
+}   // namespace
+
+bool Scaffolder::load(const char *filename) {
+    const size_t len = std::strlen(filename);
+    const size_t period = len && filename[len - 1] == 'q' ? 4 : 2;      // lines per record
+    const int fd = ::open(filename, O_RDONLY);
+    if (fd < 0) {
         std::cerr << "Cannot open file: " << filename << std::endl;
         return false;
     }
-    std::string line;
-    bool reading_name = true;
-    while (std::getline(in, line)) {
-        if (reading_name) {
-            std::istringstream iss(line);
-            iss >> line;                                // first token (an empty line keeps `line` as it was)
-            names_.emplace_back(line.empty() ? line : line.substr(1));
-            index_.emplace(names_.back(), names_.size() - 1);       // keeps the first index of a repeated name
-        } else {
-            sequences_.push_back(line);
-            if (fastq) {                                // skip "+" and the quality line
-                std::getline(in, line);
-                std::getline(in, line);
-            }
-        }
-        reading_name = !reading_name;
+    struct stat st;
+    ::fstat(fd, &st);
+    const size_t size = (size_t) st.st_size;
+    if (size == 0) {
+        ::close(fd);
+        return true;
     }
+    const char *data = (const char *) ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (data == MAP_FAILED) {
+        ::close(fd);
+        std::cerr << "Cannot open file: " << filename << std::endl;
+        return false;
+    }
+    unsigned nt = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = std::min<unsigned>(nt ? nt : 1, (unsigned) CPU_COUNT(&set));
+    nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min(nt, 64u), size / (4u << 20) + 1));
+    std::vector<const char *> cut(nt + 1);
+    cut[0] = data;
+    cut[nt] = data + size;
+    for (unsigned t = 1; t < nt; t++) {
+        const char *p = data + size / nt * t;
+        const char *nl = (const char *) std::memchr(p, '\n', (size_t) (data + size - p));
+        cut[t] = nl ? nl + 1 : data + size;
+    }
+    // lines per range -> number of each range's first line
+    std::vector<size_t> first_line(nt + 1, 0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                size_t n = 0;
+                for (const char *p = cut[t], *e; p < cut[t + 1]; n++) p = next_line(p, cut[t + 1], e);
+                first_line[t + 1] = n;
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < nt; t++) first_line[t + 1] += first_line[t];
+    }
+    const size_t lines = first_line[nt];
+    const size_t name_base = names_.size(), seq_base = sequences_.size();
+    names_.resize(name_base + (lines + period - 1) / period);                   // lines 0, P, 2P, ...
+    sequences_.resize(seq_base + (lines >= 2 ? (lines - 2) / period + 1 : 0));          // lines 1, P + 1, ...
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                size_t k = first_line[t];
+                for (const char *p = cut[t], *e; p < cut[t + 1]; k++) {
+                    const char *b = p;
+                    p = next_line(p, cut[t + 1], e);
+                    if (k % period == 0) names_[name_base + k / period] = name_of_line(b, e);
+                    else if (k % period == 1) sequences_[seq_base + k / period].assign(b, e);
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    ::munmap((void *) data, size);
+    ::close(fd);
+    for (size_t i = name_base; i < names_.size(); i++) index_.emplace(names_[i], i);     // keeps the first index of a name
     return true;
 }
 

@@ -105,14 +105,51 @@ public:
     size_t parsed_names() const { return names_.size(); }
 
 private:
+    // A column of a tokenised file: a vector whose resize does NOT zero-fill (the parser threads write every element;
+    // first touch by the writers spreads the page faults of a 5 GB table over all cores).
+    template <class T> class Column {
+        T *p_ = nullptr;
+        size_t n_ = 0, cap_ = 0;
+
+    public:
+        Column() = default;
+        Column(const Column &) = delete;
+        Column &operator=(const Column &) = delete;
+        Column(Column &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+        ~Column() { ::operator delete(p_); }
+        void resize_uninitialised(size_t n) {
+            if (n > cap_) {
+                T *q = static_cast<T *>(::operator new(n * sizeof(T)));
+                for (size_t i = 0; i < n_; i++) q[i] = p_[i];
+                ::operator delete(p_);
+                p_ = q;
+                cap_ = n;
+            }
+            n_ = n;
+        }
+        void push_back(T v) {
+            if (n_ == cap_) {
+                const size_t keep = n_;
+                resize_uninitialised(cap_ ? cap_ * 2 : 1024);
+                n_ = keep;
+            }
+            p_[n_++] = v;
+        }
+        size_t size() const { return n_; }
+        T *data() { return p_; }
+        const T *data() const { return p_; }
+        T &operator[](size_t i) { return p_[i]; }
+        const T &operator[](size_t i) const { return p_[i]; }
+    };
     struct File {                       // one tokenised PAF file (SoA int32 columns)
-        std::vector<int32_t> q_id, t_id, q_len, q_start, q_end, t_len, t_start, t_end, matches;
-        std::vector<uint8_t> strand;
-        bool anchors;
+        Column<int32_t> q_id, t_id, q_len, q_start, q_end, t_len, t_start, t_end, matches;
+        Column<uint8_t> strand;
+        bool anchors = false;
     };
     std::vector<File> files_;
     std::vector<std::string> names_;    // name table shared by all files (ids in first-seen order)
-    std::unordered_map<std::string, int32_t> name_id_;
+    struct NameIndex;                   // names_ by name (overlap_graph.cpp)
+    NameIndex *index_ = nullptr;
     tlm_graph *dev_ = nullptr;
     double build_ms_ = 0, parse_ms_ = 0, download_ms_ = 0;
     bool parsed_parallel_ = false;

@@ -110,3 +110,53 @@ def test_scaffolder_fastq_and_single_node(post):
         assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["scaffold"]["md5"]
         res = subprocess.run([post, dump, os.path.join(tmp, "missing.fa"), contigs, out], capture_output=True, text=True)
         assert res.returncode == 1 and "Cannot open file" in res.stderr
+
+
+def _model_load(text: str, fastq: bool):
+    """Scaffolder::load (Scaffolder.cpp:12-41) as a model: lines take their role from their number alone."""
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()                       # getline: no line after the final newline
+    period = 4 if fastq else 2
+    names, seqs = [], []
+    for k, ln in enumerate(lines):
+        if k % period == 0:
+            tok = ln.split()              # first whitespace-separated token minus its first character
+            names.append(tok[0][1:] if tok else ln[1:])
+        elif k % period == 1:
+            seqs.append(ln)
+    return names, seqs
+
+
+@pytest.mark.parametrize("name,fastq,text", [
+    ("plain", False, ">r1 extra words\nACGT\n>r2\nGGA\n"),
+    ("odd_line_count", False, ">r1\nACGT\n>r2\n"),
+    ("no_final_newline", False, ">r1\nACGT\n>r2\nTT"),
+    ("crlf_and_blank_sequence", False, ">r1\r\nAC\r\n>r2\n\n>r3\nT\n"),
+    ("fastq", True, "@r1 c\nACGT\n+\nIIII\n@r2\nGG\n+\nII\n"),
+    ("fastq_truncated", True, "@r1\nACGT\n+\nIIII\n@r2\nGG\n"),
+    ("multi_line_fasta_is_misread_as_the_reference_does", False, ">r1\nAC\nGT\n>r2\nTT\n"),
+    ("single_name", False, ">only\n"),
+])
+def test_scaffolder_load_roles_by_line_number(post, name, fastq, text):
+    with tempfile.TemporaryDirectory() as tmp:
+        p = os.path.join(tmp, "x.fastq" if fastq else "x.fasta")
+        open(p, "w", newline="").write(text)
+        big = os.path.join(tmp, "big.fasta")            # large enough for several parser threads, roles still by number
+        with open(big, "w") as fh:
+            for i in range(120_000):
+                fh.write(">read%d tail\n%s\n" % (i, "ACGT" * (5 + i % 37)))
+        for paths in ([p], [big, p]):
+            res = subprocess.run([post, "--list-sequences"] + paths, capture_output=True, timeout=120)
+            assert res.returncode == 0, res.stderr
+            res.stdout = res.stdout.decode()            # (no newline translation: a sequence may end in \r)
+            names, seqs = [], []
+            for q in paths:
+                n, s = _model_load(open(q, newline="").read(), q.endswith("q"))
+                names += n
+                seqs += s
+            out = res.stdout.split("\n")
+            assert out[0] == "names %d sequences %d" % (len(names), len(seqs))
+            body = res.stdout[len(out[0]) + 1:]
+            want = "".join("%d\t[%s]%s\n" % (i, nm, "\t[%s]" % seqs[i] if i < len(seqs) else "") for i, nm in enumerate(names))
+            assert body == want
