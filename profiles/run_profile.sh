@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline $*"
-KEEP='Kernel_Name|"Name"|walk_|filter_score|gather_kernel|first_seen|make_entries|make_nodes|row_ptr_kernel|node_flags|scan_units|pack_paths|det_count|walk_layout|padded_degree'
+B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-scaffold $*"
+KEEP='Kernel_Name|"Name"|walk_|filter_score|gather_kernel|kept_fields|first_seen|make_entries|make_nodes|row_ptr_kernel|node_flags|scan_units|pack_paths|det_count|walk_layout|padded_degree|bfs_|summary_kernel|dup_flags|copy_kept'
 run() {
     name=$1; shift
     timeout -k 10 280 rocprofv3 "$@" --output-format csv -d $OUT/$name -- $B > $OUT/$name.json 2> $OUT/$name.log || echo "pass $name failed"

@@ -19,7 +19,8 @@ import sys
 
 OURS = ("walk_mc_kernel", "walk_det_kernel", "filter_score_kernel", "gather_kernel", "first_seen_kernel",
         "make_entries_kernel", "make_nodes_kernel", "row_ptr_kernel", "node_flags_kernel", "scan_units_kernel",
-        "pack_paths_kernel", "det_count_kernel")
+        "pack_paths_kernel", "det_count_kernel", "kept_fields_kernel", "walk_layout_kernel", "bfs_expand_kernel",
+        "dup_flags_kernel", "copy_kept_kernel")
 
 
 def short(name: str) -> str:
