@@ -5,10 +5,14 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 #include "tlm_common.h"
 #include "walk_kernels.h"
+
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -61,6 +65,9 @@ struct WalkLane {
 struct CtxImpl : tlm_ctx {
     Workspace ws;           // lane 0 (with ctx->stream, ev0, ev1)
     WalkLane side;          // lane 1
+    // "every workgroup of the Monte-Carlo launch has started": a host-mapped word the kernel sets (tlm_walk_builders)
+    uint32_t *resident_host = nullptr, *resident_dev = nullptr;
+    std::atomic<int> gate_released{0};
 };
 
 extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
@@ -83,7 +90,9 @@ extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
         || hipMalloc((void **) &c->ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess
         || hipStreamCreateWithPriority(&c->side.stream, hipStreamNonBlocking, prio_lo) != hipSuccess
         || hipEventCreate(&c->side.ev0) != hipSuccess || hipEventCreate(&c->side.ev1) != hipSuccess
-        || hipMalloc((void **) &c->side.ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess) {
+        || hipMalloc((void **) &c->side.ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess
+        || hipHostMalloc((void **) &c->resident_host, 64, hipHostMallocMapped) != hipSuccess
+        || hipHostGetDevicePointer((void **) &c->resident_dev, c->resident_host, 0) != hipSuccess) {
         tlm_set_error("tlm_ctx_create: stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
         tlm_ctx_destroy(c);         // releases whatever was created (every handle starts out null)
         return TLM_EHIP;
@@ -105,6 +114,7 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     c->side.ws.release_scratch();
     c->side.ws.release_arena();
     (void) hipFree(c->side.ws.cursor);
+    if (c->resident_host) (void) hipHostFree(c->resident_host);
     for (hipEvent_t e : c->phase_ev) (void) hipEventDestroy(e);
     if (c->side.ev0) (void) hipEventDestroy(c->side.ev0);
     if (c->side.ev1) (void) hipEventDestroy(c->side.ev1);
@@ -312,38 +322,22 @@ extern "C" int tlm_graph_anchor_table(const tlm_graph *g, uint32_t *anchor_nodes
 // ---------------------------------------------------------------------------------------------
 // result packing kernels
 
-// Exclusive scan over the units of (accepted ? 1 : 0) and (accepted ? n_nodes : 0); one workgroup.
-__global__ __launch_bounds__(1024) void scan_units_kernel(uint32_t n_units, const UnitOut *__restrict__ units,
-                                                          uint32_t *__restrict__ p_index, uint64_t *__restrict__ n_off,
-                                                          uint64_t *__restrict__ totals) {
-    __shared__ uint64_t s_cnt[1024];
-    __shared__ uint64_t s_sum[1024];
-    uint64_t carry_cnt = 0, carry_sum = 0;
-    const int t = threadIdx.x;
-    for (uint32_t base = 0; base < n_units; base += 1024) {
-        const uint32_t i = base + t;
-        const bool acc = i < n_units && units[i].status == ST_ACCEPTED;
-        const uint64_t c = acc ? 1 : 0, v = acc ? units[i].nnodes : 0;
-        s_cnt[t] = c;
-        s_sum[t] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            uint64_t a = 0, b = 0;
-            if (t >= d) { a = s_cnt[t - d]; b = s_sum[t - d]; }
-            __syncthreads();
-            s_cnt[t] += a;
-            s_sum[t] += b;
-            __syncthreads();
-        }
-        if (i < n_units) {
-            p_index[i] = (uint32_t) (carry_cnt + s_cnt[t] - c);
-            n_off[i] = carry_sum + s_sum[t] - v;
-        }
-        carry_cnt += s_cnt[1023];
-        carry_sum += s_sum[1023];
-        __syncthreads();
-    }
-    if (t == 0) { totals[0] = carry_cnt; totals[1] = carry_sum; }
+// Exclusive scans over the units of (accepted ? 1 : 0) and (accepted ? n_nodes : 0): where each accepted path goes in the
+// packed set.  rocPRIM device scans over transform iterators (a one-workgroup scan took 35 ms for 400 000 units, and as a
+// single workgroup it could not even start while a persistent walk launch of the other lane filled the device).
+struct AcceptedCount {
+    __host__ __device__ uint32_t operator()(const UnitOut &u) const { return u.status == ST_ACCEPTED ? 1u : 0u; }
+};
+struct AcceptedNodes {
+    __host__ __device__ uint64_t operator()(const UnitOut &u) const { return u.status == ST_ACCEPTED ? (uint64_t) u.nnodes : 0ull; }
+};
+
+__global__ void scan_totals_kernel(uint32_t n_units, const UnitOut *__restrict__ units, const uint32_t *__restrict__ p_index,
+                                   const uint64_t *__restrict__ n_off, uint64_t *__restrict__ totals) {
+    const UnitOut last = units[n_units - 1];
+    const bool acc = last.status == ST_ACCEPTED;
+    totals[0] = (uint64_t) p_index[n_units - 1] + (acc ? 1u : 0u);
+    totals[1] = n_off[n_units - 1] + (acc ? (uint64_t) last.nnodes : 0ull);
 }
 
 __global__ __launch_bounds__(256) void pack_paths_kernel(uint32_t n_units, uint64_t unit_begin,
@@ -384,9 +378,11 @@ struct UnitBufs {
     uint32_t *p_index = nullptr;
     uint64_t *n_off = nullptr, *totals = nullptr;
     uint32_t *work_list = nullptr;
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
     ~UnitBufs() {
         tlm_pool_free(units); tlm_pool_free(p_index); tlm_pool_free(n_off); tlm_pool_free(totals);
-        tlm_pool_free(work_list);
+        tlm_pool_free(work_list); tlm_pool_free(scan_tmp);
     }
 };
 
@@ -426,10 +422,17 @@ int ensure_arena(Workspace &w, hipStream_t stream, uint64_t need, uint64_t keep)
 int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const int *metrics, const tlm_walk_params *p,
               uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr, int lane = 0,
               std::atomic<int> *launched = nullptr, std::atomic<int> *wait_for = nullptr) {
-    struct Signal {
+    struct Signal {         // whoever waits for this call's launch is let go when the call ends, whatever happened
         std::atomic<int> *f;
-        ~Signal() { if (f) f->store(1); }
-    } signal{launched};
+        std::atomic<int> *gate;
+        ~Signal() {
+            if (f) {
+                f->store(1);
+                gate->store(1);
+            }
+        }
+    } signal{launched, &static_cast<CtxImpl *>(ctx)->gate_released};
+    if (launched) static_cast<CtxImpl *>(ctx)->gate_released.store(0);
     TLM_CHECK(ctx && g && out && metrics, TLM_EINVAL, "walk: null argument");
     TLM_CHECK(g->ctx == ctx, TLM_EINVAL, "walk: graph belongs to another context");
     TLM_CHECK(n_slots == 1 || n_slots == 2, TLM_EINVAL, "walk: one or two metrics per launch");
@@ -573,8 +576,24 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             launch_waves = std::max<uint32_t>(4u, launch_waves);
             TLM_HIP(hipMemsetAsync(W.cursor + WALK_QUEUE_BASE, 0, WALK_QUEUE_STRIDE * WALK_XCDS * 4, s));
             if (wait_for) {
+                // The other lane's launch goes first, and this one must not reach the dispatcher before ALL workgroups of
+                // that launch are resident: two launches dispatched together share the slots, and deterministic waves that
+                // got in early sit beside the Monte-Carlo waves for the whole launch (+74 ms on the A. thaliana config).
+                // The Monte-Carlo kernel reports "every workgroup has started" through a host-mapped word; queued after
+                // that, this launch's workgroups start where Monte-Carlo workgroups retire: in the tail.
                 while (!wait_for->load()) std::this_thread::yield();
                 wait_for = nullptr;
+                if (c->resident_host) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (*(volatile uint32_t *) c->resident_host == 0 && !c->gate_released.load()
+                           && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5))
+                        std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+            }
+            a.resident_flag = nullptr;
+            if (launched && round == 0 && c->resident_host) {      // someone waits for this launch to be resident
+                *(volatile uint32_t *) c->resident_host = 0;
+                a.resident_flag = c->resident_dev;
             }
             TLM_HIP(hipEventRecord(ev0, s));
             if (is_mc) tlm_launch_walk_mc(s, launch_waves / 4, sq, a);
@@ -631,7 +650,21 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         tlm_pathset *ps = pss[k];
         const UnitOut *du = u.units + (size_t) k * n_units;
         if (n_units) {
-            hipLaunchKernelGGL(scan_units_kernel, dim3(1), dim3(1024), 0, s, n_units, du, u.p_index, u.n_off, u.totals);
+            auto cnt_in = rocprim::make_transform_iterator(du, AcceptedCount());
+            auto nod_in = rocprim::make_transform_iterator(du, AcceptedNodes());
+            size_t tb1 = 0, tb2 = 0;
+            TLM_HIP(rocprim::exclusive_scan(nullptr, tb1, cnt_in, u.p_index, 0u, (size_t) n_units, rocprim::plus<uint32_t>(), s));
+            TLM_HIP(rocprim::exclusive_scan(nullptr, tb2, nod_in, u.n_off, (uint64_t) 0, (size_t) n_units, rocprim::plus<uint64_t>(), s));
+            if (std::max(tb1, tb2) > u.scan_tmp_bytes) {
+                tlm_pool_free(u.scan_tmp);
+                u.scan_tmp = nullptr;
+                u.scan_tmp_bytes = 0;
+                if (int rc = tlm_pool_alloc(&u.scan_tmp, std::max(tb1, tb2), s)) return rc;
+                u.scan_tmp_bytes = std::max(tb1, tb2);
+            }
+            TLM_HIP(rocprim::exclusive_scan(u.scan_tmp, tb1, cnt_in, u.p_index, 0u, (size_t) n_units, rocprim::plus<uint32_t>(), s));
+            TLM_HIP(rocprim::exclusive_scan(u.scan_tmp, tb2, nod_in, u.n_off, (uint64_t) 0, (size_t) n_units, rocprim::plus<uint64_t>(), s));
+            hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1), 0, s, n_units, du, u.p_index, u.n_off, u.totals);
             uint64_t h_tot[2] = {0, 0};
             TLM_HIP(hipMemcpyAsync(h_tot, u.totals, 16, hipMemcpyDeviceToHost, s));
             TLM_HIP(hipStreamSynchronize(s));

@@ -66,6 +66,9 @@ struct WalkArgs {
     UnitOut *units;
     uint2 *arena;                   // accepted paths: {reference node, edge slot}
     uint64_t ar_cap;
+    // host-mapped word, or null: set to 1 by the workgroup that finds every workgroup of the launch started (counted in
+    // cursor[1]); the host queues the deterministic launch of tlm_walk_builders only then
+    uint32_t *resident_flag;
 };
 
 constexpr int WALK_RNG_WORDS = 640;             // raw std::mt19937 state of a wave (624 words), kept in HBM between twists

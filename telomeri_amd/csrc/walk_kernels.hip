@@ -783,7 +783,7 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
 // while it stays in the neighbourhood of one anchor -- and jumps to another id range when it crosses into the next
 // anchor's neighbourhood, which every accepted walk does once (anchors are numbered in node order, not along the genome).
 // A band fixed at the start anchor left a third of all steps probing the HBM map (measured).  So: when the
-// current node is further than BAND_SLACK from the band's centre, the band's bits are OR-ed into the wave's HBM map
+// current node is further than BAND_SLACK from the band's centre, the band's words are written to the wave's HBM map
 // (the flushed range is logged, the map is cleared from the log when the walk ends) and the band is re-loaded around the
 // current node.  The set stays exact at every moment: band ids in LDS, all others in HBM.
 constexpr uint32_t BAND_SLACK = WIN_BITS / 2 - 1024;
@@ -792,10 +792,10 @@ __device__ __forceinline__ uint32_t band_base_for(uint32_t n) { return n > WIN_B
 
 __device__ __noinline__ void band_slide(lds_u32 *win, glb_u32 *bm, uint32_t n_words, uint32_t old_lo, uint32_t new_lo, int lane) {
     const uint32_t ow = old_lo >> 5, nw = new_lo >> 5;
-    for (uint32_t i = lane; i < WIN_WORDS; i += 64) {
-        const uint32_t w = win[i];
-        if (w) bm[ow + i] |= w;             // a set bit is a real node id: the word exists
-    }
+    // the band is the truth for its ids (it was loaded from these very words, or both were zero): written back whole,
+    // so that a flag the deterministic walk has CLEARED in the band is cleared in the map too
+    for (uint32_t i = lane; i < WIN_WORDS; i += 64)
+        if (ow + i < n_words) bm[ow + i] = win[i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the two ranges may overlap: stores first, then the loads
     for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = nw + i < n_words ? bm[nw + i] : 0u;
     wave_sync();
@@ -1298,6 +1298,19 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
         uint32_t node = second;
         uint2 rec = scalar_load_u2(a.rows, node);
         for (;;) {                                          // :243
+            {   // keep the band around the walk (see band_slide)
+                const uint32_t want = band_base_for(node);
+                if (__builtin_expect(want - vs.lo + BAND_SLACK > 2u * BAND_SLACK, 0)) {
+                    if (nlog + 1 > a.cap) {
+                        status = ST_SCRATCH_OVF;
+                        break;
+                    }
+                    if (lane == 0) ws.lg[nlog] = 0x80000000u | (vs.lo >> 5);
+                    nlog++;
+                    band_slide((lds_u32 *) win, (glb_u32 *) ws.bm, a.bm_words - WALK_RNG_WORDS, vs.lo, want, lane);
+                    vs.lo = want;
+                }
+            }
             const uint32_t row = rfl(rec.x);
             const uint32_t deg = rfl(rec.y) & 0xFFFFFFu;
             bool go_back = false;
@@ -1438,6 +1451,13 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
+    if (threadIdx.x == 0) {      // "all workgroups are resident" for a host that wants to queue another launch behind this one
+        ColdArgs *ca = cold_args();
+        uint32_t *flag = ca->resident_flag;
+        if (flag && atomicAdd(ca->cursor + 1, 1u) + 1u == gridDim.x) {
+            __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     uint32_t cu;
     QueueState q = queue_init();
     while (next_work(lane, q, cu)) {
