@@ -235,6 +235,9 @@ def main() -> None:
                     "walk_mc_evals_per_s": mc_evals / (mc_ms * 1e-3) if mc_ms else None,
                     "walk_det_evals_per_s": det_evals / (det_ms * 1e-3) if det_ms else None,
                     "graph_build_cold_ms": cold_build_ms, "graph_build_device_ms": gi.build_ms, "filter_score_ms": gi.filter_ms,
+                    "graph_build_wall_ms": gi.build_wall_ms, "graph_build_alloc_ms": gi.build_alloc_ms,
+                    "graph_build_host_syncs": gi.host_syncs,
+                    "graph_build_phases_ms": {k: round(v, 3) for k, v in gi.phases().items()},
                     "filter_score_records_per_s": n_records / (gi.filter_ms * 1e-3) if gi.filter_ms else None,
                     "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
         "paths_per_step": paths_total,
