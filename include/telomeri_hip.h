@@ -74,6 +74,9 @@ typedef struct {
     double kernel_ms;              /* duration of the walk kernel(s), HIP events on the context's stream */
     uint32_t kernel_launches;      /* walk-kernel launches behind kernel_ms (re-runs after an overflow count) */
     uint32_t waves;                /* persistent wavefronts of the first launch */
+    double kernel_busy_ms;         /* first workgroup in -> last workgroup out, device clock: equals kernel_ms for a launch
+                                      that starts at once; tlm_walk_builders queues its deterministic launch behind the
+                                      Monte-Carlo launch, where kernel_ms includes the wait for free compute units */
 } tlm_counters;
 
 typedef struct {

@@ -49,7 +49,7 @@ class WalkParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("units", C.c_uint64), ("steps", C.c_uint64), ("evals", C.c_uint64), ("draws", C.c_uint64),
                 ("accepted", C.c_uint64), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
-                ("waves", C.c_uint32)]
+                ("waves", C.c_uint32), ("kernel_busy_ms", C.c_double)]
 
 
 class _Records(C.Structure):

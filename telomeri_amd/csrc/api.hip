@@ -575,6 +575,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             uint32_t launch_waves = std::min<uint32_t>(cur_waves, ((n_work + 3) / 4) * 4);
             launch_waves = std::max<uint32_t>(4u, launch_waves);
             TLM_HIP(hipMemsetAsync(W.cursor + WALK_QUEUE_BASE, 0, WALK_QUEUE_STRIDE * WALK_XCDS * 4, s));
+            TLM_HIP(hipMemsetAsync(W.cursor + 6, 0xFF, 8, s));      // first workgroup in (atomicMin)
+            TLM_HIP(hipMemsetAsync(W.cursor + 8, 0, 8, s));         // last workgroup out (atomicMax)
             if (wait_for) {
                 // The other lane's launch goes first, and this one must not reach the dispatcher before ALL workgroups of
                 // that launch are resident: two launches dispatched together share the slots, and deterministic waves that
@@ -601,6 +603,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));
             if (launched) launched->store(1);
+            unsigned long long span[2] = {0, 0};
+            TLM_HIP(hipMemcpyAsync(span, W.cursor + 6, 16, hipMemcpyDeviceToHost, s));
             TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipEventSynchronize(ev1));
             TLM_HIP(hipStreamSynchronize(s));
@@ -608,6 +612,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             TLM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             cnt[0].kernel_ms += ms;          // the launch is shared by the slots: it is booked on the first one
             cnt[0].kernel_launches++;
+            // (only the deterministic kernel stamps its span; a Monte-Carlo launch starts at once: its span is `ms`)
+            cnt[0].kernel_busy_ms += (!is_mc && span[1] > span[0]) ? (double) (span[1] - span[0]) * 1e-5 : ms;     // 100 MHz ticks
             // overflow handling: re-run the affected units with a full-size path buffer / a larger arena
             std::vector<uint32_t> sc_ovf, ar_ovf;
             for (uint32_t i = 0; i < n_all; i++) {

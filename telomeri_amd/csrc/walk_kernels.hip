@@ -1390,6 +1390,16 @@ __device__ __forceinline__ WaveScratch wave_scratch(const WalkArgs &a, uint32_t 
     return ws;
 }
 
+// First workgroup in / last workgroup out on the device's constant-rate clock (100 MHz), in cursor[6..9]: what a launch
+// took once it had compute units, however long it waited for them.
+__device__ __forceinline__ void stamp_span(uint32_t *cursor, bool leaving) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t = wall_clock64();
+        if (leaving) atomicMax(reinterpret_cast<unsigned long long *>(cursor + 8), t);
+        else atomicMin(reinterpret_cast<unsigned long long *>(cursor + 6), t);
+    }
+}
+
 // Persistent waves with one work queue per XCD.  The work items are cut into chunks of `chunk` consecutive items (the
 // trials of one start anchor under one metric) and chunk j belongs to XCD j % 8: the waves of an XCD walk the same
 // neighbourhood at the same time, so its L2 (4 MB, private to the XCD) holds the rows they share.  A wave pulls from
@@ -1501,6 +1511,7 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(Wal
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
+    stamp_span(a.cursor, false);
     uint32_t cu;
     QueueState q = queue_init();
     while (next_work(lane, q, cu)) {
@@ -1516,6 +1527,8 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(Wal
         det_walk<SQRT>(b, ws, win_s[wib], ring_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
                        (uint32_t) (unit - a.det_off[lo]));
     }
+    __syncthreads();
+    stamp_span(a.cursor, true);
 }
 
 }  // namespace

@@ -42,6 +42,7 @@ int main(int argc, char **argv) {
         Scaffolder sc(none);
         for (size_t i = 1; i < pos.size(); i++)
             if (!sc.load(pos[i])) return 1;
+        sc.materialiseAll();
         std::printf("names %zu sequences %zu\n", sc.names_.size(), sc.sequences_.size());
         for (size_t i = 0; i < sc.names_.size(); i++) {
             std::printf("%zu\t[%s]", i, sc.names_[i].c_str());

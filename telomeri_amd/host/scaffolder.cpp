@@ -95,6 +95,7 @@ bool Scaffolder::load(const char *filename) {
     const size_t name_base = names_.size(), seq_base = sequences_.size();
     names_.resize(name_base + (lines + period - 1) / period);                   // lines 0, P, 2P, ...
     sequences_.resize(seq_base + (lines >= 2 ? (lines - 2) / period + 1 : 0));          // lines 1, P + 1, ...
+    where_.resize(sequences_.size(), View{nullptr, 0});
     {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
@@ -104,15 +105,27 @@ bool Scaffolder::load(const char *filename) {
                     const char *b = p;
                     p = next_line(p, cut[t + 1], e);
                     if (k % period == 0) names_[name_base + k / period] = name_of_line(b, e);
-                    else if (k % period == 1) sequences_[seq_base + k / period].assign(b, e);
+                    else if (k % period == 1) where_[seq_base + k / period] = View{b, (size_t) (e - b)};
                 }
             });
         for (auto &x : th) x.join();
     }
-    ::munmap((void *) data, size);
+    maps_.emplace_back((void *) data, size);        // the sequence lines are copied out of it when they are asked for
     ::close(fd);
     for (size_t i = name_base; i < names_.size(); i++) index_.emplace(names_[i], i);     // keeps the first index of a name
     return true;
+}
+
+Scaffolder::~Scaffolder() {
+    for (auto &m : maps_) ::munmap(m.first, m.second);
+}
+
+void Scaffolder::materialiseAll() {
+    for (size_t i = 0; i < sequences_.size(); i++)
+        if (where_[i].p) {
+            sequences_[i].assign(where_[i].p, where_[i].n);
+            where_[i].p = nullptr;
+        }
 }
 
 std::string &Scaffolder::getSequenceFrom(const std::string &name) {     // :104-112
@@ -122,7 +135,12 @@ std::string &Scaffolder::getSequenceFrom(const std::string &name) {     // :104-
         std::cerr << "Scaffolder: no sequence named '" << name << "'" << std::endl;
         std::exit(1);
     }
-    return sequences_[it->second];
+    const size_t i = it->second;
+    if (where_[i].p) {              // first use: out of the mapped file
+        sequences_[i].assign(where_[i].p, where_[i].n);
+        where_[i].p = nullptr;
+    }
+    return sequences_[i];
 }
 
 std::string Scaffolder::substring(std::string &str, ulong start, ulong end) {      // :114-117, both ends inclusive

@@ -296,8 +296,15 @@ class Scaffolder {                      // Scaffolder.hpp:11-34
 public:
     const Path &p_;
     std::vector<std::string> names_;
+    /** As in the reference, one string per record -- but filled on demand: load() maps the file and notes where every
+     *  sequence line lies; getSequenceFrom() copies the ones the scaffold uses (a fifth of the reads on the
+     *  A. thaliana-shaped input: 2 GB instead of 10).  materialiseAll() fills the rest (the reference's state). */
     std::vector<std::string> sequences_;
     explicit Scaffolder(const Path &p) : p_(p) {}
+    ~Scaffolder();
+    Scaffolder(const Scaffolder &) = delete;
+    Scaffolder &operator=(const Scaffolder &) = delete;
+    void materialiseAll();
     bool load(const char *filename);                    // Scaffolder.cpp:12-41
     bool write(const char *filename);                   // Scaffolder.cpp:43-102
     std::string substring(std::string &str, ulong start, ulong end);   // inclusive ends (:114-117)
@@ -306,6 +313,9 @@ public:
 
 private:
     std::unordered_map<std::string, size_t> index_;     // name -> first index (the reference scans linearly)
+    struct View { const char *p; size_t n; };
+    std::vector<View> where_;                           // sequence line of record i inside a mapped file (p = null: none)
+    std::vector<std::pair<void *, size_t>> maps_;       // the mapped files, until the Scaffolder goes
 };
 
 #endif
