@@ -292,6 +292,30 @@ int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tlm_pathset *
  * (front Node*, back Node*)), inside one key in path order.  A bucket is a run of equal keys. */
 int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *order_host, uint64_t *key_host);
 
+/* ---- PAF text -> records on the device ------------------------------------------------- */
+/* OverlapGraph::load's parse loop (OverlapGraph.cpp:106-128) for CLEAN text: every line 16 whitespace-separated
+ * tokens, the nine numeric ones plain [+-]digits inside int range, the strand one character, no blank lines -- there
+ * line-wise parsing is the reference's token stream.  The text goes to the device (pinned slabs, parallel reads) and is
+ * tokenised there; names are numbered in first-seen order over the files (query before target), the numbering a
+ * sequential reader assigns.  *clean = 0: the text is something else, nothing was added; the host falls back to its
+ * exact token-stream reader for the whole graph. */
+typedef struct tlm_paf tlm_paf;
+int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out);
+void tlm_paf_destroy(tlm_paf *p);
+/* One file of the graph, in load order (at most 4).  `anchors` is OverlapGraph::load's second argument. */
+int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint64_t *n_records, int *clean);
+int tlm_paf_add_text(tlm_paf *p, const char *text_host, uint64_t bytes, int anchors, uint64_t *n_records, int *clean);
+/* After the last file: final name ids.  n_names names, blob_bytes bytes of name text in all. */
+int tlm_paf_finish(tlm_paf *p, uint32_t *n_names, uint64_t *blob_bytes);
+/* HOST buffers (any may be NULL): name i = blob[name_off[i] .. name_off[i + 1]); is_ctg[i] = Utils::startsWithInsensitive(name, "ctg") */
+int tlm_paf_names(const tlm_paf *p, uint32_t *name_off, char *blob, uint8_t *is_ctg);
+/* The columns of file `file` (DEVICE pointers owned by `p`; q_id / t_id are the final name ids). */
+int tlm_paf_records(const tlm_paf *p, int file, tlm_records *out);
+/* tlm_graph_build over the files of `p` (the handle may be destroyed afterwards). */
+int tlm_paf_build_graph(tlm_paf *p, const tlm_filter_params *fp, tlm_graph **out);
+/* host wall-clock of the stages so far: text upload, tokenising, finish */
+int tlm_paf_timing(const tlm_paf *p, double *upload_ms, double *parse_ms, double *finish_ms);
+
 /* ---- multi-GPU: one process per GPU, ONE exchange ---------------------------------------- */
 /* The graph is replicated (every rank builds it from the same files); rank r of `world` walks the units of the anchors
  * tlm_dist_anchor_range gives it (contiguous bundles of ceil(n_anchors / world) anchors: MC units

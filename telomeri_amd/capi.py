@@ -159,6 +159,16 @@ def lib() -> C.CDLL:
     L.tlm_pathset_fetch.argtypes = [V, V, C.c_uint64, V, V, V]
     L.tlm_graph_edges.argtypes = [V, C.c_uint64, V, V, V]
     L.tlm_graph_get_stats.argtypes = [V, P(GraphStats)]
+    L.tlm_paf_create.argtypes = [V, P(V)]
+    L.tlm_paf_destroy.argtypes = [V]
+    L.tlm_paf_destroy.restype = None
+    L.tlm_paf_add_file.argtypes = [V, C.c_char_p, C.c_int, P(C.c_uint64), P(C.c_int)]
+    L.tlm_paf_add_text.argtypes = [V, C.c_char_p, C.c_uint64, C.c_int, P(C.c_uint64), P(C.c_int)]
+    L.tlm_paf_finish.argtypes = [V, P(C.c_uint32), P(C.c_uint64)]
+    L.tlm_paf_names.argtypes = [V, V, V, V]
+    L.tlm_paf_records.argtypes = [V, C.c_int, P(_Records)]
+    L.tlm_paf_build_graph.argtypes = [V, P(FilterParams), P(V)]
+    L.tlm_paf_timing.argtypes = [V, P(C.c_double), P(C.c_double), P(C.c_double)]
     L.tlm_dist_unique_id.argtypes = [V]
     L.tlm_dist_init.argtypes = [V, C.c_int, C.c_int, V]
     L.tlm_dist_finalize.argtypes = [V]
@@ -557,6 +567,76 @@ class Context:
                                         _np_ptr(si), _np_ptr(es), _np_ptr(strand), _np_ptr(node_len), _np_ptr(node_anchor),
                                         C.byref(h)), "tlm_graph_from_csr")
         return Graph(self, h)
+
+
+class PafTokens:
+    """tlm_paf_*: the PAF files of one graph, tokenised on the device."""
+
+    def __init__(self, ctx: "Context") -> None:
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(lib().tlm_paf_create(ctx._h, C.byref(h)), "tlm_paf_create")
+        self._h = h
+        self.n_files = 0
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().tlm_paf_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add_file(self, path: str, anchors: bool):
+        """-> (records, clean)"""
+        n, clean = C.c_uint64(), C.c_int()
+        _check(lib().tlm_paf_add_file(self._h, path.encode(), int(anchors), C.byref(n), C.byref(clean)), "tlm_paf_add_file")
+        self.n_files += bool(clean.value)
+        return int(n.value), bool(clean.value)
+
+    def add_text(self, text: bytes, anchors: bool):
+        n, clean = C.c_uint64(), C.c_int()
+        _check(lib().tlm_paf_add_text(self._h, text, len(text), int(anchors), C.byref(n), C.byref(clean)), "tlm_paf_add_text")
+        self.n_files += bool(clean.value)
+        return int(n.value), bool(clean.value)
+
+    def finish(self):
+        """-> (names list[str], is_ctg uint8 array)"""
+        n, nb = C.c_uint32(), C.c_uint64()
+        _check(lib().tlm_paf_finish(self._h, C.byref(n), C.byref(nb)), "tlm_paf_finish")
+        off = np.zeros(n.value + 1, np.uint32)
+        blob = np.zeros(max(int(nb.value), 1), np.uint8)
+        ctg = np.zeros(max(n.value, 1), np.uint8)
+        _check(lib().tlm_paf_names(self._h, _np_ptr(off), _np_ptr(blob), _np_ptr(ctg)), "tlm_paf_names")
+        raw = blob.tobytes()
+        return [raw[off[i]:off[i + 1]].decode("latin-1") for i in range(n.value)], ctg[:n.value]
+
+    def records(self, file: int) -> "_Records":
+        r = _Records()
+        _check(lib().tlm_paf_records(self._h, file, C.byref(r)), "tlm_paf_records")
+        return r
+
+    def columns(self, file: int) -> dict:
+        """The file's columns copied to the host (tests)."""
+        import torch
+        r = self.records(file)
+        out = {}
+        for name in ("q_id", "t_id", "q_len", "q_start", "q_end", "t_len", "t_start", "t_end", "matches", "strand"):
+            dt = torch.uint8 if name == "strand" else torch.int32
+            t = torch.empty(int(r.n), dtype=dt, device="cuda:%d" % self.ctx.device)
+            src = getattr(r, name)
+            if r.n:
+                hip = C.CDLL("libamdhip64.so")
+                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                rc = hip.hipMemcpy(t.data_ptr(), src, int(r.n) * t.element_size(), 3)       # device to device
+                assert rc == 0, rc
+            out[name] = t.cpu().numpy()
+        return out
+
+    def build_graph(self, fp: FilterParams) -> "Graph":
+        h = C.c_void_p()
+        _check(lib().tlm_paf_build_graph(self._h, C.byref(fp), C.byref(h)), "tlm_paf_build_graph")
+        return Graph(self.ctx, h)
 
 
 def dist_unique_id() -> bytes:

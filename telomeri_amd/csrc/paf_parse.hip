@@ -1,0 +1,564 @@
+// telomeri_amd/csrc/paf_parse.hip -- PAF text -> record columns ON THE DEVICE.
+//
+// OverlapGraph::load reads its file as a stream of whitespace-separated tokens (reference src/OverlapGraph.cpp:106-128):
+// 12 typed tokens per record, then exactly 4 more that are discarded.  Once filter, scores and adjacency run on the GPU
+// the host's share of a load is tokenising 15 GB of text (5 s on 16 cores for the A. thaliana-shaped input) and uploading
+// the 5.5 GB of columns it produces.  Here the TEXT goes to HBM instead (pinned slabs filled by parallel preads, H2D
+// copies behind them) and is tokenised where the graph build wants its input:
+//   pass A  line starts per 32 KB tile (a line starts at byte 0 and after every '\n')   -> record index of every tile
+//   pass B  one thread per line: 16 tokens, the nine numeric ones as strict [+-]digits inside int range, the strand as
+//           one character; the two names go through a device dictionary (open addressing over the text itself: a slot
+//           holds WHERE a name occurs first, an equal name is recognised by comparing bytes) and come out as slot numbers
+//   finish  occupied slots sorted by first occurrence (file, offset) = first-seen order, the numbering a sequential reader
+//           assigns; slot numbers in the columns become those ids; name bytes gathered into one blob for the host
+// Exactly like the host's parallel tokeniser (telomeri_amd/host/overlap_graph.cpp) this is only valid on CLEAN text --
+// every line 16 tokens, plain integers, one-character strand, no blank lines; then line-wise parsing IS the token
+// stream.  Anything else raises `clean = 0` and the caller falls back to the exact operator>> reader on the host.
+// tests/test_gpu_parity.py compares columns, ids and names with the host tokeniser on every fixture and malformed input.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#include "tlm_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+namespace {
+
+constexpr uint32_t TILE = 32u << 10;            // bytes of text per workgroup
+constexpr uint32_t TILE_THREADS = 256;
+constexpr uint32_t TILE_MAX_LINES = 4096;       // more line starts than this in one tile: not a PAF file (blank lines)
+constexpr int MAX_FILES = 4;
+constexpr unsigned long long EMPTY = ~0ull;
+
+// a name's first occurrence: file (2 bits) | offset in that file's text (46 bits) | length (16 bits); ordered by
+// (file, offset) = the order in which a sequential reader meets the names
+__host__ __device__ inline unsigned long long pack_occ(uint32_t file, uint64_t off, uint32_t len) {
+    return ((unsigned long long) file << 62) | ((unsigned long long) off << 16) | len;
+}
+__host__ __device__ inline uint32_t occ_file(unsigned long long p) { return (uint32_t) (p >> 62); }
+__host__ __device__ inline uint64_t occ_off(unsigned long long p) { return (p >> 16) & ((1ull << 46) - 1); }
+__host__ __device__ inline uint32_t occ_len(unsigned long long p) { return (uint32_t) (p & 0xFFFFu); }
+
+struct Texts {
+    const char *p[MAX_FILES];
+};
+
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() { tlm_pool_free(p); }
+};
+
+__device__ inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// ---- pass A: line starts per tile
+__global__ __launch_bounds__(TILE_THREADS) void count_lines_kernel(const char *__restrict__ text, uint64_t bytes,
+                                                                   uint64_t n_tiles, uint32_t *__restrict__ tile_lines) {
+    __shared__ uint32_t s_cnt;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
+        uint32_t n = 0;
+        for (uint64_t p = b + threadIdx.x; p < e; p += TILE_THREADS) n += p == 0 || text[p - 1] == '\n';
+        for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, n);
+        __syncthreads();
+        if (threadIdx.x == 0) tile_lines[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// ---- the dictionary
+struct Dict {
+    unsigned long long *slot;       // first occurrence of the slot's name, or EMPTY
+    uint32_t mask;
+    uint32_t *n_names;              // occupied slots; n_names[1] = flags of the parse
+};
+
+__device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, uint32_t file, uint64_t off, uint32_t len) {
+    const char *s = tx.p[file] + off;
+    unsigned long long h = 1469598103934665603ull;
+    for (uint32_t i = 0; i < len; i++) { h ^= (unsigned char) s[i]; h *= 1099511628211ull; }
+    h ^= h >> 29;
+    const unsigned long long mine = pack_occ(file, off, len);
+    uint32_t probes = 0;
+    for (uint32_t j = (uint32_t) h & d.mask;; j = (j + 1) & d.mask) {
+        if (probes++ > d.mask) {            // every slot taken by another name: more names than the table was made for
+            atomicOr(d.n_names + 1, 8u);
+            return 0;
+        }
+        unsigned long long cur = d.slot[j];
+        if (cur == EMPTY) {
+            cur = atomicCAS(&d.slot[j], EMPTY, mine);
+            if (cur == EMPTY) {
+                atomicAdd(d.n_names, 1u);
+                return j;
+            }
+        }
+        if (occ_len(cur) == len) {          // whatever occurrence the slot shows at the moment spells the slot's name
+            const char *o = tx.p[occ_file(cur)] + occ_off(cur);
+            bool same = true;
+            for (uint32_t i = 0; i < len && same; i++) same = o[i] == s[i];
+            if (same) {
+                if (mine < cur) atomicMin(&d.slot[j], mine);
+                return j;
+            }
+        }
+    }
+}
+
+struct Columns {
+    int32_t *q_id, *t_id, *q_len, *q_start, *q_end, *t_len, *t_start, *t_end, *matches;
+    uint8_t *strand;
+};
+
+__device__ inline bool strict_int(const char *s, const char *e, int32_t &v) {
+    if (s >= e) return false;
+    bool neg = false;
+    if (*s == '+' || *s == '-') { neg = *s == '-'; s++; }
+    if (s >= e || e - s > 10) return false;
+    long long acc = 0;
+    for (; s < e; s++) {
+        if (*s < '0' || *s > '9') return false;
+        acc = acc * 10 + (*s - '0');
+    }
+    if (neg) acc = -acc;
+    if (acc > 2147483647ll || acc < -2147483648ll) return false;
+    v = (int32_t) acc;
+    return true;
+}
+
+// flags: 1 = a line is not 16 clean tokens, 2 = too many line starts in a tile, 4 = a name of 65 535 bytes or more
+__global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uint32_t file, uint64_t bytes, uint64_t n_tiles,
+                                                                   const uint64_t *__restrict__ tile_base, Dict dict,
+                                                                   Columns out, uint32_t *__restrict__ flags) {
+    __shared__ uint16_t s_start[TILE_MAX_LINES];
+    __shared__ uint32_t s_scan[TILE_THREADS];
+    const char *text = tx.p[file];
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
+        // line starts of the tile, in order: every thread owns 128 consecutive bytes
+        constexpr uint32_t PER = TILE / TILE_THREADS;
+        const uint64_t mb = b + (uint64_t) threadIdx.x * PER, me = min(e, mb + PER);
+        uint32_t n = 0;
+        for (uint64_t p = mb; p < me; p++) n += p == 0 || text[p - 1] == '\n';
+        s_scan[threadIdx.x] = n;
+        __syncthreads();
+        for (uint32_t d = 1; d < TILE_THREADS; d <<= 1) {
+            const uint32_t a = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s_scan[threadIdx.x] += a;
+            __syncthreads();
+        }
+        const uint32_t total = s_scan[TILE_THREADS - 1];
+        uint32_t at = s_scan[threadIdx.x] - n;
+        if (total > TILE_MAX_LINES) {
+            if (threadIdx.x == 0) atomicOr(flags, 2u);
+        } else {
+            for (uint64_t p = mb; p < me; p++)
+                if (p == 0 || text[p - 1] == '\n') s_start[at++] = (uint16_t) (p - b);
+        }
+        __syncthreads();
+        if (total <= TILE_MAX_LINES) {
+            for (uint32_t l = threadIdx.x; l < total; l += TILE_THREADS) {
+                const uint64_t r = tile_base[tile] + l;
+                const char *p = text + b + s_start[l];
+                const char *end = text + bytes;
+                const char *tok[16], *tend[16];
+                int nt = 0;
+                while (p < end && *p != '\n') {
+                    while (p < end && *p != '\n' && is_ws(*p)) p++;
+                    if (p >= end || *p == '\n') break;
+                    if (nt == 16) { nt = 17; break; }
+                    tok[nt] = p;
+                    while (p < end && *p != '\n' && !is_ws(*p)) p++;
+                    tend[nt++] = p;
+                }
+                int32_t v[9];
+                const int num_idx[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
+                bool ok = nt == 16 && tend[4] - tok[4] == 1;
+                for (int k = 0; ok && k < 9; k++) ok = strict_int(tok[num_idx[k]], tend[num_idx[k]], v[k]);
+                if (!ok) {
+                    atomicOr(flags, 1u);
+                    continue;
+                }
+                const uint64_t qn = (uint64_t) (tend[0] - tok[0]), tn = (uint64_t) (tend[5] - tok[5]);
+                if (qn >= 0xFFFFu || tn >= 0xFFFFu) {
+                    atomicOr(flags, 4u);
+                    continue;
+                }
+                out.q_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (tok[0] - text), (uint32_t) qn);
+                out.t_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (tok[5] - text), (uint32_t) tn);
+                out.q_len[r] = v[0]; out.q_start[r] = v[1]; out.q_end[r] = v[2];
+                out.t_len[r] = v[3]; out.t_start[r] = v[4]; out.t_end[r] = v[5];
+                out.matches[r] = v[6];
+                out.strand[r] = *tok[4] == '-';
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- finish
+__global__ void collect_slots_kernel(const unsigned long long *__restrict__ slot, uint64_t n_slots,
+                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals,
+                                     uint32_t *__restrict__ counter) {
+    for (uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (uint64_t) gridDim.x * blockDim.x) {
+        const unsigned long long k = slot[s];
+        if (k != EMPTY) {
+            const uint32_t i = atomicAdd(counter, 1u);
+            keys[i] = k;
+            vals[i] = (uint32_t) s;
+        }
+    }
+}
+
+__global__ void names_kernel(uint32_t n, const unsigned long long *__restrict__ occ, const uint32_t *__restrict__ slot_of,
+                             Texts tx, uint32_t *__restrict__ id_of_slot, uint32_t *__restrict__ len_out,
+                             uint8_t *__restrict__ is_ctg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    id_of_slot[slot_of[i]] = i;
+    const uint32_t len = occ_len(occ[i]);
+    len_out[i] = len;
+    const char *s = tx.p[occ_file(occ[i])] + occ_off(occ[i]);
+    // Utils::startsWithInsensitive(name, "ctg") (Utils.hpp:17-27)
+    is_ctg[i] = len >= 3 && (s[0] | 0x20) == 'c' && (s[1] | 0x20) == 't' && (s[2] | 0x20) == 'g';
+}
+
+__global__ void blob_kernel(uint32_t n, const unsigned long long *__restrict__ occ, const uint32_t *__restrict__ off,
+                            Texts tx, char *__restrict__ blob) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const char *s = tx.p[occ_file(occ[i])] + occ_off(occ[i]);
+    const uint32_t len = occ_len(occ[i]);
+    for (uint32_t k = 0; k < len; k++) blob[off[i] + k] = s[k];
+}
+
+__global__ void remap_kernel(uint64_t n, int32_t *__restrict__ q_id, int32_t *__restrict__ t_id,
+                             const uint32_t *__restrict__ id_of_slot) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        q_id[i] = (int32_t) id_of_slot[(uint32_t) q_id[i]];
+        t_id[i] = (int32_t) id_of_slot[(uint32_t) t_id[i]];
+    }
+}
+
+unsigned grid_of(uint64_t n, unsigned per = 256) {
+    return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((n + per - 1) / per, 256u * 32u));
+}
+
+}   // namespace
+
+struct tlm_paf {
+    tlm_ctx *ctx = nullptr;
+    int n_files = 0;
+    char *text[MAX_FILES] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t bytes[MAX_FILES] = {0, 0, 0, 0};
+    uint64_t n[MAX_FILES] = {0, 0, 0, 0};
+    int anchors[MAX_FILES] = {0, 0, 0, 0};
+    Columns cols[MAX_FILES] = {};
+    unsigned long long *slot = nullptr;
+    uint64_t n_slots = 0;
+    uint32_t *n_names_dev = nullptr;     // [0] occupied slots, [1] flags, [2] collect counter
+    bool finished = false;
+    uint32_t n_names = 0;
+    uint8_t *is_ctg = nullptr;
+    uint32_t *name_off = nullptr;        // [n_names + 1]
+    char *blob = nullptr;
+    uint64_t blob_bytes = 0;
+    double upload_ms = 0, parse_ms = 0, finish_ms = 0;
+};
+
+extern "C" int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out) {
+    TLM_CHECK(ctx && out, TLM_EINVAL, "tlm_paf_create: null argument");
+    tlm_paf *p = new tlm_paf();
+    p->ctx = ctx;
+    *out = p;
+    return TLM_OK;
+}
+
+extern "C" void tlm_paf_destroy(tlm_paf *p) {
+    if (!p) return;
+    (void) hipSetDevice(p->ctx->device);
+    (void) hipStreamSynchronize(p->ctx->stream);
+    for (int f = 0; f < MAX_FILES; f++) {
+        tlm_pool_free(p->text[f]);
+        void *c[] = {p->cols[f].q_id, p->cols[f].t_id, p->cols[f].q_len, p->cols[f].q_start, p->cols[f].q_end, p->cols[f].t_len,
+                     p->cols[f].t_start, p->cols[f].t_end, p->cols[f].matches, p->cols[f].strand};
+        for (void *b : c) tlm_pool_free(b);
+    }
+    tlm_pool_free(p->slot); tlm_pool_free(p->n_names_dev); tlm_pool_free(p->is_ctg); tlm_pool_free(p->name_off);
+    tlm_pool_free(p->blob);
+    delete p;
+}
+
+// text already on the device (p->text[f], p->bytes[f]): tokenise it
+static int tokenise_on_device(tlm_paf *p, int f, uint64_t *n_records, int *clean) {
+    hipStream_t s = p->ctx->stream;
+    const uint64_t bytes = p->bytes[f];
+    *clean = 1;
+    *n_records = 0;
+    if (bytes == 0) return TLM_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t n_tiles = (bytes + TILE - 1) / TILE;
+    Tmp tile_lines, tile_base, scan_tmp;
+    if (int rc = tlm_pool_alloc(&tile_lines.p, n_tiles * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&tile_base.p, (n_tiles + 1) * 8, s)) return rc;
+    hipLaunchKernelGGL(count_lines_kernel, dim3(grid_of(n_tiles, 1)), dim3(TILE_THREADS), 0, s, p->text[f], bytes, n_tiles,
+                       (uint32_t *) tile_lines.p);
+    {
+        struct ToU64 {
+            __host__ __device__ uint64_t operator()(uint32_t v) const { return v; }
+        };
+        auto in = rocprim::make_transform_iterator((const uint32_t *) tile_lines.p, ToU64());
+        size_t tb = 0;
+        TLM_HIP(rocprim::exclusive_scan(nullptr, tb, in, (uint64_t *) tile_base.p, (uint64_t) 0, (size_t) n_tiles,
+                                        rocprim::plus<uint64_t>(), s));
+        if (int rc = tlm_pool_alloc(&scan_tmp.p, tb, s)) return rc;
+        TLM_HIP(rocprim::exclusive_scan(scan_tmp.p, tb, in, (uint64_t *) tile_base.p, (uint64_t) 0, (size_t) n_tiles,
+                                        rocprim::plus<uint64_t>(), s));
+    }
+    uint64_t last_base = 0;
+    uint32_t last_lines = 0;
+    TLM_HIP(hipMemcpyAsync(&last_base, (uint64_t *) tile_base.p + (n_tiles - 1), 8, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipMemcpyAsync(&last_lines, (uint32_t *) tile_lines.p + (n_tiles - 1), 4, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    const uint64_t n = last_base + last_lines;
+    TLM_CHECK(n < (1ull << 31), TLM_ELIMIT, "tlm_paf: %llu lines exceed the 2^31 record limit", (unsigned long long) n);
+    // dictionary: created with the first file, sized from its record count (names are few compared with records)
+    if (!p->slot) {
+        uint64_t want = std::max<uint64_t>(1u << 20, std::min<uint64_t>(n, 1ull << 27));
+        uint64_t cap = 1;
+        while (cap < want) cap <<= 1;
+        p->n_slots = cap;
+        if (int rc = tlm_pool_alloc((void **) &p->slot, cap * 8, s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &p->n_names_dev, 16, s)) return rc;
+        TLM_HIP(hipMemsetAsync(p->slot, 0xFF, cap * 8, s));
+        TLM_HIP(hipMemsetAsync(p->n_names_dev, 0, 16, s));
+    }
+    Columns &c = p->cols[f];
+    int32_t **i32[] = {&c.q_id, &c.t_id, &c.q_len, &c.q_start, &c.q_end, &c.t_len, &c.t_start, &c.t_end, &c.matches};
+    for (int32_t **col : i32)
+        if (int rc = tlm_pool_alloc((void **) col, (n ? n : 1) * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc((void **) &c.strand, n ? n : 1, s)) return rc;
+    Texts tx;
+    for (int k = 0; k < MAX_FILES; k++) tx.p[k] = p->text[k];
+    Dict d{p->slot, (uint32_t) (p->n_slots - 1), p->n_names_dev};
+    TLM_HIP(hipMemsetAsync(p->n_names_dev + 1, 0, 4, s));
+    hipLaunchKernelGGL(parse_tiles_kernel, dim3(grid_of(n_tiles, 1)), dim3(TILE_THREADS), 0, s, tx, (uint32_t) f, bytes, n_tiles,
+                       (const uint64_t *) tile_base.p, d, c, p->n_names_dev + 1);
+    uint32_t h[2] = {0, 0};
+    TLM_HIP(hipMemcpyAsync(h, p->n_names_dev, 8, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    p->parse_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (h[1] != 0 || (uint64_t) h[0] * 2 > p->n_slots) {       // not clean PAF text (or a dictionary too full to trust)
+        *clean = 0;
+        return TLM_OK;
+    }
+    p->n[f] = n;
+    *n_records = n;
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint64_t *n_records, int *clean) {
+    TLM_CHECK(p && path && n_records && clean, TLM_EINVAL, "tlm_paf_add_file: null argument");
+    TLM_CHECK(!p->finished && p->n_files < MAX_FILES, TLM_EINVAL, "tlm_paf_add_file: at most %d files, before tlm_paf_finish", MAX_FILES);
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const int fd = ::open(path, O_RDONLY);
+    TLM_CHECK(fd >= 0, TLM_EINVAL, "Cannot open file: %s", path);
+    struct stat st;
+    ::fstat(fd, &st);
+    const uint64_t bytes = (uint64_t) st.st_size;
+    TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_add_file: file too large");
+    const int f = p->n_files;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = tlm_pool_alloc((void **) &p->text[f], bytes + 64, s);
+    if (rc == TLM_OK && bytes) {
+        // pinned slabs filled by parallel preads (the page cache copies at memory speed), H2D copies behind them
+        constexpr size_t SLAB = 128u << 20;
+        constexpr int N_SLABS = 3, READERS = 8;
+        char *slab[N_SLABS] = {nullptr, nullptr, nullptr};
+        hipEvent_t done[N_SLABS] = {nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (int k = 0; k < N_SLABS && ok; k++)
+            ok = hipHostMalloc((void **) &slab[k], SLAB, hipHostMallocDefault) == hipSuccess
+                 && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+        uint64_t at = 0;
+        for (int k = 0; ok && at < bytes; k = (k + 1) % N_SLABS) {
+            const size_t len = (size_t) std::min<uint64_t>(SLAB, bytes - at);
+            ok = hipEventSynchronize(done[k]) == hipSuccess;        // the slab's previous copy has left it
+            std::vector<std::thread> th;
+            bool read_ok[READERS];
+            for (int t = 0; t < READERS; t++)
+                th.emplace_back([&, t] {
+                    size_t a = len * (size_t) t / READERS, b = len * (size_t) (t + 1) / READERS;
+                    read_ok[t] = true;
+                    while (a < b) {
+                        const ssize_t got = ::pread(fd, slab[k] + a, b - a, (off_t) (at + a));
+                        if (got <= 0) { read_ok[t] = false; break; }
+                        a += (size_t) got;
+                    }
+                });
+            for (auto &x : th) x.join();
+            for (int t = 0; t < READERS; t++) ok = ok && read_ok[t];
+            ok = ok && hipMemcpyAsync(p->text[f] + at, slab[k], len, hipMemcpyHostToDevice, s) == hipSuccess
+                 && hipEventRecord(done[k], s) == hipSuccess;
+            at += len;
+        }
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        for (int k = 0; k < N_SLABS; k++) {
+            if (done[k]) (void) hipEventDestroy(done[k]);
+            if (slab[k]) (void) hipHostFree(slab[k]);
+        }
+        if (!ok) {
+            tlm_set_error("tlm_paf_add_file: reading or uploading %s failed", path);
+            rc = TLM_EHIP;
+        }
+    }
+    ::close(fd);
+    if (rc != TLM_OK) return rc;
+    p->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    p->bytes[f] = bytes;
+    p->anchors[f] = anchors;
+    p->n_files = f + 1;
+    rc = tokenise_on_device(p, f, n_records, clean);
+    if (rc != TLM_OK || !*clean) p->n_files = f;        // nothing was appended (the buffers go with the handle)
+    return rc;
+}
+
+extern "C" int tlm_paf_add_text(tlm_paf *p, const char *text_host, uint64_t bytes, int anchors, uint64_t *n_records, int *clean) {
+    TLM_CHECK(p && (text_host || bytes == 0) && n_records && clean, TLM_EINVAL, "tlm_paf_add_text: null argument");
+    TLM_CHECK(!p->finished && p->n_files < MAX_FILES, TLM_EINVAL, "tlm_paf_add_text: at most %d files, before tlm_paf_finish", MAX_FILES);
+    TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_add_text: text too large");
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const int f = p->n_files;
+    if (int rc = tlm_pool_alloc((void **) &p->text[f], bytes + 64, s)) return rc;
+    if (bytes) TLM_HIP(hipMemcpyAsync(p->text[f], text_host, bytes, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    p->bytes[f] = bytes;
+    p->anchors[f] = anchors;
+    p->n_files = f + 1;
+    const int rc = tokenise_on_device(p, f, n_records, clean);
+    if (rc != TLM_OK || !*clean) p->n_files = f;
+    return rc;
+}
+
+extern "C" int tlm_paf_finish(tlm_paf *p, uint32_t *n_names_out, uint64_t *blob_bytes_out) {
+    TLM_CHECK(p && n_names_out, TLM_EINVAL, "tlm_paf_finish: null argument");
+    TLM_CHECK(!p->finished, TLM_EINVAL, "tlm_paf_finish: called twice");
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t n = 0;
+    if (p->slot) {
+        TLM_HIP(hipMemcpyAsync(&n, p->n_names_dev, 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+    p->n_names = n;
+    if (int rc = tlm_pool_alloc((void **) &p->is_ctg, n ? n : 1, s)) return rc;
+    if (int rc = tlm_pool_alloc((void **) &p->name_off, ((size_t) n + 1) * 4, s)) return rc;
+    TLM_HIP(hipMemsetAsync(p->name_off, 0, ((size_t) n + 1) * 4, s));
+    if (n) {
+        Tmp keys, vals, keys2, vals2, sort_tmp, id_of_slot, lens, scan_tmp;
+        if (int rc = tlm_pool_alloc(&keys.p, (size_t) n * 8, s)) return rc;
+        if (int rc = tlm_pool_alloc(&vals.p, (size_t) n * 4, s)) return rc;
+        if (int rc = tlm_pool_alloc(&keys2.p, (size_t) n * 8, s)) return rc;
+        if (int rc = tlm_pool_alloc(&vals2.p, (size_t) n * 4, s)) return rc;
+        if (int rc = tlm_pool_alloc(&id_of_slot.p, p->n_slots * 4, s)) return rc;
+        if (int rc = tlm_pool_alloc(&lens.p, ((size_t) n + 1) * 4, s)) return rc;
+        TLM_HIP(hipMemsetAsync(p->n_names_dev + 2, 0, 4, s));
+        hipLaunchKernelGGL(collect_slots_kernel, dim3(grid_of(p->n_slots)), dim3(256), 0, s, p->slot, p->n_slots,
+                           (unsigned long long *) keys.p, (uint32_t *) vals.p, p->n_names_dev + 2);
+        size_t tb = 0;
+        TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *) keys.p, (unsigned long long *) keys2.p,
+                                          (uint32_t *) vals.p, (uint32_t *) vals2.p, (size_t) n, 0, 64, s));
+        if (int rc = tlm_pool_alloc(&sort_tmp.p, tb, s)) return rc;
+        TLM_HIP(rocprim::radix_sort_pairs(sort_tmp.p, tb, (unsigned long long *) keys.p, (unsigned long long *) keys2.p,
+                                          (uint32_t *) vals.p, (uint32_t *) vals2.p, (size_t) n, 0, 64, s));
+        Texts tx;
+        for (int k = 0; k < MAX_FILES; k++) tx.p[k] = p->text[k];
+        TLM_HIP(hipMemsetAsync(lens.p, 0, ((size_t) n + 1) * 4, s));
+        hipLaunchKernelGGL(names_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (const unsigned long long *) keys2.p,
+                           (const uint32_t *) vals2.p, tx, (uint32_t *) id_of_slot.p, (uint32_t *) lens.p, p->is_ctg);
+        size_t tb2 = 0;
+        TLM_HIP(rocprim::exclusive_scan(nullptr, tb2, (const uint32_t *) lens.p, p->name_off, 0u, (size_t) n + 1,
+                                        rocprim::plus<uint32_t>(), s));
+        if (int rc = tlm_pool_alloc(&scan_tmp.p, tb2, s)) return rc;
+        TLM_HIP(rocprim::exclusive_scan(scan_tmp.p, tb2, (const uint32_t *) lens.p, p->name_off, 0u, (size_t) n + 1,
+                                        rocprim::plus<uint32_t>(), s));
+        uint32_t total = 0;
+        TLM_HIP(hipMemcpyAsync(&total, p->name_off + n, 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        p->blob_bytes = total;
+        if (int rc = tlm_pool_alloc((void **) &p->blob, total ? total : 1, s)) return rc;
+        hipLaunchKernelGGL(blob_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (const unsigned long long *) keys2.p,
+                           (const uint32_t *) p->name_off, tx, p->blob);
+        for (int f = 0; f < p->n_files; f++)
+            if (p->n[f])
+                hipLaunchKernelGGL(remap_kernel, dim3(grid_of(p->n[f])), dim3(256), 0, s, p->n[f], p->cols[f].q_id, p->cols[f].t_id,
+                                   (const uint32_t *) id_of_slot.p);
+        TLM_HIP(hipStreamSynchronize(s));
+        TLM_HIP(hipGetLastError());
+    }
+    // the text is no longer needed
+    for (int f = 0; f < MAX_FILES; f++) {
+        tlm_pool_free(p->text[f]);
+        p->text[f] = nullptr;
+    }
+    tlm_pool_free(p->slot);
+    p->slot = nullptr;
+    p->finished = true;
+    p->finish_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *n_names_out = n;
+    if (blob_bytes_out) *blob_bytes_out = p->blob_bytes;
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_names(const tlm_paf *p, uint32_t *name_off_host, char *blob_host, uint8_t *is_ctg_host) {
+    TLM_CHECK(p && p->finished, TLM_EINVAL, "tlm_paf_names: call tlm_paf_finish first");
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    if (name_off_host) TLM_HIP(hipMemcpyAsync(name_off_host, p->name_off, ((size_t) p->n_names + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (blob_host && p->blob_bytes) TLM_HIP(hipMemcpyAsync(blob_host, p->blob, p->blob_bytes, hipMemcpyDeviceToHost, s));
+    if (is_ctg_host && p->n_names) TLM_HIP(hipMemcpyAsync(is_ctg_host, p->is_ctg, p->n_names, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_records(const tlm_paf *p, int file, tlm_records *out) {
+    TLM_CHECK(p && out && p->finished && file >= 0 && file < p->n_files, TLM_EINVAL, "tlm_paf_records: bad argument");
+    const Columns &c = p->cols[file];
+    out->n = p->n[file];
+    out->q_id = c.q_id; out->t_id = c.t_id; out->q_len = c.q_len; out->q_start = c.q_start; out->q_end = c.q_end;
+    out->t_len = c.t_len; out->t_start = c.t_start; out->t_end = c.t_end; out->matches = c.matches;
+    out->strand = c.strand;
+    out->anchors = p->anchors[file];
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_timing(const tlm_paf *p, double *upload_ms, double *parse_ms, double *finish_ms) {
+    TLM_CHECK(p, TLM_EINVAL, "tlm_paf_timing: null argument");
+    if (upload_ms) *upload_ms = p->upload_ms;
+    if (parse_ms) *parse_ms = p->parse_ms;
+    if (finish_ms) *finish_ms = p->finish_ms;
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_build_graph(tlm_paf *p, const tlm_filter_params *fp, tlm_graph **out) {
+    TLM_CHECK(p && fp && out && p->finished && p->n_files >= 1, TLM_EINVAL, "tlm_paf_build_graph: finish the files first");
+    tlm_records recs[MAX_FILES];
+    for (int f = 0; f < p->n_files; f++)
+        if (int rc = tlm_paf_records(p, f, &recs[f])) return rc;
+    return tlm_graph_build(p->ctx, fp, recs, p->n_files, p->n_names, p->is_ctg, out);
+}

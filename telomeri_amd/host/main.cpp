@@ -121,7 +121,7 @@ int main(int argc, char **argv) {
     if (!graph.end_loads()) return 1;
     build_ms = graph.last_build_ms();
     dl_ms = graph.last_download_ms();
-    std::cout << "load breakdown: tokenise+intern " << parse_ms << " ms (" << (graph.last_parse_was_parallel() ? "parallel" : "sequential")
+    std::cout << "load breakdown: tokenise+intern " << parse_ms << " ms (" << graph.last_parse_mode()
               << "), device graph build " << build_ms << " ms, download+materialise " << dl_ms << " ms" << std::endl;
     std::cout << "Done (" << lap() << "s)" << std::endl << graph.stats() << std::endl;
 

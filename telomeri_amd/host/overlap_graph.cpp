@@ -460,11 +460,58 @@ struct OverlapGraph::NameIndex {
 
 OverlapGraph::~OverlapGraph() {
     if (dev_) tlm_graph_destroy(dev_);
+    if (paf_) tlm_paf_destroy(paf_);
     delete index_;
+}
+
+// Lean graphs in a begin_loads() / end_loads() bracket: the file's TEXT goes to the device and is tokenised there
+// (tlm_paf_add_file; csrc/paf_parse.hip).  Returns false when the device path does not apply or the text is not clean PAF
+// (then every file tokenised on the device so far is tokenised again on the host, so that all files share one name table).
+bool OverlapGraph::tokenize_on_device(char *filepath, bool anchors, ulong &records) {
+    if (!lean_ || !deferred_ || test_load_num_ != 0) return false;
+    if (const char *e = std::getenv("TLM_DEVICE_PARSE")) {
+        if (std::atoi(e) == 0) return false;
+    }
+    if (!files_.empty() && device_files_.empty()) return false;        // an earlier file already went through the host
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!paf_ && tlm_paf_create(context(), &paf_) != TLM_OK) die("tlm_paf_create");
+    uint64_t n = 0;
+    int clean = 0;
+    if (tlm_paf_add_file(paf_, filepath, anchors ? 1 : 0, &n, &clean) != TLM_OK) {
+        // (a file that cannot be opened is reported by the host tokeniser with the reference's message)
+        clean = 0;
+    }
+    if (!clean) {
+        tlm_paf_destroy(paf_);
+        paf_ = nullptr;
+        std::vector<std::pair<std::string, bool>> redo;
+        redo.swap(device_files_);
+        files_.clear();
+        for (auto &f : redo) {
+            ulong ctr = 0;
+            std::vector<char> path(f.first.begin(), f.first.end());
+            path.push_back(0);
+            if (!tokenize(path.data(), f.second, ctr)) return false;
+        }
+        return false;
+    }
+    device_files_.emplace_back(filepath, anchors);
+    files_.emplace_back();              // keeps the file count; no host columns
+    files_.back().anchors = anchors;
+    records = (ulong) n;
+    parse_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    parsed_on_device_ = true;
+    parsed_parallel_ = false;
+    return true;
 }
 
 bool OverlapGraph::load(char *filepath, bool anchors) {
     ulong ctr = 0;
+    if (tokenize_on_device(filepath, anchors, ctr)) {
+        pending_.emplace_back(filepath, ctr);
+        return true;
+    }
+    parsed_on_device_ = false;
     if (!tokenize(filepath, anchors, ctr)) return false;
     if (deferred_) {
         pending_.emplace_back(filepath, ctr);
@@ -639,6 +686,54 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
 
 bool OverlapGraph::rebuild() {
     tlm_ctx *ctx = context();
+    tlm_filter_params dfp;
+    dfp.mode = (int32_t) filter_params_.mode;          // same numbering as TLM_MODE_*
+    dfp.min_overlap_length = filter_params_.min_overlap_length;
+    dfp.min_overlap_percentage = filter_params_.min_overlap_percentage;
+    dfp.max_overhang_length = filter_params_.max_overhang_length;
+    dfp.max_overhang_percentage = filter_params_.max_overhang_percentage;
+    if (paf_) {         // the files were tokenised on the device: names from there, the columns never leave it
+        uint32_t n_names = 0;
+        uint64_t blob_bytes = 0;
+        if (tlm_paf_finish(paf_, &n_names, &blob_bytes) != TLM_OK) die("tlm_paf_finish");
+        std::vector<uint32_t> off((size_t) n_names + 1);
+        std::vector<char> blob(blob_bytes ? blob_bytes : 1);
+        if (tlm_paf_names(paf_, off.data(), blob.data(), nullptr) != TLM_OK) die("tlm_paf_names");
+        names_.resize(n_names);
+        for (uint32_t i = 0; i < n_names; i++) names_[i].assign(blob.data() + off[i], off[i + 1] - off[i]);
+        if (dev_) { tlm_graph_destroy(dev_); dev_ = nullptr; }
+        if (tlm_paf_build_graph(paf_, &dfp, &dev_) != TLM_OK) die("tlm_paf_build_graph");
+        double up = 0, pa = 0, fi = 0;
+        tlm_paf_timing(paf_, &up, &pa, &fi);
+        if (getenv("TLM_HOST_TIMING"))
+            std::cerr << "[host timing] device tokeniser: text upload " << up << " ms, tokenise " << pa << " ms, names " << fi
+                      << " ms" << std::endl;
+        tlm_paf_destroy(paf_);
+        paf_ = nullptr;
+        tlm_graph_info gi;
+        tlm_graph_get_info(dev_, &gi);
+        build_ms_ = gi.build_ms;
+        const auto t_dl = std::chrono::steady_clock::now();
+        const size_t N = gi.n_nodes;
+        std::vector<uint32_t> node_len(N);
+        std::vector<uint8_t> anchor(N);
+        std::vector<int32_t> name_id(N);
+        if (tlm_graph_download(dev_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               node_len.data(), anchor.data(), name_id.data()) != TLM_OK)
+            die("tlm_graph_download");
+        nodes_.clear();
+        nodes_.resize(N);
+        edges_.clear();
+        for (size_t i = 0; i < N; i++) {
+            Node &n = nodes_[i];
+            n.anchor = anchor[i] != 0;
+            n.index = (uint) i;
+            n.length = node_len[i];
+            n.name = names_[(size_t) name_id[i]];
+        }
+        download_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count();
+        return true;
+    }
     std::vector<tlm_records> recs(files_.size());
     for (size_t i = 0; i < files_.size(); i++) {
         const File &f = files_[i];

@@ -32,6 +32,7 @@
 struct tlm_ctx;
 struct tlm_graph;
 struct tlm_pathset;
+struct tlm_paf;
 
 typedef unsigned int uint;
 typedef unsigned long ulong;
@@ -99,6 +100,8 @@ public:
     double last_parse_ms() const { return parse_ms_; }      // host tokenising + interning of the last load
     double last_download_ms() const { return download_ms_; }
     bool last_parse_was_parallel() const { return parsed_parallel_; }
+    /** "device", "parallel" (host, all cores) or "sequential" (host, the exact token-stream reader) */
+    const char *last_parse_mode() const { return parsed_on_device_ ? "device" : parsed_parallel_ ? "parallel" : "sequential"; }
     /** The host half of load alone (no GPU needed): tokenise `filepath` into the pending columns. */
     bool tokenize(char *filepath, bool anchors, ulong &records);
     uint64_t parse_checksum() const;    // FNV-1a over every tokenised column and the name table (tests)
@@ -153,6 +156,12 @@ private:
     tlm_graph *dev_ = nullptr;
     double build_ms_ = 0, parse_ms_ = 0, download_ms_ = 0;
     bool parsed_parallel_ = false;
+    // lean graphs between begin_loads() and end_loads(): the text is tokenised on the device (tlm_paf_*), the host keeps
+    // no columns at all; a file that is not clean PAF text sends every file of the graph back to the host tokeniser
+    bool parsed_on_device_ = false;
+    tlm_paf *paf_ = nullptr;
+    std::vector<std::pair<std::string, bool>> device_files_;       // (path, anchors) of the files tokenised on the device
+    bool tokenize_on_device(char *filepath, bool anchors, ulong &records);
     bool deferred_ = false;
     bool lean_ = false;
     std::vector<std::pair<std::string, ulong>> pending_;   // (path, records read) of the loads since begin_loads()

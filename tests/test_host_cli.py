@@ -177,3 +177,94 @@ def test_lean_host_equals_materialised_host(binary, name):
             outs.append((res.returncode, body, keep))
         assert outs[0] == outs[1]
         assert any(ln.startswith("-  min_OS") for ln in outs[0][2])
+
+
+# ---- the device tokeniser (csrc/paf_parse.hip) against the host tokeniser and the token-stream model ----------------
+
+def _host_parse(binary, paths):
+    import test_host_ingest as TI
+    return TI.run(binary, paths, threads=3)
+
+
+def test_device_tokeniser_equals_host_tokeniser(binary):
+    """Clean PAF text: columns, name ids (first-seen order over the files) and names from the device are those of the
+    host tokeniser -- compared through the same checksum `telomeri_hip --parse-only` prints."""
+    import test_host_ingest as TI
+    from telomeri_amd import capi
+    ctx = capi.Context(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = [G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz"), G.gunzip_to(tmp, "ecoli_cr.paf.gz")]
+        recs, modes, n_names, cs = _host_parse(binary, paths)
+        paf = capi.PafTokens(ctx)
+        got = [paf.add_file(p, anchors=i > 0) for i, p in enumerate(paths)]
+        assert [n for n, _ in got] == recs and all(c for _, c in got)
+        names, is_ctg = paf.finish()
+        files = [paf.columns(i) for i in range(3)]
+        assert len(names) == n_names and TI.checksum(files, names) == cs
+        assert [bool(x) for x in is_ctg] == [nm.lower().startswith("ctg") for nm in names]
+        # and the graph built from the device's records is the graph of the files
+        fp = capi.FilterParams.default()
+        g = paf.build_graph(fp)
+        og = po.Graph()
+        pfp = po.FilterParams.default()
+        for i, p in enumerate(paths):
+            assert og.load_paf(p, i > 0, pfp)
+        import helpers as H
+        H.assert_csr_equal(g.download(), og.csr())
+
+
+@pytest.mark.parametrize("name,text,expect_clean", [
+    ("clean", None, True),
+    ("no_trailing_newline", "strip", True),
+    ("crlf", "crlf", True),
+    ("ragged_17_tokens", "extra", False),
+    ("ragged_15_tokens", "short", False),
+    ("number_with_suffix", "suffix", False),
+    ("overflow", "overflow", False),
+    ("two_char_strand", "strand", False),
+    ("blank_line", "blank", False),
+    ("empty", "empty", True),
+])
+def test_device_tokeniser_verdict_on_malformed_text(name, text, expect_clean):
+    """What is not 16 clean tokens per line is refused (clean = 0: the host's exact token-stream reader takes over);
+    what is accepted equals the token-stream model."""
+    import test_host_ingest as TI
+    from telomeri_amd import capi
+    L = TI.LINE
+    body = {None: L * 40, "strip": (L * 5).rstrip("\n"), "crlf": (L * 4).replace("\n", "\r\n"),
+            "extra": L * 3 + L.replace("dv:f:0.01", "dv:f:0.01\textra") + L, "short": L * 2 + L.replace("\tdv:f:0.01", "") + L,
+            "suffix": L + L.replace("\t6500\t", "\t65x0\t") + L, "overflow": L + L.replace("\t9000\t", "\t99999999999\t"),
+            "strand": L + L.replace("\t+\t", "\t+-\t"), "blank": L + "\n" + L, "empty": ""}[text]
+    ctx = capi.Context(0)
+    paf = capi.PafTokens(ctx)
+    n, clean = paf.add_text(body.encode(), anchors=False)
+    assert clean == expect_clean
+    if clean:
+        cols, names = TI.stream_parse(body)
+        assert n == len(cols["q_len"])
+        got_names, _ = paf.finish()
+        assert got_names == names
+        if n:
+            got = paf.columns(0)
+            for k in cols:
+                np.testing.assert_array_equal(got[k], np.array(cols[k]), err_msg=k)
+
+
+def test_cli_falls_back_to_the_host_tokeniser(binary):
+    """A file that is not clean PAF sends the WHOLE graph back to the host tokeniser: same output as with the device
+    tokeniser switched off."""
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
+        # a blank line in the SECOND file: the first one has already been tokenised on the device by then
+        txt = open(cr).read().split("\n")
+        open(cr, "w").write("\n".join(txt[:3] + [""] + txt[3:]))
+        outs = []
+        for env in ({}, {"TLM_DEVICE_PARSE": "0"}):
+            res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, cr, "r", "c", "o"], capture_output=True, text=True,
+                                 timeout=300, env=dict(os.environ, **env))
+            assert res.returncode == 0, res.stderr
+            outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
+        assert outs[0] == outs[1] and any(ln.startswith("Loaded") for ln in outs[0])
+        res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, G.gunzip_to(tmp, "tiny_cr.paf.gz"), "r", "c", "o"],
+                             capture_output=True, text=True, timeout=300)
+        assert "(device)" in res.stdout
