@@ -473,6 +473,7 @@ bool OverlapGraph::tokenize_on_device(char *filepath, bool anchors, ulong &recor
         if (std::atoi(e) == 0) return false;
     }
     if (!files_.empty() && device_files_.empty()) return false;        // an earlier file already went through the host
+    if (::access(filepath, R_OK) != 0) return false;                   // the host tokeniser reports it, as the reference does
     const auto t_begin = std::chrono::steady_clock::now();
     if (!paf_ && tlm_paf_create(context(), &paf_) != TLM_OK) die("tlm_paf_create");
     uint64_t n = 0;

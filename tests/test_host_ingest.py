@@ -230,9 +230,9 @@ def test_run_sh_contract(tmp_path):
     d.mkdir()
     res = subprocess.run(["bash", run, str(d)], capture_output=True, text=True)
     assert res.returncode == 1 and "no ./minimap2/minimap2" in res.stderr          # both PAFs missing: would be built
-    (d / "rr_overlaps.paf").write_text("")
+    (d / "cr_overlaps.paf").write_text("")
     (d / "reads.fasta").write_text(">r\nA\n")
     (d / "contigs.fastq").write_text("@c\nA\n+\nI\n")
     res = subprocess.run(["bash", run, str(d)], capture_output=True, text=True)
     assert "Using existing overlap files!" in res.stdout                           # one of the two exists: reused as is
-    assert res.returncode == 1 and "Cannot open file: %s" % (d / "cr_overlaps.paf") in res.stderr
+    assert res.returncode == 1 and "Cannot open file: %s" % (d / "rr_overlaps.paf") in res.stderr
