@@ -111,6 +111,7 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
                              env=dict(os.environ, TLM_HOST_TIMING="1"))
         out["scaffold_wall_s"] = round(time.time() - t0, 3)
         out["exit"] = res.returncode
+        out["host_timing"] = [ln[len("[host timing] "):] for ln in res.stderr.splitlines() if ln.startswith("[host timing]")]
         done = [float(x) for x in re.findall(r"Done \(([0-9.e+-]+)s\)", res.stdout)]
         names = ["load_s", "path_build_s", "consensus_s", "fasta_load_s", "scaffold_write_s"]
         out["stages_s"] = {k: v for k, v in zip(names, done)}

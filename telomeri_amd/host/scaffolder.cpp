@@ -8,6 +8,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -171,14 +172,20 @@ void Scaffolder::swapBases(std::string &str) {          // :129-147
 //   n_m        : seq[0 .. e_m-1.q_end]
 namespace {
 
+struct Piece {              // a cut of a sequence that stays where it is (a loaded string or the mapped file)
+    const char *p;
+    size_t n;
+    bool complement;        // A <-> T, G <-> C on the way out (Scaffolder::swapBases)
+};
+
 class PieceStack {          // the pieces cut so far, oldest first
-    std::vector<std::string> pieces_;
+    std::vector<Piece> pieces_;
     size_t total_ = 0;
 
 public:
-    void push(std::string piece) {
-        total_ += piece.size();
-        pieces_.push_back(std::move(piece));
+    void push(Piece piece) {
+        total_ += piece.n;
+        pieces_.push_back(piece);
     }
     // Drop the `count` characters appended last.  In the reference's reversed string those are its tail; here they are
     // the HEAD of the newest piece, then of the one before it, and so on.
@@ -187,20 +194,42 @@ public:
         if (count > total_) return;
         total_ -= count;
         while (count > 0) {
-            std::string &newest = pieces_.back();
-            if (newest.size() <= count) {
-                count -= newest.size();
+            Piece &newest = pieces_.back();
+            if (newest.n <= count) {
+                count -= newest.n;
                 pieces_.pop_back();
             } else {
-                newest.erase(0, count);
+                newest.p += count;
+                newest.n -= count;
                 count = 0;
             }
         }
     }
     void write_newest_first(std::ostream &out) const {
-        for (auto it = pieces_.rbegin(); it != pieces_.rend(); ++it) out << *it;
+        char swap[256];
+        for (int c = 0; c < 256; c++) swap[c] = (char) c;
+        swap[(unsigned char) 'A'] = 'T'; swap[(unsigned char) 'T'] = 'A';
+        swap[(unsigned char) 'G'] = 'C'; swap[(unsigned char) 'C'] = 'G';
+        std::string buf;
+        for (auto it = pieces_.rbegin(); it != pieces_.rend(); ++it) {
+            if (!it->complement) {
+                out.write(it->p, (std::streamsize) it->n);
+            } else {
+                buf.resize(it->n);
+                for (size_t i = 0; i < it->n; i++) buf[i] = swap[(unsigned char) it->p[i]];
+                out.write(buf.data(), (std::streamsize) buf.size());
+            }
+        }
     }
 };
+
+// Scaffolder::substring (Scaffolder.cpp:114-117: str.substr(start, end - start + 1), both ends inclusive) on a view:
+// clamped at the end of the sequence, std::out_of_range when `start` lies beyond it -- as std::string::substr.
+Piece cut(const char *seq, size_t size, ulong start, ulong end, bool complement) {
+    if (start > size) throw std::out_of_range("basic_string::substr");
+    const ulong count = end - start + 1;         // (wraps like the reference's unsigned arithmetic)
+    return Piece{seq + start, (size_t) std::min<ulong>(count, size - start), complement};
+}
 
 }   // namespace
 
@@ -223,26 +252,41 @@ bool Scaffolder::write(const char *filename) {
         out << std::string(seq.rbegin(), seq.rend());
         return true;
     }
+    // The pieces are views: a read contributes a couple of hundred characters of its ten thousand, so the sequences stay
+    // where they are (the mapped file, or sequences_[i] once somebody has asked for the string) until the final write.
+    auto view_of = [&](const std::string &name, const char *&seq, size_t &size) {
+        auto it = index_.find(name);
+        if (it == index_.end() || it->second >= sequences_.size()) {
+            std::cerr << "Scaffolder: no sequence named '" << name << "'" << std::endl;
+            std::exit(1);
+        }
+        const size_t i = it->second;
+        if (where_[i].p) { seq = where_[i].p; size = where_[i].n; }
+        else { seq = sequences_[i].data(); size = sequences_[i].size(); }
+    };
     PieceStack scaffold;
-    std::cout << name_of(0);
-    {
-        std::string &seq = getSequenceFrom(name_of(0));
-        scaffold.push(substring(seq, (ulong) p_.edges_[0]->t_end + 1, seq.size()));
-    }
+    const char *seq = nullptr;
+    size_t size = 0;
+    std::string chain = name_of(0);         // the node-name chain the reference prints piece by piece
+    view_of(name_of(0), seq, size);
+    scaffold.push(cut(seq, size, (ulong) p_.edges_[0]->t_end + 1, size, false));
     for (size_t k = 1; k < n_edges; k++) {
         const OverlapGraph::Edge &arriving = *p_.edges_[k - 1], &leaving = *p_.edges_[k];
         const ulong from = leaving.t_end, to = arriving.q_end;
         if (from < to) {
-            std::string piece = substring(getSequenceFrom(name_of(k)), from + 1, to);
-            if (arriving.relative_strand) swapBases(piece);
-            std::cout << '-' << name_of(k);
-            scaffold.push(std::move(piece));
+            view_of(name_of(k), seq, size);
+            chain += '-';
+            chain += name_of(k);
+            scaffold.push(cut(seq, size, from + 1, to, arriving.relative_strand));
         } else if (from > to) {
             scaffold.drop_last(from - to);
         }
     }
-    std::cout << '-' << name_of(n_nodes - 1) << std::endl;
-    scaffold.push(substring(getSequenceFrom(name_of(n_nodes - 1)), 0, p_.edges_[n_edges - 1]->q_end));
+    chain += '-';
+    chain += name_of(n_nodes - 1);
+    std::cout << chain << std::endl;
+    view_of(name_of(n_nodes - 1), seq, size);
+    scaffold.push(cut(seq, size, 0, p_.edges_[n_edges - 1]->q_end, false));
     scaffold.write_newest_first(out);
     out << std::endl;
     return true;
