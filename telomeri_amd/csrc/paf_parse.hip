@@ -19,7 +19,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -384,9 +387,16 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
     const auto t0 = std::chrono::steady_clock::now();
     int rc = tlm_pool_alloc((void **) &p->text[f], bytes + 64, s);
     if (rc == TLM_OK && bytes) {
-        // pinned slabs filled by parallel preads (the page cache copies at memory speed), H2D copies behind them
-        constexpr size_t SLAB = 128u << 20;
-        constexpr int N_SLABS = 3, READERS = 8;
+        // pinned slabs filled by parallel preads (the page cache copies at memory speed), H2D copies behind them:
+        // the readers of slab k+1 work while slab k crosses PCIe
+        constexpr size_t SLAB = 256u << 20, PIECE = 4u << 20;
+        constexpr int N_SLABS = 3;
+        unsigned readers = std::thread::hardware_concurrency();
+        {
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) readers = std::min<unsigned>(readers ? readers : 1, (unsigned) CPU_COUNT(&set));
+        }
+        readers = std::max(1u, std::min(readers, 32u));
         char *slab[N_SLABS] = {nullptr, nullptr, nullptr};
         hipEvent_t done[N_SLABS] = {nullptr, nullptr, nullptr};
         bool ok = true;
@@ -397,21 +407,24 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
         for (int k = 0; ok && at < bytes; k = (k + 1) % N_SLABS) {
             const size_t len = (size_t) std::min<uint64_t>(SLAB, bytes - at);
             ok = hipEventSynchronize(done[k]) == hipSuccess;        // the slab's previous copy has left it
-            std::vector<std::thread> th;
-            bool read_ok[READERS];
-            for (int t = 0; t < READERS; t++)
-                th.emplace_back([&, t] {
-                    size_t a = len * (size_t) t / READERS, b = len * (size_t) (t + 1) / READERS;
-                    read_ok[t] = true;
+            std::atomic<size_t> next{0};
+            std::atomic<bool> read_ok{true};
+            auto work = [&] {
+                for (size_t a = next.fetch_add(PIECE); a < len; a = next.fetch_add(PIECE)) {
+                    size_t b = std::min(len, a + PIECE);
                     while (a < b) {
                         const ssize_t got = ::pread(fd, slab[k] + a, b - a, (off_t) (at + a));
-                        if (got <= 0) { read_ok[t] = false; break; }
+                        if (got <= 0) { read_ok = false; return; }
                         a += (size_t) got;
                     }
-                });
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < readers; t++) th.emplace_back(work);
+            work();
             for (auto &x : th) x.join();
-            for (int t = 0; t < READERS; t++) ok = ok && read_ok[t];
-            ok = ok && hipMemcpyAsync(p->text[f] + at, slab[k], len, hipMemcpyHostToDevice, s) == hipSuccess
+            ok = ok && read_ok.load()
+                 && hipMemcpyAsync(p->text[f] + at, slab[k], len, hipMemcpyHostToDevice, s) == hipSuccess
                  && hipEventRecord(done[k], s) == hipSuccess;
             at += len;
         }

@@ -150,7 +150,13 @@ int main(int argc, char **argv) {
                            {2, false, Utils::Metrics::EXTENSION_SCORE}, {3, false, Utils::Metrics::OVERLAP_SCORE}};
     uint64_t evals = 0;
     double kernel_ms = 0;
+    if (!out) {     // the four builder calls of Main.cpp:237-243 as one device call (same paths_, same log lines)
+        pm.buildAll(graph, Utils::Metrics::EXTENSION_SCORE, Utils::Metrics::OVERLAP_SCORE);
+        evals += pm.last_counters.evals;
+        kernel_ms += pm.last_counters.kernel_ms;
+    }
     for (const B &b : builders) {                                                     // Main.cpp:237-243
+        if (!out) break;        // (--dump wants the builders one by one, to write a section after each)
         const size_t before = pm.paths().size();
         if (b.mc) pm.buildMonteCarlo(graph, b.m);
         else pm.buildDeterministic(graph, b.m);

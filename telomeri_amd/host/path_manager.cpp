@@ -108,6 +108,48 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
     std::cout << "Found " << n_paths << " paths." << std::endl;      // PathManager.cpp:172,387
 }
 
+void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, const Utils::Metrics &mb) {
+    tlm_ctx *ctx = OverlapGraph::context();
+    tlm_graph *dg = g.device_graph();
+    if (!dg) {
+        std::cerr << "PathManager: the graph has not been loaded" << std::endl;
+        std::exit(1);
+    }
+    tlm_walk_params wp{params_.rebuild_attempts, params_.backtrack_attempts, params_.len_threshold};
+    uint64_t mc0 = 0, mc1 = tlm_mc_units(dg, &wp), d0 = 0, d1 = tlm_det_units(dg);
+    if (tlm_dist_world(ctx) > 1) {
+        uint32_t a0 = 0, a1 = 0;
+        if (tlm_dist_anchor_range(dg, tlm_dist_rank(ctx), tlm_dist_world(ctx), &a0, &a1) != TLM_OK) die_tlm("anchor range");
+        tlm_graph_info gi;
+        tlm_graph_get_info(dg, &gi);
+        std::vector<uint64_t> det_off((size_t) gi.n_anchors + 1);
+        if (tlm_graph_anchor_table(dg, nullptr, det_off.data()) != TLM_OK) die_tlm("anchor table");
+        mc0 = (uint64_t) a0 * (uint64_t) std::max(params_.rebuild_attempts, 0);
+        mc1 = (uint64_t) a1 * (uint64_t) std::max(params_.rebuild_attempts, 0);
+        d0 = det_off[a0];
+        d1 = det_off[a1];
+    }
+    tlm_pathset *sets[4] = {nullptr, nullptr, nullptr, nullptr};
+    tlm_counters c[4];
+    if (tlm_walk_builders(ctx, dg, (int) ma, (int) mb, &wp, mc0, mc1, d0, d1, sets, c) != TLM_OK) die_tlm("walk");
+    graph_ = &g;
+    last_counters = Counters{0, 0, 0, 0, 0, 0.0};
+    const Utils::Metrics metric_of[4] = {ma, mb, ma, mb};
+    for (int k = 0; k < 4; k++) {
+        std::cout << (k < 2 ? "> Monte Carlo heuristic: " : "> Deterministic heuristic: ") << Utils::getMetricName(metric_of[k])
+                  << std::endl;                                                 // PathManager.cpp:16,183
+        uint64_t n_paths = 0;
+        tlm_pathset_sizes(sets[k], &n_paths, nullptr, nullptr);
+        append_from(g, sets[k]);
+        dev_sets_.push_back(sets[k]);
+        std::cout << "Found " << n_paths << " paths." << std::endl;            // :172,387
+        last_counters.units += c[k].units; last_counters.steps += c[k].steps; last_counters.evals += c[k].evals;
+        last_counters.draws += c[k].draws; last_counters.accepted += c[k].accepted;
+        last_counters.kernel_ms += k < 2 ? c[k].kernel_ms : c[k].kernel_busy_ms;
+    }
+    if (!packed_) materialiseAll();
+}
+
 PathManager::~PathManager() {
     for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
 }

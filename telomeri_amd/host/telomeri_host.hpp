@@ -256,6 +256,10 @@ public:
     void buildMonteCarlo(const OverlapGraph &g, const Utils::Metrics &metric);
     /** PathManager.cpp:179-386 on the device. */
     void buildDeterministic(const OverlapGraph &g, const Utils::Metrics &metric);
+    /** Not in the reference: the four builder calls of main() (Main.cpp:237-243: buildMonteCarlo under `a` and `b`, then
+     *  buildDeterministic under `a` and `b`) as ONE device call (tlm_walk_builders: both metrics share a launch, the
+     *  deterministic launch fills the Monte-Carlo launch's tail).  Same paths_, same order, same log lines. */
+    void buildAll(const OverlapGraph &g, const Utils::Metrics &a, const Utils::Metrics &b);
     /** Not in the reference: the single exchange of a one-process-per-GPU job (every rank's paths -> every rank, in the
      *  order one PathManager would hold them); a no-op without TLM_WORLD > 1.  Between the builders and filterUnique. */
     void gather();
