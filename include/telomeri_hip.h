@@ -287,6 +287,9 @@ int tlm_pathset_concat(tlm_ctx *ctx, int n, tlm_pathset *const *sets, tlm_pathse
 /* PathManager::filterUnique (PathManager.cpp:432-438): std::unique with Path::operator== (Path.cpp:46-49: same
  * node sequence) -- only ADJACENT duplicates go, the first of a run stays. */
 int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tlm_pathset **out);
+/* The same, CONSUMING `in`: when there is no adjacent duplicate (the usual case) *out is `in` itself -- no second copy of
+ * a 10 GB Path set -- otherwise the filtered set, and `in` has been destroyed. */
+int tlm_pathset_filter_unique_take(tlm_ctx *ctx, tlm_pathset *in, tlm_pathset **out);
 /* PathManager::getPathsBetweenAnchors (PathManager.cpp:626-645): HOST buffers of n_paths entries each;
  * order[j] = path index, key[j] = (front node << 32) | back node, sorted by key (the std::map's order over
  * (front Node*, back Node*)), inside one key in path order.  A bucket is a run of equal keys. */

@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
     L.tlm_pathset_destroy.argtypes = [V]
     L.tlm_pathset_concat.argtypes = [V, C.c_int, P(V), P(V)]
     L.tlm_pathset_filter_unique.argtypes = [V, V, P(V)]
+    L.tlm_pathset_filter_unique_take.argtypes = [V, V, P(V)]
     L.tlm_pathset_anchor_pairs.argtypes = [V, V, V, V]
     L.tlm_pathset_summary.argtypes = [V, V, V, V, V, V]
     L.tlm_pathset_fetch.argtypes = [V, V, C.c_uint64, V, V, V]
@@ -252,6 +253,13 @@ class PathSet:
         """PathManager::filterUnique on the device."""
         h = C.c_void_p()
         _check(lib().tlm_pathset_filter_unique(self._ctx._h, self._h, C.byref(h)), "tlm_pathset_filter_unique")
+        return PathSet(h, self.counters, self._ctx)
+
+    def filter_unique_take(self) -> "PathSet":
+        """tlm_pathset_filter_unique_take: consumes this set (it is the result itself when nothing was dropped)."""
+        h = C.c_void_p()
+        _check(lib().tlm_pathset_filter_unique_take(self._ctx._h, self._h, C.byref(h)), "tlm_pathset_filter_unique_take")
+        self._h = None
         return PathSet(h, self.counters, self._ctx)
 
     def anchor_pairs(self):

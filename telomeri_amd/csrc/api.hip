@@ -513,11 +513,12 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         if (int rc = ensure_scratch(W, s, waves, cap, bm_words)) return rc;
         dirty.armed = true;
         // arena for the accepted paths: the worst case (every unit accepted at full buffer length) when that is small,
-        // else 4096 nodes per unit (the A. thaliana-shaped paths average 3500) -- a guess that the overflow re-run below
-        // corrects, and that tlm_ctx_set_arena_limit can cap (tests force the re-run with it)
+        // else 2048 nodes per unit (the A. thaliana-shaped walks leave 1630 accepted path nodes per unit: 3500 per path,
+        // 46 % accepted) -- a guess that the overflow re-run below corrects, and that tlm_ctx_set_arena_limit can cap
+        // (tests force the re-run with it).  Fresh device memory costs ~30 ms per GB to obtain: guessing high is not free.
         {
             const uint64_t worst = (uint64_t) n_all * cap;
-            uint64_t want = std::min<uint64_t>(worst, std::max<uint64_t>((uint64_t) n_all * 4096u, 1u << 20));
+            uint64_t want = std::min<uint64_t>(worst, std::max<uint64_t>((uint64_t) n_all * 2048u, 1u << 20));
             if (ctx->arena_limit) want = std::max<uint64_t>(64u, std::min<uint64_t>(want, ctx->arena_limit / sizeof(uint2)));
             if (int rc = ensure_arena(W, s, want, 0)) return rc;
         }

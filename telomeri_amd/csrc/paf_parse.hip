@@ -400,13 +400,21 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
         char *slab[N_SLABS] = {nullptr, nullptr, nullptr};
         hipEvent_t done[N_SLABS] = {nullptr, nullptr, nullptr};
         bool ok = true;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+        double t_pin = 0, t_wait = 0, t_read = 0;
+        auto tp = now();
         for (int k = 0; k < N_SLABS && ok; k++)
             ok = hipHostMalloc((void **) &slab[k], SLAB, hipHostMallocDefault) == hipSuccess
                  && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+        t_pin = ms_since(tp);
         uint64_t at = 0;
         for (int k = 0; ok && at < bytes; k = (k + 1) % N_SLABS) {
             const size_t len = (size_t) std::min<uint64_t>(SLAB, bytes - at);
+            tp = now();
             ok = hipEventSynchronize(done[k]) == hipSuccess;        // the slab's previous copy has left it
+            t_wait += ms_since(tp);
+            tp = now();
             std::atomic<size_t> next{0};
             std::atomic<bool> read_ok{true};
             auto work = [&] {
@@ -423,16 +431,25 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             for (unsigned t = 1; t < readers; t++) th.emplace_back(work);
             work();
             for (auto &x : th) x.join();
+            t_read += ms_since(tp);
             ok = ok && read_ok.load()
                  && hipMemcpyAsync(p->text[f] + at, slab[k], len, hipMemcpyHostToDevice, s) == hipSuccess
                  && hipEventRecord(done[k], s) == hipSuccess;
             at += len;
         }
+        tp = now();
         ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        t_wait += ms_since(tp);
+        tp = now();
         for (int k = 0; k < N_SLABS; k++) {
             if (done[k]) (void) hipEventDestroy(done[k]);
             if (slab[k]) (void) hipHostFree(slab[k]);
         }
+        t_pin += ms_since(tp);
+        if (getenv("TLM_HOST_TIMING"))
+            fprintf(stderr, "[host timing] text upload of %s: %u readers, pinned slabs %.0f ms, reads %.0f ms, waiting for copies "
+                            "%.0f ms, device allocation %.0f ms\n", path, readers, t_pin, t_read, t_wait,
+                    std::chrono::duration<double, std::milli>(tp - t0).count() - t_pin - t_read - t_wait);
         if (!ok) {
             tlm_set_error("tlm_paf_add_file: reading or uploading %s failed", path);
             rc = TLM_EHIP;

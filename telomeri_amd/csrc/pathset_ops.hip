@@ -188,6 +188,13 @@ __global__ __launch_bounds__(256) void fetch_kernel(uint64_t n, const uint64_t *
     }
 }
 
+__global__ void count_dropped_kernel(uint64_t n, const uint8_t *__restrict__ keep, uint32_t *__restrict__ dropped) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) c += keep[i] == 0;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(dropped, c);
+}
+
 unsigned blocks_for(uint64_t n, unsigned per) {
     uint64_t b = (n + per - 1) / per;
     return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(b, 256u * 16u));
@@ -258,6 +265,33 @@ extern "C" int tlm_pathset_filter_unique(tlm_ctx *ctx, const tlm_pathset *in, tl
     TLM_HIP(hipStreamSynchronize(s));
     TLM_HIP(hipGetLastError());
     *out = ps;
+    return TLM_OK;
+}
+
+extern "C" int tlm_pathset_filter_unique_take(tlm_ctx *ctx, tlm_pathset *in, tlm_pathset **out) {
+    TLM_CHECK(ctx && in && out && in->ctx == ctx, TLM_EINVAL, "tlm_pathset_filter_unique_take: bad argument");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = in->n_paths;
+    if (n > 1) {        // is there an adjacent duplicate at all?  (usually not: then the set is handed back as it is)
+        Tmp keep, cnt;
+        if (int rc = tlm_pool_alloc(&keep.p, n, s)) return rc;
+        if (int rc = tlm_pool_alloc(&cnt.p, 4, s)) return rc;
+        TLM_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
+        hipLaunchKernelGGL(dup_flags_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, in->off, in->nodes, (uint8_t *) keep.p);
+        hipLaunchKernelGGL(count_dropped_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, (const uint8_t *) keep.p, (uint32_t *) cnt.p);
+        uint32_t dropped = 0;
+        TLM_HIP(hipMemcpyAsync(&dropped, cnt.p, 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        if (dropped) {
+            if (int rc = tlm_pathset_filter_unique(ctx, in, out)) return rc;
+            tlm_pathset_destroy(in);
+            return TLM_OK;
+        }
+    }
+    in->n_units = 0;
+    in->stats.clear();
+    *out = in;
     return TLM_OK;
 }
 

@@ -298,11 +298,10 @@ void PathManager::filterUnique() {      // PathManager.cpp:432-438: ADJACENT dup
     tlm_pathset *all = single_set();
     if (!all) return;
     tlm_pathset *uniq = nullptr;
-    if (tlm_pathset_filter_unique(OverlapGraph::context(), all, &uniq) != TLM_OK) {
+    if (tlm_pathset_filter_unique_take(OverlapGraph::context(), all, &uniq) != TLM_OK) {      // consumes `all`
         std::cerr << "telomeri_hip: filterUnique failed: " << tlm_last_error() << std::endl;
         std::exit(1);
     }
-    tlm_pathset_destroy(all);
     dev_sets_.assign(1, uniq);
     paths_.clear();
     edge_pool_.clear();

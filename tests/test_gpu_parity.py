@@ -306,6 +306,11 @@ def test_filter_unique_and_anchor_pairs_on_device(ctx, name, mode):
     H.assert_paths_equal(duniq.filter_unique().to_host(), ouniq)
     empty = dg.walk_det(capi.METRIC_ES, 0, 0)
     assert empty.filter_unique().n_paths == 0 and empty.anchor_pairs() == []
+    # the consuming variant: the filtered set when something is dropped, the set itself when nothing is
+    H.assert_paths_equal(capi.PathSet.concat(dsets).filter_unique_take().to_host(), ouniq)
+    again = duniq.filter_unique_take()
+    H.assert_paths_equal(again.to_host(), ouniq)
+    assert empty.filter_unique_take().n_paths == 0
 
 
 def test_walk_overflow_reruns(ctx):
