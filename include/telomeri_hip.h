@@ -348,6 +348,25 @@ typedef struct {
  * *out: the sets of all ranks, builder by builder, inside a builder in rank order (= unit order); unit[i] carries the
  * builder in its top byte as tlm_pathset_concat does.  With world == 1 this IS tlm_pathset_concat. */
 int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *const *sets, tlm_pathset **out, tlm_exchange_info *info);
+/* The LAZY form of the exchange.  What the host stages read of EVERY path (Main.cpp:247-352: length, end nodes, equality)
+ * travels as a 45-byte summary in one ncclAllGather; node lists stay on the rank that built them and are broadcast by
+ * their owner when asked for.  `sets` as for tlm_pathset_allgather (they may be destroyed afterwards: the handle keeps
+ * this rank's paths).  world == 1: no communication. */
+typedef struct tlm_gathered tlm_gathered;
+int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathset *const *sets, tlm_gathered **out, tlm_exchange_info *info);
+void tlm_gathered_destroy(tlm_gathered *g);
+int tlm_gathered_sizes(const tlm_gathered *g, uint64_t *n_paths, uint64_t *n_local_paths);
+/* HOST arrays of n_paths entries (any may be NULL), in paths_ order (builder by builder, rank order inside): unit (builder
+ * in the top byte), Path::length(), first and last node, node count, hash of the node sequence (tlm_pathset_summary),
+ * owning rank, dup_of_prev = 1 iff the path has the node sequence of its predecessor IN THE SAME BLOCK (exact: compared
+ * where the paths are), block_first = 1 for the first path of a (rank, builder) block -- whose predecessor in paths_
+ * order lives elsewhere: PathManager::filterUnique (PathManager.cpp:432-438) settles those few through tlm_gathered_fetch
+ * when the two summaries coincide. */
+int tlm_gathered_export(const tlm_gathered *g, uint64_t *unit, int64_t *length, uint32_t *front, uint32_t *back,
+                        uint32_t *n_nodes, uint64_t *hash, uint32_t *owner, uint8_t *dup_of_prev, uint8_t *block_first);
+/* COLLECTIVE: every rank calls it with the SAME index list (positions in paths_ order); every rank receives the node and
+ * slot lists of those paths, concatenated in request order, in HOST buffers of sum(n_nodes[index[k]]) entries. */
+int tlm_gathered_fetch(tlm_ctx *ctx, const tlm_gathered *g, uint64_t n, const uint64_t *index, uint32_t *nodes, uint32_t *slots);
 /* The placement rule of that exchange, as host arithmetic: counts[(r * n_sets + b) * 2 + {0, 1}] = paths, nodes of rank
  * r's set b -> where that block starts in the result (same (r, b) indexing), and the result's totals[2]. */
 int tlm_exchange_layout(int world, int n_sets, const uint64_t *counts, uint64_t *path_base, uint64_t *node_base,

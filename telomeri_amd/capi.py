@@ -179,6 +179,12 @@ def lib() -> C.CDLL:
     L.tlm_dist_anchor_range.argtypes = [V, C.c_int, C.c_int, P(C.c_uint32), P(C.c_uint32)]
     L.tlm_pathset_allgather.argtypes = [V, C.c_int, P(V), P(V), P(ExchangeInfo)]
     L.tlm_exchange_layout.argtypes = [C.c_int, C.c_int, V, V, V, V]
+    L.tlm_pathset_gather_summaries.argtypes = [V, C.c_int, P(V), P(V), P(ExchangeInfo)]
+    L.tlm_gathered_destroy.argtypes = [V]
+    L.tlm_gathered_destroy.restype = None
+    L.tlm_gathered_sizes.argtypes = [V, P(C.c_uint64), P(C.c_uint64)]
+    L.tlm_gathered_export.argtypes = [V] + [V] * 9
+    L.tlm_gathered_fetch.argtypes = [V, V, C.c_uint64, V, V, V]
     _lib = L
     return L
 
@@ -575,6 +581,47 @@ class Context:
                                         _np_ptr(si), _np_ptr(es), _np_ptr(strand), _np_ptr(node_len), _np_ptr(node_anchor),
                                         C.byref(h)), "tlm_graph_from_csr")
         return Graph(self, h)
+
+
+class Gathered:
+    """tlm_pathset_gather_summaries: the lazy exchange -- summaries of every path of the job, node lists on demand."""
+
+    def __init__(self, sets):
+        self.ctx = sets[0]._ctx
+        arr = (C.c_void_p * len(sets))(*[s._h for s in sets])
+        h = C.c_void_p()
+        self.info = ExchangeInfo()
+        _check(lib().tlm_pathset_gather_summaries(self.ctx._h, len(sets), arr, C.byref(h), C.byref(self.info)),
+               "tlm_pathset_gather_summaries")
+        self._h = h
+        n, nl = C.c_uint64(), C.c_uint64()
+        _check(lib().tlm_gathered_sizes(self._h, C.byref(n), C.byref(nl)), "tlm_gathered_sizes")
+        self.n_paths, self.n_local_paths = int(n.value), int(nl.value)
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().tlm_gathered_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def export(self) -> dict:
+        n = self.n_paths
+        out = {"unit": np.zeros(n, np.uint64), "length": np.zeros(n, np.int64), "front": np.zeros(n, np.uint32),
+               "back": np.zeros(n, np.uint32), "n_nodes": np.zeros(n, np.uint32), "hash": np.zeros(n, np.uint64),
+               "owner": np.zeros(n, np.uint32), "dup_of_prev": np.zeros(n, np.uint8), "block_first": np.zeros(n, np.uint8)}
+        _check(lib().tlm_gathered_export(self._h, *[_np_ptr(out[k]) for k in (
+            "unit", "length", "front", "back", "n_nodes", "hash", "owner", "dup_of_prev", "block_first")]), "tlm_gathered_export")
+        return out
+
+    def fetch(self, index, n_nodes):
+        index = np.ascontiguousarray(index, np.uint64)
+        total = int(np.asarray(n_nodes)[index.astype(np.int64)].sum()) if index.size else 0
+        nodes, slots = np.zeros(total, np.uint32), np.zeros(total, np.uint32)
+        _check(lib().tlm_gathered_fetch(self.ctx._h, self._h, index.shape[0], _np_ptr(index), _np_ptr(nodes), _np_ptr(slots)),
+               "tlm_gathered_fetch")
+        return nodes, slots
 
 
 class PafTokens:

@@ -37,6 +37,7 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
 };
 
 RcclApi *rccl_api() {
@@ -66,6 +67,7 @@ RcclApi *rccl_api() {
     api.Recv = (decltype(api.Recv)) sym("ncclRecv");
     api.GroupStart = (decltype(api.GroupStart)) sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd)) sym("ncclGroupEnd");
+    api.Broadcast = (decltype(api.Broadcast)) sym("ncclBroadcast");
     if (!ok) {
         tlm_set_error("librccl.so.1 lacks an expected symbol");
         return nullptr;
@@ -386,5 +388,265 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
     }
     guard.p = nullptr;
     *out = ps;
+    return TLM_OK;
+}
+
+// ================================================================================================================
+// The LAZY form of the exchange.  The consumers of the gathered Path set (reference Main.cpp:247-352: filterUnique,
+// getPathsBetweenAnchors, PathGroup / PathWindow grouping, the consensus tournament) read of EVERY path its length, its
+// end nodes and whether it equals another path; node lists they need for the ~200 consensus paths the scaffold is made
+// of.  So what travels for every path is a 45-byte summary (unit, length, front, back, node count, 64-bit hash of the node
+// sequence, "equals its predecessor" flag -- exact, computed where the paths are), one ncclAllGather of a few MB; node
+// lists stay on the rank that built them and are broadcast by their owner when somebody asks (tlm_gathered_fetch, a
+// collective every rank joins with the same request).  A. thaliana config at N = 8: 2.1 MB per rank instead of 0.98 GB to
+// each of 7 peers.
+struct tlm_gathered {
+    tlm_ctx *ctx = nullptr;
+    int world = 1, rank = 0, n_sets = 0;
+    tlm_pathset *local = nullptr;           // this rank's sets, concatenated (builder tags in `unit`)
+    std::vector<uint64_t> counts;           // [world][n_sets][2]
+    // every path of the job, in paths_ order (builder by builder, rank order inside)
+    std::vector<uint64_t> unit, hash, local_index;      // local_index: position inside the owner's concatenated set
+    std::vector<int64_t> length;
+    std::vector<uint32_t> front, back, n_nodes, owner;
+    std::vector<uint8_t> dup, block_first;
+};
+
+namespace {
+
+struct SummaryRow {         // one path on the wire (SoA on the device, this is only the byte budget): 45 bytes
+    static constexpr size_t BYTES = 8 + 8 + 4 + 4 + 4 + 8 + 1;
+};
+
+}   // namespace
+
+extern "C" void tlm_gathered_destroy(tlm_gathered *g) {
+    if (!g) return;
+    tlm_pathset_destroy(g->local);
+    delete g;
+}
+
+extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathset *const *sets, tlm_gathered **out,
+                                            tlm_exchange_info *info) {
+    TLM_CHECK(ctx && sets && out && n_sets >= 1 && n_sets <= 8, TLM_EINVAL, "tlm_pathset_gather_summaries: bad argument");
+    const int world = ctx->world, rank = ctx->rank;
+    TLM_CHECK(world * n_sets <= TLM_EXCHANGE_MAX_BLOCKS, TLM_ELIMIT, "tlm_pathset_gather_summaries: %d blocks", world * n_sets);
+    const bool single = world == 1 && !(ctx->comm && getenv("TLM_EXCHANGE_SELFTEST"));
+    RcclApi *api = single ? nullptr : rccl_api();
+    if (!single && !api) return TLM_EHIP;
+    TLM_CHECK(single || ctx->comm, TLM_EINVAL, "tlm_pathset_gather_summaries: tlm_dist_init has not been called");
+    if (info) std::memset(info, 0, sizeof(*info));
+    const auto t_wall = std::chrono::steady_clock::now();
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TLM_HIP(hipEventRecord(ctx->ev0, s));
+    tlm_gathered *g = new tlm_gathered();
+    struct Guard {
+        tlm_gathered *p;
+        ~Guard() { tlm_gathered_destroy(p); }
+    } guard{g};
+    g->ctx = ctx;
+    g->world = world;
+    g->rank = rank;
+    g->n_sets = n_sets;
+    if (int rc = tlm_pathset_concat(ctx, n_sets, sets, &g->local)) return rc;
+    const uint64_t mine = g->local->n_paths;
+
+    // ---- sizes: (paths, nodes) of every block
+    const size_t per_rank = (size_t) n_sets * 2;
+    std::vector<uint64_t> my_counts(per_rank);
+    g->counts.assign(per_rank * world, 0);
+    for (int b = 0; b < n_sets; b++) {
+        my_counts[2 * b] = sets[b]->n_paths;
+        my_counts[2 * b + 1] = sets[b]->n_nodes_total;
+    }
+    if (single) {
+        g->counts = my_counts;
+    } else {
+        Tmp d_mine, d_all;
+        if (int rc = tlm_pool_alloc(&d_mine.p, per_rank * 8, s)) return rc;
+        if (int rc = tlm_pool_alloc(&d_all.p, per_rank * 8 * world, s)) return rc;
+        TLM_HIP(hipMemcpyAsync(d_mine.p, my_counts.data(), per_rank * 8, hipMemcpyHostToDevice, s));
+        TLM_NCCL(api, api->AllGather(d_mine.p, d_all.p, per_rank, ncclUint64, (ncclComm_t) ctx->comm, s));
+        TLM_HIP(hipMemcpyAsync(g->counts.data(), d_all.p, per_rank * 8 * world, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+    }
+    uint64_t max_paths = 0;
+    std::vector<uint64_t> rank_paths(world, 0);
+    for (int r = 0; r < world; r++) {
+        for (int b = 0; b < n_sets; b++) rank_paths[r] += g->counts[(size_t) r * per_rank + 2 * b];
+        max_paths = std::max(max_paths, rank_paths[r]);
+    }
+    TLM_CHECK(rank_paths[rank] == mine, TLM_EINTERNAL, "tlm_pathset_gather_summaries: local count mismatch");
+
+    // ---- summaries: this rank's columns, padded to the longest rank, one all-gather
+    // slab of a rank: [unit u64 x P][length i64 x P][hash u64 x P][front u32 x P][back u32 x P][n_nodes u32 x P][dup u8 x P]
+    const uint64_t P = std::max<uint64_t>(max_paths, 1);
+    const size_t slab = (size_t) P * SummaryRow::BYTES;
+    Tmp d_slab, d_allslabs;
+    if (int rc = tlm_pool_alloc(&d_slab.p, slab, s)) return rc;
+    if (int rc = tlm_pool_alloc(&d_allslabs.p, slab * world, s)) return rc;
+    char *base = (char *) d_slab.p;
+    uint64_t *d_unit = (uint64_t *) base;
+    int64_t *d_len = (int64_t *) (base + 8 * P);
+    uint64_t *d_hash = (uint64_t *) (base + 16 * P);
+    uint32_t *d_front = (uint32_t *) (base + 24 * P), *d_back = (uint32_t *) (base + 28 * P), *d_cnt = (uint32_t *) (base + 32 * P);
+    uint8_t *d_dup = (uint8_t *) (base + 36 * P);
+    TLM_HIP(hipMemsetAsync(base, 0, slab, s));
+    if (mine) {
+        TLM_HIP(hipMemcpyAsync(d_unit, g->local->unit, mine * 8, hipMemcpyDeviceToDevice, s));
+        TLM_HIP(hipMemcpyAsync(d_len, g->local->length, mine * 8, hipMemcpyDeviceToDevice, s));
+        if (int rc = tlm_pathset_summary_dev(g->local, s, d_front, d_back, d_cnt, d_hash, d_dup)) return rc;
+    }
+    std::vector<char> h_all(slab * world);
+    if (single) {
+        TLM_HIP(hipMemcpyAsync(h_all.data(), d_slab.p, slab, hipMemcpyDeviceToHost, s));
+    } else {
+        TLM_NCCL(api, api->AllGather(d_slab.p, d_allslabs.p, slab, ncclUint8, (ncclComm_t) ctx->comm, s));
+        TLM_HIP(hipMemcpyAsync(h_all.data(), d_allslabs.p, slab * world, hipMemcpyDeviceToHost, s));
+    }
+    TLM_HIP(hipEventRecord(ctx->ev1, s));
+    TLM_HIP(hipStreamSynchronize(s));
+
+    // ---- paths_ order on the host: builder by builder, rank order inside
+    uint64_t total = 0;
+    for (int r = 0; r < world; r++) total += rank_paths[r];
+    g->unit.resize(total); g->hash.resize(total); g->local_index.resize(total); g->length.resize(total);
+    g->front.resize(total); g->back.resize(total); g->n_nodes.resize(total); g->owner.resize(total);
+    g->dup.resize(total); g->block_first.assign(total, 0);
+    uint64_t at = 0;
+    for (int b = 0; b < n_sets; b++)
+        for (int r = 0; r < world; r++) {
+            const char *rb = h_all.data() + slab * r;
+            uint64_t first = 0;                 // position of block b inside rank r's concatenated set
+            for (int bb = 0; bb < b; bb++) first += g->counts[(size_t) r * per_rank + 2 * bb];
+            const uint64_t np = g->counts[(size_t) r * per_rank + 2 * b];
+            for (uint64_t i = 0; i < np; i++, at++) {
+                const uint64_t k = first + i;
+                std::memcpy(&g->unit[at], rb + 8 * k, 8);
+                std::memcpy(&g->length[at], rb + 8 * P + 8 * k, 8);
+                std::memcpy(&g->hash[at], rb + 16 * P + 8 * k, 8);
+                std::memcpy(&g->front[at], rb + 24 * P + 4 * k, 4);
+                std::memcpy(&g->back[at], rb + 28 * P + 4 * k, 4);
+                std::memcpy(&g->n_nodes[at], rb + 32 * P + 4 * k, 4);
+                g->dup[at] = (uint8_t) rb[36 * P + k];
+                g->owner[at] = (uint32_t) r;
+                g->local_index[at] = k;
+                if (i == 0) {                   // its predecessor in paths_ order lives in another block: decided by the
+                    g->block_first[at] = 1;     // caller through tlm_gathered_fetch when the summaries coincide
+                    g->dup[at] = 0;
+                }
+            }
+        }
+    if (info) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        info->device_ms = ms;
+        info->bytes_sent = single ? 0 : (uint64_t) (slab + per_rank * 8) * (uint64_t) (world - 1);
+        info->bytes_received = info->bytes_sent;
+        info->slot_bits = 0;
+        info->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
+    }
+    guard.p = nullptr;
+    *out = g;
+    return TLM_OK;
+}
+
+extern "C" int tlm_gathered_sizes(const tlm_gathered *g, uint64_t *n_paths, uint64_t *n_local_paths) {
+    TLM_CHECK(g, TLM_EINVAL, "tlm_gathered_sizes: null argument");
+    if (n_paths) *n_paths = g->unit.size();
+    if (n_local_paths) *n_local_paths = g->local->n_paths;
+    return TLM_OK;
+}
+
+extern "C" int tlm_gathered_export(const tlm_gathered *g, uint64_t *unit, int64_t *length, uint32_t *front, uint32_t *back,
+                                   uint32_t *n_nodes, uint64_t *hash, uint32_t *owner, uint8_t *dup_of_prev,
+                                   uint8_t *block_first) {
+    TLM_CHECK(g, TLM_EINVAL, "tlm_gathered_export: null argument");
+    const size_t n = g->unit.size();
+    auto put = [n](void *dst, const void *src, size_t elem) { if (dst && n) std::memcpy(dst, src, n * elem); };
+    put(unit, g->unit.data(), 8); put(length, g->length.data(), 8); put(front, g->front.data(), 4); put(back, g->back.data(), 4);
+    put(n_nodes, g->n_nodes.data(), 4); put(hash, g->hash.data(), 8); put(owner, g->owner.data(), 4);
+    put(dup_of_prev, g->dup.data(), 1); put(block_first, g->block_first.data(), 1);
+    return TLM_OK;
+}
+
+// COLLECTIVE: every rank calls it with the same `index` list (positions in paths_ order).  For every owner that appears
+// in the list: the owner gathers the requested node / slot lists out of its set into a staging buffer and broadcasts it
+// (sizes are known to everybody from the summaries); everybody ends up with all requested lists, in request order.
+extern "C" int tlm_gathered_fetch(tlm_ctx *ctx, const tlm_gathered *g, uint64_t n, const uint64_t *index, uint32_t *nodes_host,
+                                  uint32_t *slots_host) {
+    TLM_CHECK(ctx && g && g->ctx == ctx && (n == 0 || index), TLM_EINVAL, "tlm_gathered_fetch: bad argument");
+    if (!n) return TLM_OK;
+    const uint64_t total_paths = g->unit.size();
+    for (uint64_t k = 0; k < n; k++)
+        TLM_CHECK(index[k] < total_paths, TLM_EINVAL, "tlm_gathered_fetch: path %llu of %llu", (unsigned long long) index[k],
+                  (unsigned long long) total_paths);
+    const int world = g->world, rank = g->rank;
+    const bool single = world == 1 && !(ctx->comm && getenv("TLM_EXCHANGE_SELFTEST"));
+    RcclApi *api = single ? nullptr : rccl_api();
+    if (!single && !api) return TLM_EHIP;
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // staging layout: owner by owner, inside an owner in request order
+    std::vector<uint64_t> dst(n + 1, 0);            // where request k lies in the staging buffer
+    std::vector<uint64_t> owner_begin(world + 1, 0);
+    std::vector<std::vector<uint64_t>> req_of(world);
+    for (uint64_t k = 0; k < n; k++) req_of[g->owner[index[k]]].push_back(k);
+    uint64_t at = 0;
+    for (int o = 0; o < world; o++) {
+        owner_begin[o] = at;
+        for (uint64_t k : req_of[o]) {
+            dst[k] = at;
+            at += g->n_nodes[index[k]];
+        }
+    }
+    owner_begin[world] = at;
+    const uint64_t total = at;
+    Tmp st_nodes, st_slots, d_idx, d_dst;
+    if (int rc = tlm_pool_alloc(&st_nodes.p, (total ? total : 1) * 4, s)) return rc;
+    if (int rc = tlm_pool_alloc(&st_slots.p, (total ? total : 1) * 4, s)) return rc;
+    const std::vector<uint64_t> &mine = req_of[rank];
+    if (!mine.empty()) {
+        std::vector<uint64_t> li(mine.size()), ld(mine.size() + 1);
+        for (size_t j = 0; j < mine.size(); j++) {
+            li[j] = g->local_index[index[mine[j]]];
+            ld[j] = dst[mine[j]];
+        }
+        ld[mine.size()] = owner_begin[rank + 1];
+        if (int rc = tlm_pool_alloc(&d_idx.p, li.size() * 8, s)) return rc;
+        if (int rc = tlm_pool_alloc(&d_dst.p, ld.size() * 8, s)) return rc;
+        TLM_HIP(hipMemcpyAsync(d_idx.p, li.data(), li.size() * 8, hipMemcpyHostToDevice, s));
+        TLM_HIP(hipMemcpyAsync(d_dst.p, ld.data(), ld.size() * 8, hipMemcpyHostToDevice, s));
+        if (int rc = tlm_pathset_gather_dev(g->local, s, li.size(), (const uint64_t *) d_idx.p, (const uint64_t *) d_dst.p,
+                                            (uint32_t *) st_nodes.p, (uint32_t *) st_slots.p))
+            return rc;
+        TLM_HIP(hipStreamSynchronize(s));       // li / ld go out of scope
+    }
+    if (!single) {
+        TLM_NCCL(api, api->GroupStart());
+        for (int o = 0; o < world; o++) {
+            const uint64_t len = owner_begin[o + 1] - owner_begin[o];
+            if (!len) continue;
+            uint32_t *pn = (uint32_t *) st_nodes.p + owner_begin[o], *psl = (uint32_t *) st_slots.p + owner_begin[o];
+            TLM_NCCL(api, api->Broadcast(pn, pn, len * 4, ncclUint8, o, (ncclComm_t) ctx->comm, s));
+            TLM_NCCL(api, api->Broadcast(psl, psl, len * 4, ncclUint8, o, (ncclComm_t) ctx->comm, s));
+        }
+        TLM_NCCL(api, api->GroupEnd());
+    }
+    std::vector<uint32_t> hn(total), hs(total);
+    if (total) {
+        TLM_HIP(hipMemcpyAsync(hn.data(), st_nodes.p, total * 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(hs.data(), st_slots.p, total * 4, hipMemcpyDeviceToHost, s));
+    }
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    uint64_t out_at = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        const uint64_t len = g->n_nodes[index[k]];
+        if (nodes_host && len) std::memcpy(nodes_host + out_at, hn.data() + dst[k], len * 4);
+        if (slots_host && len) std::memcpy(slots_host + out_at, hs.data() + dst[k], len * 4);
+        out_at += len;
+    }
     return TLM_OK;
 }

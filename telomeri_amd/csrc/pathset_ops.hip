@@ -195,6 +195,10 @@ __global__ void count_dropped_kernel(uint64_t n, const uint8_t *__restrict__ kee
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(dropped, c);
 }
 
+__global__ void invert_flags_kernel(uint64_t n, uint8_t *__restrict__ f) {       // keep (1 = differs) -> dup (1 = equal)
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) f[i] = f[i] ? 0 : 1;
+}
+
 unsigned blocks_for(uint64_t n, unsigned per) {
     uint64_t b = (n + per - 1) / per;
     return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(b, 256u * 16u));
@@ -374,6 +378,30 @@ extern "C" int tlm_pathset_fetch(tlm_ctx *ctx, const tlm_pathset *ps, uint64_t n
     if (nodes && total) TLM_HIP(hipMemcpyAsync(nodes, o_n.p, total * 4, hipMemcpyDeviceToHost, s));
     if (slots && total) TLM_HIP(hipMemcpyAsync(slots, o_s.p, total * 4, hipMemcpyDeviceToHost, s));
     TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    return TLM_OK;
+}
+
+// ---- internal (exchange.hip): the same on device buffers ------------------------------------------------------
+// Summary columns of `ps` into DEVICE arrays of n_paths entries; dup[i] = 1 iff path i has the node sequence of path
+// i - 1 (exact, dup_flags_kernel).
+int tlm_pathset_summary_dev(const tlm_pathset *ps, hipStream_t s, uint32_t *front, uint32_t *back, uint32_t *n_nodes,
+                            uint64_t *hash, uint8_t *dup) {
+    const uint64_t n = ps->n_paths;
+    if (!n) return TLM_OK;
+    hipLaunchKernelGGL(summary_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, ps->off, ps->nodes, front, back, n_nodes, hash);
+    hipLaunchKernelGGL(dup_flags_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, ps->off, ps->nodes, dup);
+    hipLaunchKernelGGL(invert_flags_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, dup);
+    TLM_HIP(hipGetLastError());
+    return TLM_OK;
+}
+
+// Paths index[0..n) (DEVICE) of `ps` -> DEVICE buffers at dst_off[k] (DEVICE, n + 1 entries).
+int tlm_pathset_gather_dev(const tlm_pathset *ps, hipStream_t s, uint64_t n, const uint64_t *index_dev, const uint64_t *dst_off_dev,
+                           uint32_t *nodes_dev, uint32_t *slots_dev) {
+    if (!n) return TLM_OK;
+    hipLaunchKernelGGL(fetch_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, index_dev, dst_off_dev, ps->off, ps->nodes,
+                       ps->slots, nodes_dev, slots_dev);
     TLM_HIP(hipGetLastError());
     return TLM_OK;
 }

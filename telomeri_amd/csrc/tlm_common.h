@@ -111,6 +111,12 @@ void tlm_pool_trim(int device);                              // return every cac
 void tlm_pool_info(int device, tlm_memory_info *out);
 double tlm_pool_thread_malloc_ms();                          // host time this thread has spent in hipMalloc so far
 
+// path-set helpers on device buffers (pathset_ops.hip), for the exchange
+int tlm_pathset_summary_dev(const tlm_pathset *ps, hipStream_t s, uint32_t *front, uint32_t *back, uint32_t *n_nodes,
+                            uint64_t *hash, uint8_t *dup);
+int tlm_pathset_gather_dev(const tlm_pathset *ps, hipStream_t s, uint64_t n, const uint64_t *index_dev, const uint64_t *dst_off_dev,
+                           uint32_t *nodes_dev, uint32_t *slots_dev);
+
 // graph build (csr_build.hip)
 int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g);   // node_flags, anchors, det_off, info
 

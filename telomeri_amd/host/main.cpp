@@ -174,7 +174,9 @@ int main(int argc, char **argv) {
         }
     }
     pm.gather();                    // multi-GPU jobs: the one exchange (nothing happens in a one-process job)
-    if (tlm_dist_rank(OverlapGraph::context()) != 0) return 0;     // every rank holds all paths now; rank 0 finishes the job
+    // Every rank now knows every path (summaries; node lists come from their owners on demand, collectively): all ranks
+    // run the same host stages below, rank 0 keeps the scaffold file.
+    const bool keeps_output = tlm_dist_rank(OverlapGraph::context()) == 0;
     pm.filterUnique();                                                                // Main.cpp:247
     auto pba = pm.getPathsBetweenAnchors();                                           // Main.cpp:251-252
     if (out) {
@@ -199,7 +201,8 @@ int main(int argc, char **argv) {
     std::cout << "Anchor pairs with paths: " << pba.size() << std::endl;
     if (no_scaffold) return 0;
     const auto t_total = std::chrono::steady_clock::now();
-    const int rc = run_post_stages(pm, pba, pos[2], pos[3], pos[4]);              // Main.cpp:254-388
+    static char dev_null[] = "/dev/null";
+    const int rc = run_post_stages(pm, pba, pos[2], pos[3], keeps_output ? pos[4] : dev_null);     // Main.cpp:254-388
     std::cout << "Host stages after the path build: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_total).count()
               << "s" << std::endl;
     return rc;

@@ -50,16 +50,50 @@ static void die_tlm(const char *what) {
 // job on every rank, in the reference's order (tlm_pathset_allgather).  Call after the builders, before filterUnique.
 void PathManager::gather() {
     tlm_ctx *ctx = OverlapGraph::context();
-    if (tlm_dist_world(ctx) <= 1 || dev_sets_.empty()) return;
-    tlm_pathset *all = nullptr;
+    // (TLM_FORCE_GATHER: a one-process job goes through the gathered representation too -- what tests on one GPU can reach)
+    if ((tlm_dist_world(ctx) <= 1 && !std::getenv("TLM_FORCE_GATHER")) || dev_sets_.empty()) return;
+    const char *mode = std::getenv("TLM_EXCHANGE");
     tlm_exchange_info xi{};
-    if (tlm_pathset_allgather(ctx, (int) dev_sets_.size(), dev_sets_.data(), &all, &xi) != TLM_OK) die_tlm("allgather");
-    for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
-    dev_sets_.assign(1, all);
-    paths_.clear();
-    edge_pool_.clear();
-    append_from(*graph_, all);
-    if (!packed_) materialiseAll();
+    if (mode && std::string(mode) == "full") {      // every node list to every rank (tlm_pathset_allgather)
+        tlm_pathset *all = nullptr;
+        if (tlm_pathset_allgather(ctx, (int) dev_sets_.size(), dev_sets_.data(), &all, &xi) != TLM_OK) die_tlm("allgather");
+        for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
+        dev_sets_.assign(1, all);
+        paths_.clear();
+        edge_pool_.clear();
+        append_from(*graph_, all);
+        if (!packed_) materialiseAll();
+    } else {            // summaries to every rank, node lists on demand: every rank goes on to run the same host stages
+        if (tlm_pathset_gather_summaries(ctx, (int) dev_sets_.size(), dev_sets_.data(), &gathered_, &xi) != TLM_OK)
+            die_tlm("gather_summaries");
+        for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
+        dev_sets_.clear();
+        uint64_t n = 0;
+        tlm_gathered_sizes(gathered_, &n, nullptr);
+        std::vector<int64_t> length(n);
+        std::vector<uint32_t> front(n), back(n), count(n);
+        std::vector<uint64_t> hash(n);
+        gathered_dup_.assign(n, 0);
+        gathered_block_first_.assign(n, 0);
+        if (tlm_gathered_export(gathered_, nullptr, length.data(), front.data(), back.data(), count.data(), hash.data(), nullptr,
+                                gathered_dup_.data(), gathered_block_first_.data()) != TLM_OK)
+            die_tlm("gathered export");
+        paths_.clear();
+        edge_pool_.clear();
+        paths_.resize(n);
+        for (uint64_t i = 0; i < n; i++) {
+            Path &p = paths_[i];
+            p.owner_ = this;
+            p.index_ = i;
+            p.hash_ = hash[i];
+            p.front_ = front[i];
+            p.back_ = back[i];
+            p.n_nodes_ = count[i];
+            p.have_nodes_ = false;
+            p.setLength((long) length[i]);
+        }
+        if (!packed_) materialiseAll();
+    }
     std::cout << "Gathered " << paths_.size() << " paths from " << tlm_dist_world(ctx) << " ranks (" << xi.bytes_sent
               << " bytes sent, " << xi.device_ms << " ms)." << std::endl;
 }
@@ -152,6 +186,7 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
 
 PathManager::~PathManager() {
     for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
+    if (gathered_) tlm_gathered_destroy(gathered_);
 }
 
 void PathManager::append_from(const OverlapGraph &g, tlm_pathset *ps) {
@@ -183,8 +218,21 @@ void PathManager::append_from(const OverlapGraph &g, tlm_pathset *ps) {
 
 void PathManager::materialise(const Path &p) const { materialise(std::vector<const Path *>{&p}); }
 
-void PathManager::materialise(const std::vector<const Path *> &want) const {
-    // requested paths by device set (paths_ = the sets one after the other), one fetch per set
+// node and slot lists of the paths `v` (all of this manager, none materialised yet), concatenated in that order
+void PathManager::fetch_lists(const std::vector<const Path *> &v, std::vector<uint32_t> &nodes, std::vector<uint32_t> &slots) const {
+    uint64_t total = 0;
+    for (const Path *p : v) total += p->n_nodes_;
+    nodes.assign(total, 0);
+    slots.assign(total, 0);
+    if (v.empty()) return;
+    if (gathered_) {        // from the owning ranks: a collective, every rank asks for the same paths at the same moment
+        std::vector<uint64_t> idx(v.size());
+        for (size_t j = 0; j < v.size(); j++) idx[j] = v[j]->index_;
+        if (tlm_gathered_fetch(OverlapGraph::context(), gathered_, idx.size(), idx.data(), nodes.data(), slots.data()) != TLM_OK)
+            die_tlm("gathered fetch");
+        return;
+    }
+    // from the device sets (paths_ = the sets one after the other): one fetch per set, results back in request order
     std::vector<uint64_t> set_end;
     uint64_t acc = 0;
     for (tlm_pathset *ps : dev_sets_) {
@@ -192,71 +240,84 @@ void PathManager::materialise(const std::vector<const Path *> &want) const {
         tlm_pathset_sizes(ps, &n, nullptr, nullptr);
         set_end.push_back(acc += n);
     }
-    std::vector<std::vector<const Path *>> by_set(dev_sets_.size());
-    for (const Path *p : want) {
-        if (p->have_nodes_ || p->owner_ != this) continue;
-        const size_t k = std::upper_bound(set_end.begin(), set_end.end(), p->index_) - set_end.begin();
+    std::vector<uint64_t> at(v.size() + 1, 0);
+    for (size_t j = 0; j < v.size(); j++) at[j + 1] = at[j] + v[j]->n_nodes_;
+    std::vector<std::vector<size_t>> by_set(dev_sets_.size());
+    for (size_t j = 0; j < v.size(); j++) {
+        const size_t k = std::upper_bound(set_end.begin(), set_end.end(), v[j]->index_) - set_end.begin();
         if (k >= dev_sets_.size()) {
-            std::cerr << "PathManager: path " << p->index_ << " is not in a device set" << std::endl;
+            std::cerr << "PathManager: path " << v[j]->index_ << " is not in a device set" << std::endl;
             std::exit(1);
         }
-        by_set[k].push_back(p);
+        by_set[k].push_back(j);
     }
-    const bool lean = graph_->lean();
     for (size_t k = 0; k < by_set.size(); k++) {
-        const std::vector<const Path *> &v = by_set[k];
-        if (v.empty()) continue;
+        if (by_set[k].empty()) continue;
         const uint64_t first = k ? set_end[k - 1] : 0;
-        std::vector<uint64_t> idx(v.size());
-        uint64_t total = 0;
-        for (size_t j = 0; j < v.size(); j++) {
-            idx[j] = v[j]->index_ - first;
-            total += v[j]->n_nodes_;
+        std::vector<uint64_t> idx;
+        uint64_t sub = 0;
+        for (size_t j : by_set[k]) {
+            idx.push_back(v[j]->index_ - first);
+            sub += v[j]->n_nodes_;
         }
-        std::vector<uint32_t> nodes(total), slots(total);
-        if (tlm_pathset_fetch(OverlapGraph::context(), dev_sets_[k], idx.size(), idx.data(), nodes.data(), slots.data()) != TLM_OK)
+        std::vector<uint32_t> sn(sub), ss(sub);
+        if (tlm_pathset_fetch(OverlapGraph::context(), dev_sets_[k], idx.size(), idx.data(), sn.data(), ss.data()) != TLM_OK)
             die_tlm("fetch");
-        std::vector<tlm_edge> fetched;
-        if (lean) {         // the Edge records of these paths, from the device CSR (nodes_[..].edges is empty)
-            std::vector<uint32_t> en, es;
-            en.reserve(total);
-            es.reserve(total);
-            uint64_t a = 0;
-            for (const Path *p : v) {
-                for (uint64_t j = 0; j + 1 < p->n_nodes_; j++) {
-                    en.push_back(nodes[a + j]);
-                    es.push_back(slots[a + j]);
-                }
-                a += p->n_nodes_;
-            }
-            fetched.resize(en.size());
-            if (tlm_graph_edges(graph_->device_graph(), en.size(), en.data(), es.data(), fetched.data()) != TLM_OK)
-                die_tlm("edge fetch");
+        uint64_t a = 0;
+        for (size_t j : by_set[k]) {
+            std::copy(sn.begin() + (long) a, sn.begin() + (long) (a + v[j]->n_nodes_), nodes.begin() + (long) at[j]);
+            std::copy(ss.begin() + (long) a, ss.begin() + (long) (a + v[j]->n_nodes_), slots.begin() + (long) at[j]);
+            a += v[j]->n_nodes_;
         }
-        uint64_t a = 0, fe = 0;
-        for (const Path *cp : v) {
-            Path &p = const_cast<Path &>(*cp);          // paths_ elements are ours; filling the lazy members is not a change
-            const uint64_t n = p.n_nodes_;
-            p.nodes_.resize(n);
-            p.edges_.resize(n ? n - 1 : 0);
-            for (uint64_t j = 0; j < n; j++) {
-                const OverlapGraph::Node *node = &graph_->nodes_[nodes[a + j]];
-                p.nodes_[j] = node;
-                if (j + 1 < n) {
-                    if (lean) {
-                        const tlm_edge &e = fetched[fe++];
-                        edge_pool_.push_back(OverlapGraph::Edge{e.q_index, e.t_index, e.q_start, e.q_end, e.t_start, e.t_end,
-                                                                e.overlap_score, e.sequence_identity, e.extension_score,
-                                                                e.relative_strand != 0});
-                        p.edges_[j] = &edge_pool_.back();
-                    } else {
-                        p.edges_[j] = &node->edges[slots[a + j]];
-                    }
+    }
+}
+
+void PathManager::materialise(const std::vector<const Path *> &want) const {
+    std::vector<const Path *> v;
+    for (const Path *p : want)
+        if (!p->have_nodes_ && p->owner_ == this && std::find(v.begin(), v.end(), p) == v.end()) v.push_back(p);
+    if (v.empty()) return;
+    std::vector<uint32_t> nodes, slots;
+    fetch_lists(v, nodes, slots);
+    const bool lean = graph_->lean();
+    std::vector<tlm_edge> fetched;
+    if (lean) {         // the Edge records of these paths, from the device CSR (nodes_[..].edges is empty)
+        std::vector<uint32_t> en, es;
+        uint64_t a = 0;
+        for (const Path *p : v) {
+            for (uint64_t j = 0; j + 1 < p->n_nodes_; j++) {
+                en.push_back(nodes[a + j]);
+                es.push_back(slots[a + j]);
+            }
+            a += p->n_nodes_;
+        }
+        fetched.resize(en.size());
+        if (tlm_graph_edges(graph_->device_graph(), en.size(), en.data(), es.data(), fetched.data()) != TLM_OK)
+            die_tlm("edge fetch");
+    }
+    uint64_t a = 0, fe = 0;
+    for (const Path *cp : v) {
+        Path &p = const_cast<Path &>(*cp);          // paths_ elements are ours; filling the lazy members is not a change
+        const uint64_t n = p.n_nodes_;
+        p.nodes_.resize(n);
+        p.edges_.resize(n ? n - 1 : 0);
+        for (uint64_t j = 0; j < n; j++) {
+            const OverlapGraph::Node *node = &graph_->nodes_[nodes[a + j]];
+            p.nodes_[j] = node;
+            if (j + 1 < n) {
+                if (lean) {
+                    const tlm_edge &e = fetched[fe++];
+                    edge_pool_.push_back(OverlapGraph::Edge{e.q_index, e.t_index, e.q_start, e.q_end, e.t_start, e.t_end,
+                                                            e.overlap_score, e.sequence_identity, e.extension_score,
+                                                            e.relative_strand != 0});
+                    p.edges_[j] = &edge_pool_.back();
+                } else {
+                    p.edges_[j] = &node->edges[slots[a + j]];
                 }
             }
-            a += n;
-            p.have_nodes_ = true;
         }
+        a += n;
+        p.have_nodes_ = true;
     }
 }
 
@@ -295,6 +356,38 @@ void PathManager::buildDeterministic(const OverlapGraph &g, const Utils::Metrics
 }
 
 void PathManager::filterUnique() {      // PathManager.cpp:432-438: ADJACENT duplicates only; on the device
+    if (gathered_) {
+        // Inside a (rank, builder) block the owner has compared neighbours exactly.  A block's first path follows a path
+        // of ANOTHER block (another rank, or another builder): when the two summaries coincide -- which needs two builders
+        // or two ranks to have produced the same walk back to back -- the node lists are fetched and compared.
+        const size_t n = paths_.size();
+        std::vector<uint8_t> drop(gathered_dup_);
+        std::vector<const Path *> suspects;
+        std::vector<size_t> suspect_at;
+        for (size_t i = 1; i < n; i++)
+            if (gathered_block_first_[i] && paths_[i].n_nodes_ == paths_[i - 1].n_nodes_ && paths_[i].hash_ == paths_[i - 1].hash_)
+                suspect_at.push_back(i);
+        for (size_t i : suspect_at) {
+            suspects.push_back(&paths_[i - 1]);
+            suspects.push_back(&paths_[i]);
+        }
+        if (!suspects.empty()) {
+            std::vector<uint32_t> nodes, slots;
+            fetch_lists(suspects, nodes, slots);
+            uint64_t a = 0;
+            for (size_t i : suspect_at) {
+                const uint64_t len = paths_[i].n_nodes_;
+                drop[i] = std::equal(nodes.begin() + (long) a, nodes.begin() + (long) (a + len), nodes.begin() + (long) (a + len));
+                a += 2 * len;
+            }
+        }
+        std::vector<Path> kept;
+        kept.reserve(n);
+        for (size_t i = 0; i < n; i++)
+            if (!drop[i]) kept.push_back(std::move(paths_[i]));
+        paths_.swap(kept);
+        return;
+    }
     tlm_pathset *all = single_set();
     if (!all) return;
     tlm_pathset *uniq = nullptr;
@@ -337,6 +430,10 @@ std::string PathManager::stats() {      // the report of PathManager.cpp:440-465
 std::map<std::pair<const OverlapGraph::Node *, const OverlapGraph::Node *>, std::vector<const Path *>>
 PathManager::getPathsBetweenAnchors() {  // PathManager.cpp:626-645: buckets by (front, back), each in paths_ order
     std::map<std::pair<const OverlapGraph::Node *, const OverlapGraph::Node *>, std::vector<const Path *>> out;
+    if (gathered_) {        // from the summaries, as the reference's loop does it
+        for (const Path &p : paths_) out[{&graph_->nodes_[p.front_], &graph_->nodes_[p.back_]}].push_back(&p);
+        return out;
+    }
     tlm_pathset *all = single_set();
     if (!all) return out;
     std::vector<uint32_t> order(paths_.size());

@@ -33,6 +33,7 @@ struct tlm_ctx;
 struct tlm_graph;
 struct tlm_pathset;
 struct tlm_paf;
+struct tlm_gathered;
 
 typedef unsigned int uint;
 typedef unsigned long ulong;
@@ -300,6 +301,11 @@ private:
     void append_from(const OverlapGraph &g, tlm_pathset *ps);   // Path objects (packed views) of a device set
     tlm_pathset *single_set();                                   // concatenation of dev_sets_ (owned by dev_sets_)
     bool packed_ = true;
+    // multi-GPU jobs after gather(): the summaries of every rank's paths (paths_ = views of them, Path::index_ = position
+    // in the gathered order); node lists are fetched from their owners, collectively, when somebody asks
+    tlm_gathered *gathered_ = nullptr;
+    std::vector<uint8_t> gathered_dup_, gathered_block_first_;
+    void fetch_lists(const std::vector<const Path *> &v, std::vector<uint32_t> &nodes, std::vector<uint32_t> &slots) const;
     // paths_ is the concatenation of dev_sets_ in order (Path::index_ = position in paths_); Edge records fetched for
     // the paths of a lean graph live here (a deque: pointers into it stay valid)
     mutable std::deque<OverlapGraph::Edge> edge_pool_;

@@ -498,6 +498,47 @@ def test_exchange_single_rank(ctx, monkeypatch):
     c2.dist_finalize()
 
 
+@pytest.mark.parametrize("selftest", [False, True])
+def test_lazy_exchange_single_rank(ctx, monkeypatch, selftest):
+    """tlm_pathset_gather_summaries / tlm_gathered_fetch on one GPU: the summaries are those of tlm_pathset_concat's set,
+    the duplicate flags are exact inside a builder block, fetched node lists equal the set's.  With a one-rank communicator
+    and TLM_EXCHANGE_SELFTEST the RCCL all-gathers and broadcasts really run."""
+    ds = H.quirks_dataset()                  # its contig<->contig edge makes whole runs of identical paths
+    c2 = capi.Context(0)
+    dg = H.device_graph(c2, ds, capi.FilterParams.default("min"))
+    wp = capi.WalkParams.default(rb_att=30, bt_att=5)
+    sets = list(dg.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp))
+    if selftest:
+        c2.dist_init(0, 1, capi.dist_unique_id())
+        monkeypatch.setenv("TLM_EXCHANGE_SELFTEST", "1")
+    want = capi.PathSet.concat(sets)
+    h = want.to_host()
+    front, back, count, hsh = want.summary()
+    g = capi.Gathered(sets)
+    assert g.n_paths == g.n_local_paths == len(h)
+    e = g.export()
+    np.testing.assert_array_equal(e["unit"], h.unit)
+    np.testing.assert_array_equal(e["length"], h.length)
+    for k, w in (("front", front), ("back", back), ("n_nodes", count), ("hash", hsh)):
+        np.testing.assert_array_equal(e[k], w, err_msg=k)
+    assert int(e["owner"].max()) == 0
+    off = h.off.astype(np.int64)
+    seqs = [h.nodes[off[i]:off[i + 1]].tobytes() for i in range(len(h))]
+    builder = (h.unit >> np.uint64(56)).astype(np.int64)
+    first = np.r_[True, builder[1:] != builder[:-1]]
+    nonempty = np.array([s.n_paths for s in sets]) > 0
+    np.testing.assert_array_equal(e["block_first"].astype(bool), first)
+    assert int(first.sum()) == int(nonempty.sum())
+    want_dup = np.array([(not first[i]) and seqs[i] == seqs[i - 1] for i in range(len(h))])
+    np.testing.assert_array_equal(e["dup_of_prev"].astype(bool), want_dup)
+    assert want_dup.any()
+    pick = np.array([len(h) - 1, 0, 5, 5, len(h) // 2], np.uint64)
+    nodes, slots = g.fetch(pick, e["n_nodes"])
+    np.testing.assert_array_equal(nodes, np.concatenate([h.nodes[off[i]:off[i + 1]] for i in pick.astype(np.int64)]))
+    np.testing.assert_array_equal(slots, np.concatenate([h.slots[off[i]:off[i + 1]] for i in pick.astype(np.int64)]))
+    assert (g.info.bytes_sent == 0) and (g.info.device_ms > 0)
+
+
 def _synthetic_csr(n_reads=400, deg=90, seed=0, wild=False):
     """A random graph handed over as CSR (tlm_graph_from_csr): degrees above one 64-lane chunk,
     optionally metrics whose double sums are NOT exact (forces the in-order serial summation)."""

@@ -268,3 +268,31 @@ def test_cli_falls_back_to_the_host_tokeniser(binary):
         res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, G.gunzip_to(tmp, "tiny_cr.paf.gz"), "r", "c", "o"],
                              capture_output=True, text=True, timeout=300)
         assert "(device)" in res.stdout
+
+
+@pytest.mark.parametrize("name", ["tiny", "quirks"])
+@pytest.mark.parametrize("mode", ["lazy", "full"])
+def test_cli_through_the_gathered_representation(binary, name, mode):
+    """The host's multi-GPU code path on one GPU (TLM_FORCE_GATHER): paths_ rebuilt from the exchange's result -- the
+    gathered summaries with node lists fetched on demand (lazy), or the gathered set (full) -- gives the same report and
+    the same scaffold as the one-process path.  quirks has runs of identical paths: filterUnique on the flags."""
+    from telomeri_amd import synth
+    import helpers as H
+    meta = G.load_json(name + ".json")
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
+        reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
+        synth.write_fasta(ds, reads, contigs)
+        outs = []
+        for env in ({}, {"TLM_FORCE_GATHER": "1", "TLM_EXCHANGE": mode}):
+            out = os.path.join(tmp, "o%d.fa" % len(outs))
+            res = subprocess.run([binary] + _flags(meta["args"]) + [rr, cr, reads, contigs, out], capture_output=True, text=True,
+                                 timeout=300, env=dict(os.environ, **env))
+            body = open(out, "rb").read() if os.path.exists(out) else b""
+            keep = [ln for ln in res.stdout.splitlines() if ln.startswith(("-", "Paths", "Found", "Consensus", "Final", "ctg", "read",
+                                                                           "Anchor pairs"))]
+            outs.append((res.returncode, body, keep))
+            if env:
+                assert "Gathered" in res.stdout
+        assert outs[0] == outs[1]
