@@ -79,7 +79,10 @@ def main() -> None:
         ctx.set_walk_tuning(args.waves_per_cu, 0)
     # the product's exchange: an RCCL communicator owned by the library context (tlm_dist_init); torch.distributed only
     # carries the 128-byte unique id to the other ranks and the final max / sum of the timing
-    use_abi_exchange = world > 1 and args.dist_backend == "nccl" and os.environ.get("TLM_EXCHANGE", "abi") == "abi"
+    # TLM_EXCHANGE: "lazy" (default: path summaries to every rank, node lists on demand -- what the host stages consume),
+    # "full" (every node list to every rank), "torch" (the harness's gather over torch.distributed)
+    exchange_mode = os.environ.get("TLM_EXCHANGE", "lazy")
+    use_abi_exchange = world > 1 and args.dist_backend == "nccl" and exchange_mode in ("lazy", "full")
     if use_abi_exchange:
         box = [capi.dist_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
@@ -136,8 +139,12 @@ def main() -> None:
             else:
                 a, b = g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
                 sets += [a, b]; ctrs += [("det", a.counters), ("det", b.counters)]
-        if use_abi_exchange:            # ONE grouped RCCL exchange of the packed device buffers (tlm_pathset_allgather)
-            gathered, xi = capi.PathSet.allgather(sets)
+        if use_abi_exchange:            # ONE RCCL exchange through the library's own communicator
+            if exchange_mode == "lazy":     # tlm_pathset_gather_summaries
+                gathered = capi.Gathered(sets)
+                xi = gathered.info
+            else:                           # tlm_pathset_allgather
+                gathered, xi = capi.PathSet.allgather(sets)
             n_total = gathered.n_paths
             exch["bytes_sent"] = int(xi.bytes_sent); exch["bytes_received"] = int(xi.bytes_received)
             exch["ms"] = exch.get("ms", 0.0) + float(xi.device_ms); exch["calls"] = exch.get("calls", 0) + 1
@@ -248,7 +255,9 @@ def main() -> None:
         "paths_per_step": paths_total,
     }
     if world > 1:
-        out["exchange"] = {"transport": "tlm_pathset_allgather (RCCL send/recv, library-owned communicator)" if use_abi_exchange
+        out["exchange"] = {"transport": ("tlm_pathset_gather_summaries (RCCL all-gather of 45-byte path summaries; node lists "
+                                         "stay with their owners until tlm_gathered_fetch asks)" if exchange_mode == "lazy" else
+                                         "tlm_pathset_allgather (RCCL send/recv of every node list)") if use_abi_exchange
                            else "telomeri_amd.pathgather over torch.distributed/%s" % args.dist_backend,
                            "allgather_bytes_sent_per_rank": exch.get("bytes_sent"),
                            "allgather_bytes_received_per_rank": exch.get("bytes_received"),
