@@ -504,11 +504,12 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         // persistent grid = what is resident at once: blocks/CU from the occupancy query (a block is 4
         // waves), optionally capped by the tuning knob; never more than 8 blocks (32 waves) per CU
         const bool sq = metrics[0] >= 2;
-        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq), 8);
+        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq), 32 / WALK_WAVES_PER_BLOCK);
         if (ctx->waves_per_cu) bpc = std::max(1, std::min(bpc, ctx->waves_per_cu / WALK_WAVES_PER_BLOCK));
         uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) bpc * WALK_WAVES_PER_BLOCK;
-        waves = std::min<uint32_t>(waves, ((n_all + 3) / 4) * 4);
-        waves = std::max<uint32_t>(4u, (waves / 4) * 4);
+        constexpr uint32_t WPB = WALK_WAVES_PER_BLOCK;
+        waves = std::min<uint32_t>(waves, ((n_all + WPB - 1) / WPB) * WPB);
+        waves = std::max<uint32_t>(WPB, (waves / WPB) * WPB);
         cnt[0].waves = waves;
         if (int rc = ensure_scratch(W, s, waves, cap, bm_words)) return rc;
         dirty.armed = true;
@@ -573,8 +574,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             a.bm_words = W.bm_words;
             a.arena = W.arena;
             a.ar_cap = W.ar_cap;
-            uint32_t launch_waves = std::min<uint32_t>(cur_waves, ((n_work + 3) / 4) * 4);
-            launch_waves = std::max<uint32_t>(4u, launch_waves);
+            uint32_t launch_waves = std::min<uint32_t>(cur_waves, ((n_work + WPB - 1) / WPB) * WPB);
+            launch_waves = std::max<uint32_t>(WPB, launch_waves);
             TLM_HIP(hipMemsetAsync(W.cursor + WALK_QUEUE_BASE, 0, WALK_QUEUE_STRIDE * WALK_XCDS * 4, s));
             TLM_HIP(hipMemsetAsync(W.cursor + 6, 0xFF, 8, s));      // first workgroup in (atomicMin)
             TLM_HIP(hipMemsetAsync(W.cursor + 8, 0, 8, s));         // last workgroup out (atomicMax)
@@ -599,8 +600,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 a.resident_flag = c->resident_dev;
             }
             TLM_HIP(hipEventRecord(ev0, s));
-            if (is_mc) tlm_launch_walk_mc(s, launch_waves / 4, sq, a);
-            else tlm_launch_walk_det(s, launch_waves / 4, sq, a);
+            if (is_mc) tlm_launch_walk_mc(s, launch_waves / WPB, sq, a);
+            else tlm_launch_walk_det(s, launch_waves / WPB, sq, a);
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));
             if (launched) launched->store(1);
@@ -640,7 +641,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 // bound the re-run's scratch to ~8 GiB
                 const uint64_t per_wave = (uint64_t) full_cap * 12u + (uint64_t) bm_words * 4u;
                 uint64_t w = (8ull << 30) / per_wave;
-                cur_waves = (uint32_t) std::max<uint64_t>(4, std::min<uint64_t>(cur_waves, (w / 4) * 4));
+                cur_waves = (uint32_t) std::max<uint64_t>(WPB, std::min<uint64_t>(cur_waves, (w / WPB) * WPB));
                 if (int rc = ensure_scratch(W, s, cur_waves, cur_cap, bm_words)) return rc;
             }
             work = sc_ovf;

@@ -76,7 +76,10 @@ constexpr int WALK_XCDS = 8;                    // MI355X: 8 accelerator dies, e
 constexpr int WALK_QUEUE_BASE = 32;             // u32 index of XCD 0's work cursor; one 64-byte line per cursor
 constexpr int WALK_QUEUE_STRIDE = 16;
 constexpr int WALK_CURSOR_WORDS = WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * WALK_XCDS;
-constexpr int WALK_BLOCK = 256;                 // 4 independent waves per workgroup
+#ifndef TLM_WALK_BLOCK
+#define TLM_WALK_BLOCK 256
+#endif
+constexpr int WALK_BLOCK = TLM_WALK_BLOCK;      // independent waves of a workgroup (4 by default)
 constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
 
 // resident workgroups per CU of the kernel (occupancy query): the persistent grid is sized from it
