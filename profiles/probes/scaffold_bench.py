@@ -107,8 +107,11 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
         out["input_bytes"] = nb
         out["input_written_s"] = round(time.time() - t0, 2)
         t0 = time.time()
-        res = subprocess.run([binary] + list(extra_args) + [rr, cr, reads, contigs, fasta], capture_output=True, text=True,
-                             env=dict(os.environ, TLM_HOST_TIMING="1"))
+        cmd = [binary] + list(extra_args) + [rr, cr, reads, contigs, fasta]
+        prof = os.environ.get("TLM_SCAFFOLD_ROCPROF")      # a directory: kernel trace + stats of the host program's run
+        if prof:
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", prof, "--"] + cmd
+        res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, TLM_HOST_TIMING="1"))
         out["scaffold_wall_s"] = round(time.time() - t0, 3)
         out["exit"] = res.returncode
         out["host_timing"] = [ln[len("[host timing] "):] for ln in res.stderr.splitlines() if ln.startswith("[host timing]")]
