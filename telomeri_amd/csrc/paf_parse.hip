@@ -176,35 +176,51 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
                 const uint64_t r = tile_base[tile] + l;
                 const char *p = text + b + s_start[l];
                 const char *end = text + bytes;
-                const char *tok[16], *tend[16];
+                // the tokens are consumed as they come (no token table: an array indexed by the token counter would live
+                // in scratch memory): two names as (start, length), nine integers, the strand
+                const char *q_name = nullptr, *t_name = nullptr;
+                uint32_t q_n = 0, t_n = 0;
+                int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
+                bool ok = true, minus = false;
                 int nt = 0;
                 while (p < end && *p != '\n') {
                     while (p < end && *p != '\n' && is_ws(*p)) p++;
                     if (p >= end || *p == '\n') break;
-                    if (nt == 16) { nt = 17; break; }
-                    tok[nt] = p;
+                    const char *ts = p;
                     while (p < end && *p != '\n' && !is_ws(*p)) p++;
-                    tend[nt++] = p;
+                    const char *te = p;
+                    switch (nt) {
+                        case 0: q_name = ts; q_n = (uint32_t) min((long) (te - ts), 0x10000l); break;
+                        case 1: ok = ok && strict_int(ts, te, v0); break;
+                        case 2: ok = ok && strict_int(ts, te, v1); break;
+                        case 3: ok = ok && strict_int(ts, te, v2); break;
+                        case 4: ok = ok && te - ts == 1; minus = *ts == '-'; break;
+                        case 5: t_name = ts; t_n = (uint32_t) min((long) (te - ts), 0x10000l); break;
+                        case 6: ok = ok && strict_int(ts, te, v3); break;
+                        case 7: ok = ok && strict_int(ts, te, v4); break;
+                        case 8: ok = ok && strict_int(ts, te, v5); break;
+                        case 9: ok = ok && strict_int(ts, te, v6); break;
+                        case 10: ok = ok && strict_int(ts, te, v7); break;
+                        case 11: ok = ok && strict_int(ts, te, v8); break;
+                        default: break;         // 12..15: discarded tokens; 16 and beyond: counted, refused below
+                    }
+                    nt++;
                 }
-                int32_t v[9];
-                const int num_idx[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
-                bool ok = nt == 16 && tend[4] - tok[4] == 1;
-                for (int k = 0; ok && k < 9; k++) ok = strict_int(tok[num_idx[k]], tend[num_idx[k]], v[k]);
-                if (!ok) {
+                (void) v7; (void) v8;           // alignment block length and mapping quality: parsed (they must be integers), never used
+                if (!ok || nt != 16) {
                     atomicOr(flags, 1u);
                     continue;
                 }
-                const uint64_t qn = (uint64_t) (tend[0] - tok[0]), tn = (uint64_t) (tend[5] - tok[5]);
-                if (qn >= 0xFFFFu || tn >= 0xFFFFu) {
+                if (q_n >= 0xFFFFu || t_n >= 0xFFFFu) {
                     atomicOr(flags, 4u);
                     continue;
                 }
-                out.q_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (tok[0] - text), (uint32_t) qn);
-                out.t_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (tok[5] - text), (uint32_t) tn);
-                out.q_len[r] = v[0]; out.q_start[r] = v[1]; out.q_end[r] = v[2];
-                out.t_len[r] = v[3]; out.t_start[r] = v[4]; out.t_end[r] = v[5];
-                out.matches[r] = v[6];
-                out.strand[r] = *tok[4] == '-';
+                out.q_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (q_name - text), q_n);
+                out.t_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (t_name - text), t_n);
+                out.q_len[r] = v0; out.q_start[r] = v1; out.q_end[r] = v2;
+                out.t_len[r] = v3; out.t_start[r] = v4; out.t_end[r] = v5;
+                out.matches[r] = v6;
+                out.strand[r] = minus;
             }
         }
         __syncthreads();

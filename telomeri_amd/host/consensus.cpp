@@ -282,6 +282,11 @@ Path PathManager::constructConsensusPath(const std::map<AnchorPair, std::vector<
     }
     if (!seed) throw std::out_of_range("map::at");      // what the reference's consensus_paths.at() throws here
 
+    {   // the node lists of all candidates in ONE fetch (any of them may be chained in)
+        std::vector<const Path *> need;
+        for (const auto &c : open) need.push_back(c.second.consensus);
+        materialise(need);
+    }
     const Path *seed_path = open.at(*seed).consensus;
     if (!seed_path->materialised()) materialise(*seed_path);
     Path scaffold;                              // a plain Path: node and edge lists only
