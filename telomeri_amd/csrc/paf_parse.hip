@@ -87,10 +87,24 @@ struct Dict {
     uint32_t *n_names;              // occupied slots; n_names[1] = flags of the parse
 };
 
-__device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, uint32_t file, uint64_t off, uint32_t len) {
-    const char *s = tx.p[file] + off;
+// The text of the file being parsed, as a workgroup sees it: its tile (+ overhang) staged in LDS by coalesced loads,
+// everything else in HBM.  Per-thread byte-wise reads of lines ~100 bytes apart touch 64 cache lines per wave
+// instruction; out of LDS they are conflict-free.
+struct TileText {
+    const char *lds;        // bytes [begin, begin + size) of the text
+    const char *global;
+    uint64_t begin;
+    uint32_t size;
+    __device__ __forceinline__ char operator[](uint64_t pos) const {
+        const uint64_t d = pos - begin;
+        return d < size ? lds[d] : global[pos];
+    }
+};
+
+__device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const TileText &mine_text, uint32_t file, uint64_t off,
+                                       uint32_t len) {
     unsigned long long h = 1469598103934665603ull;
-    for (uint32_t i = 0; i < len; i++) { h ^= (unsigned char) s[i]; h *= 1099511628211ull; }
+    for (uint32_t i = 0; i < len; i++) { h ^= (unsigned char) mine_text[off + i]; h *= 1099511628211ull; }
     h ^= h >> 29;
     const unsigned long long mine = pack_occ(file, off, len);
     uint32_t probes = 0;
@@ -110,7 +124,7 @@ __device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, uint32_t 
         if (occ_len(cur) == len) {          // whatever occurrence the slot shows at the moment spells the slot's name
             const char *o = tx.p[occ_file(cur)] + occ_off(cur);
             bool same = true;
-            for (uint32_t i = 0; i < len && same; i++) same = o[i] == s[i];
+            for (uint32_t i = 0; i < len && same; i++) same = o[i] == mine_text[off + i];
             if (same) {
                 if (mine < cur) atomicMin(&d.slot[j], mine);
                 return j;
@@ -124,15 +138,17 @@ struct Columns {
     uint8_t *strand;
 };
 
-__device__ inline bool strict_int(const char *s, const char *e, int32_t &v) {
+__device__ inline bool strict_int(const TileText &t, uint64_t s, uint64_t e, int32_t &v) {
     if (s >= e) return false;
     bool neg = false;
-    if (*s == '+' || *s == '-') { neg = *s == '-'; s++; }
+    const char c0 = t[s];
+    if (c0 == '+' || c0 == '-') { neg = c0 == '-'; s++; }
     if (s >= e || e - s > 10) return false;
     long long acc = 0;
     for (; s < e; s++) {
-        if (*s < '0' || *s > '9') return false;
-        acc = acc * 10 + (*s - '0');
+        const char c = t[s];
+        if (c < '0' || c > '9') return false;
+        acc = acc * 10 + (c - '0');
     }
     if (neg) acc = -acc;
     if (acc > 2147483647ll || acc < -2147483648ll) return false;
@@ -141,19 +157,29 @@ __device__ inline bool strict_int(const char *s, const char *e, int32_t &v) {
 }
 
 // flags: 1 = a line is not 16 clean tokens, 2 = too many line starts in a tile, 4 = a name of 65 535 bytes or more
+constexpr uint32_t TILE_OVERHANG = 4096;        // bytes after the tile staged with it: the tile's last line ends in there
+
 __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uint32_t file, uint64_t bytes, uint64_t n_tiles,
                                                                    const uint64_t *__restrict__ tile_base, Dict dict,
                                                                    Columns out, uint32_t *__restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) char s_text[TILE + TILE_OVERHANG];
     __shared__ uint16_t s_start[TILE_MAX_LINES];
     __shared__ uint32_t s_scan[TILE_THREADS];
     const char *text = tx.p[file];
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
+        // the tile and its overhang into LDS, 16 bytes per lane and load (the buffer is 64 bytes longer than the text)
+        const uint32_t staged = (uint32_t) min((uint64_t) (TILE + TILE_OVERHANG), bytes - b);
+        for (uint32_t o = threadIdx.x * 16u; o < staged; o += TILE_THREADS * 16u)
+            *reinterpret_cast<uint4 *>(s_text + o) = *reinterpret_cast<const uint4 *>(text + b + o);
+        const char before = b ? text[b - 1] : '\n';
+        __syncthreads();
+        const TileText t{s_text, text, b, staged};
         // line starts of the tile, in order: every thread owns 128 consecutive bytes
         constexpr uint32_t PER = TILE / TILE_THREADS;
-        const uint64_t mb = b + (uint64_t) threadIdx.x * PER, me = min(e, mb + PER);
+        const uint32_t m0 = threadIdx.x * PER, m1 = (uint32_t) min((uint64_t) (m0 + PER), e - b);
         uint32_t n = 0;
-        for (uint64_t p = mb; p < me; p++) n += p == 0 || text[p - 1] == '\n';
+        for (uint32_t o = m0; o < m1; o++) n += (o ? s_text[o - 1] : before) == '\n';
         s_scan[threadIdx.x] = n;
         __syncthreads();
         for (uint32_t d = 1; d < TILE_THREADS; d <<= 1) {
@@ -167,46 +193,45 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
         if (total > TILE_MAX_LINES) {
             if (threadIdx.x == 0) atomicOr(flags, 2u);
         } else {
-            for (uint64_t p = mb; p < me; p++)
-                if (p == 0 || text[p - 1] == '\n') s_start[at++] = (uint16_t) (p - b);
+            for (uint32_t o = m0; o < m1; o++)
+                if ((o ? s_text[o - 1] : before) == '\n') s_start[at++] = (uint16_t) o;
         }
         __syncthreads();
         if (total <= TILE_MAX_LINES) {
             for (uint32_t l = threadIdx.x; l < total; l += TILE_THREADS) {
                 const uint64_t r = tile_base[tile] + l;
-                const char *p = text + b + s_start[l];
-                const char *end = text + bytes;
-                // the tokens are consumed as they come (no token table: an array indexed by the token counter would live
-                // in scratch memory): two names as (start, length), nine integers, the strand
-                const char *q_name = nullptr, *t_name = nullptr;
+                uint64_t p = b + s_start[l];
+                // the tokens are consumed as they come: two names as (start, length), nine integers, the strand
+                uint64_t q_name = 0, t_name = 0;
                 uint32_t q_n = 0, t_n = 0;
                 int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
                 bool ok = true, minus = false;
                 int nt = 0;
-                while (p < end && *p != '\n') {
-                    while (p < end && *p != '\n' && is_ws(*p)) p++;
-                    if (p >= end || *p == '\n') break;
-                    const char *ts = p;
-                    while (p < end && *p != '\n' && !is_ws(*p)) p++;
-                    const char *te = p;
+                for (;;) {
+                    char c = 0;
+                    while (p < bytes && (c = t[p]) != '\n' && is_ws(c)) p++;
+                    if (p >= bytes || c == '\n') break;
+                    const uint64_t ts = p;
+                    while (p < bytes && (c = t[p]) != '\n' && !is_ws(c)) p++;
+                    const uint64_t te = p;
                     switch (nt) {
-                        case 0: q_name = ts; q_n = (uint32_t) min((long) (te - ts), 0x10000l); break;
-                        case 1: ok = ok && strict_int(ts, te, v0); break;
-                        case 2: ok = ok && strict_int(ts, te, v1); break;
-                        case 3: ok = ok && strict_int(ts, te, v2); break;
-                        case 4: ok = ok && te - ts == 1; minus = *ts == '-'; break;
-                        case 5: t_name = ts; t_n = (uint32_t) min((long) (te - ts), 0x10000l); break;
-                        case 6: ok = ok && strict_int(ts, te, v3); break;
-                        case 7: ok = ok && strict_int(ts, te, v4); break;
-                        case 8: ok = ok && strict_int(ts, te, v5); break;
-                        case 9: ok = ok && strict_int(ts, te, v6); break;
-                        case 10: ok = ok && strict_int(ts, te, v7); break;
-                        case 11: ok = ok && strict_int(ts, te, v8); break;
+                        case 0: q_name = ts; q_n = (uint32_t) min(te - ts, (uint64_t) 0x10000); break;
+                        case 1: ok = ok && strict_int(t, ts, te, v0); break;
+                        case 2: ok = ok && strict_int(t, ts, te, v1); break;
+                        case 3: ok = ok && strict_int(t, ts, te, v2); break;
+                        case 4: ok = ok && te - ts == 1; minus = t[ts] == '-'; break;
+                        case 5: t_name = ts; t_n = (uint32_t) min(te - ts, (uint64_t) 0x10000); break;
+                        case 6: ok = ok && strict_int(t, ts, te, v3); break;
+                        case 7: ok = ok && strict_int(t, ts, te, v4); break;
+                        case 8: ok = ok && strict_int(t, ts, te, v5); break;
+                        case 9: ok = ok && strict_int(t, ts, te, v6); break;
+                        case 10: ok = ok && strict_int(t, ts, te, v7); break;
+                        case 11: ok = ok && strict_int(t, ts, te, v8); break;
                         default: break;         // 12..15: discarded tokens; 16 and beyond: counted, refused below
                     }
                     nt++;
                 }
-                (void) v7; (void) v8;           // alignment block length and mapping quality: parsed (they must be integers), never used
+                (void) v7; (void) v8;           // alignment block length and mapping quality: must be integers, never used
                 if (!ok || nt != 16) {
                     atomicOr(flags, 1u);
                     continue;
@@ -215,8 +240,8 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
                     atomicOr(flags, 4u);
                     continue;
                 }
-                out.q_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (q_name - text), q_n);
-                out.t_id[r] = (int32_t) dict_intern(dict, tx, file, (uint64_t) (t_name - text), t_n);
+                out.q_id[r] = (int32_t) dict_intern(dict, tx, t, file, q_name, q_n);
+                out.t_id[r] = (int32_t) dict_intern(dict, tx, t, file, t_name, t_n);
                 out.q_len[r] = v0; out.q_start[r] = v1; out.q_end[r] = v2;
                 out.t_len[r] = v3; out.t_start[r] = v4; out.t_end[r] = v5;
                 out.matches[r] = v6;

@@ -21,6 +21,7 @@ void Path::updateLength() {             // Path.cpp:6-16: first node's length + 
 }
 
 bool Path::operator==(const Path &o) const {       // Path.cpp:46-49: the node sequences are equal (edges are not compared)
+    if (this == &o) return true;                    // (a group's consensus is compared with every member, itself included)
     if (node_count() != o.node_count()) return false;
     // two paths of device sets: a different hash of the node sequence settles it without fetching either list
     if (owner_ && o.owner_ && hash_ != o.hash_) return false;
