@@ -28,6 +28,28 @@ extern "C" const char *tlm_last_error(void) { return g_err; }
 
 extern "C" int tlm_abi_version(void) { return TLM_ABI_VERSION; }
 
+void tlm_ctx_defer(tlm_ctx *ctx, std::function<void()> fn) {
+    std::lock_guard<std::mutex> lk(ctx->deferred_mu);
+    ctx->deferred.push_back(std::move(fn));
+}
+
+void tlm_ctx_start_deferred(tlm_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->deferred_mu);
+    for (auto &fn : ctx->deferred) ctx->deferred_running.emplace_back(std::move(fn));
+    ctx->deferred.clear();
+}
+
+void tlm_ctx_join_deferred(tlm_ctx *ctx) {
+    tlm_ctx_start_deferred(ctx);
+    std::vector<std::thread> running;
+    {
+        std::lock_guard<std::mutex> lk(ctx->deferred_mu);
+        running.swap(ctx->deferred_running);
+    }
+    for (auto &t : running)
+        if (t.joinable()) t.join();
+}
+
 extern "C" uint32_t tlm_walk_seed(int metric, uint32_t anchor_node, uint32_t r) {
     return 5489u + 0x9E3779B9u * (anchor_node + 1u) + 0x85EBCA6Bu * r + 0xC2B2AE35u * (uint32_t) metric;
 }
@@ -105,6 +127,7 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     if (!ctx) return;
     CtxImpl *c = static_cast<CtxImpl *>(ctx);
     (void) hipSetDevice(c->device);
+    tlm_ctx_join_deferred(ctx);
     tlm_dist_finalize(ctx);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->side.stream) (void) hipStreamSynchronize(c->side.stream);
@@ -605,6 +628,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));
             if (launched) launched->store(1);
+            if (lane == 0 && round == 0) tlm_ctx_start_deferred(ctx);      // the device is busy for a while: the host tidies up
             unsigned long long span[2] = {0, 0};
             TLM_HIP(hipMemcpyAsync(span, W.cursor + 6, 16, hipMemcpyDeviceToHost, s));
             TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));

@@ -320,12 +320,6 @@ struct tlm_paf {
     char *blob = nullptr;
     uint64_t blob_bytes = 0;
     double upload_ms = 0, parse_ms = 0, finish_ms = 0;
-    std::vector<std::thread> cleanup;    // unpin + unmap of uploaded files
-    void join_cleanup() {
-        for (auto &t : cleanup)
-            if (t.joinable()) t.join();
-        cleanup.clear();
-    }
 };
 
 extern "C" int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out) {
@@ -338,7 +332,6 @@ extern "C" int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out) {
 
 extern "C" void tlm_paf_destroy(tlm_paf *p) {
     if (!p) return;
-    p->join_cleanup();
     (void) hipSetDevice(p->ctx->device);
     (void) hipStreamSynchronize(p->ctx->stream);
     for (int f = 0; f < MAX_FILES; f++) {
@@ -498,9 +491,10 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             const double t_copy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
             for (hipEvent_t e : done)
                 if (e) (void) hipEventDestroy(e);
-            // unpinning and unmapping 15 GB of populated pages takes longer than the copies did: behind the scenes,
-            // while the text is being tokenised (joined when the handle is finished or destroyed)
-            p->cleanup.emplace_back([m, bytes, registered, dev = p->ctx->device] {
+            // unpinning and unmapping 15 GB of populated pages takes longer than the copies did (0.65 s) and holds up every
+            // allocation of the process meanwhile: deferred to the context, which does it when the device has just been
+            // given a long kernel (the walks), or when it goes
+            tlm_ctx_defer(p->ctx, [m, bytes, registered, dev = p->ctx->device] {
                 (void) hipSetDevice(dev);
                 const auto t0 = std::chrono::steady_clock::now();
                 for (uint64_t k = 0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);
@@ -675,7 +669,6 @@ extern "C" int tlm_paf_finish(tlm_paf *p, uint32_t *n_names_out, uint64_t *blob_
         TLM_HIP(hipStreamSynchronize(s));
         TLM_HIP(hipGetLastError());
     }
-    p->join_cleanup();
     // the text is no longer needed
     for (int f = 0; f < MAX_FILES; f++) {
         tlm_pool_free(p->text[f]);

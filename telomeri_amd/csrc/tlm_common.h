@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/telomeri_hip.h"
@@ -40,7 +43,16 @@ struct tlm_ctx {
     std::vector<hipEvent_t> phase_ev;   // graph-build phase marks, created on first use
     void *comm = nullptr;          // ncclComm_t (exchange.hip); rank / world of the one-process-per-GPU job
     int rank = 0, world = 1;
+    // host-side tidying that may wait (unpinning and unmapping 15 GB of uploaded text takes 0.65 s and blocks every
+    // allocation of the process meanwhile): started when the device has just been given a long kernel, or at the latest
+    // when the context goes
+    std::mutex deferred_mu;
+    std::vector<std::function<void()>> deferred;
+    std::vector<std::thread> deferred_running;
 };
+void tlm_ctx_defer(tlm_ctx *ctx, std::function<void()> fn);
+void tlm_ctx_start_deferred(tlm_ctx *ctx);      // run what has been deferred so far, in background threads
+void tlm_ctx_join_deferred(tlm_ctx *ctx);       // start the rest and wait for all of it
 
 // Device-resident graph.  HBM layout:
 //   row_ptr[N+1]            u32   CSR offsets (A < 2^32)
