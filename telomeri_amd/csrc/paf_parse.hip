@@ -491,18 +491,15 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             const double t_copy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
             for (hipEvent_t e : done)
                 if (e) (void) hipEventDestroy(e);
-            // unpinning and unmapping 15 GB of populated pages takes longer than the copies did (0.65 s) and holds up every
-            // allocation of the process meanwhile: deferred to the context, which does it when the device has just been
-            // given a long kernel (the walks), or when it goes
-            tlm_ctx_defer(p->ctx, [m, bytes, registered, dev = p->ctx->device] {
-                (void) hipSetDevice(dev);
-                const auto t0 = std::chrono::steady_clock::now();
-                for (uint64_t k = 0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);
+            // unmapping 15 GB of populated pages takes longer than the copies did (0.65 s) and holds up every allocation
+            // of the process meanwhile: deferred to the context, which does it when the device has just been given a long
+            // kernel (the walks), or when it goes
+            for (uint64_t k = 0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);   // (instant while the device idles)
+            tlm_ctx_defer(p->ctx, [m, bytes] {
                 const auto t1 = std::chrono::steady_clock::now();
                 ::munmap(m, bytes);      // (0.65 s for 15.6 GB of populated pages, serialised by the kernel whatever the thread count)
                 if (getenv("TLM_HOST_TIMING"))
-                    fprintf(stderr, "[host timing] behind the scenes: unpinning %.0f ms, unmapping %.0f ms\n",
-                            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    fprintf(stderr, "[host timing] behind the scenes: unmapping %.0f ms\n",
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
             });
             uploaded = ok;
