@@ -296,3 +296,45 @@ def test_cli_through_the_gathered_representation(binary, name, mode):
             if env:
                 assert "Gathered" in res.stdout
         assert outs[0] == outs[1]
+
+
+def test_device_tokeniser_long_lines_and_tile_borders():
+    """Lines that straddle the 32 KB tiles of the tokeniser kernel and run past the overhang staged in LDS (names of
+    several thousand characters) are parsed through the same accessor from HBM; names of 65 535 bytes are refused."""
+    import test_host_ingest as TI
+    from telomeri_amd import capi
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(3000):
+        qn = "read%d" % rng.integers(0, 40) if i % 97 else "q" * int(rng.integers(3000, 9000)) + str(i % 3)
+        tn = "read%d" % rng.integers(0, 40) if i % 89 else "t" * int(rng.integers(4100, 20000))
+        lines.append("%s\t9000\t%d\t8000\t%s\t%s\t7000\t5\t6990\t6500\t7990\t60\ttp:A:S\tcm:i:9\ts1:i:8\tdv:f:0.01\n" % (
+            qn, i, "+-"[i % 2], tn))
+    body = "".join(lines)
+    ctx = capi.Context(0)
+    paf = capi.PafTokens(ctx)
+    n, clean = paf.add_text(body.encode(), anchors=False)
+    assert clean and n == len(lines)
+    cols, names = TI.stream_parse(body)
+    got_names, _ = paf.finish()
+    assert got_names == names
+    got = paf.columns(0)
+    for k in cols:
+        np.testing.assert_array_equal(got[k], np.array(cols[k]), err_msg=k)
+    paf = capi.PafTokens(ctx)
+    n, clean = paf.add_text((lines[0] + lines[0].replace("read", "r" * 70000, 1)).encode(), anchors=False)
+    assert not clean
+
+
+def test_cli_text_upload_through_slabs(binary):
+    """The fallback of the text upload (pread into pinned slabs, for files that cannot be mapped and pinned) feeds the
+    tokeniser the same bytes."""
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
+        outs = []
+        for env in ({}, {"TLM_UPLOAD_SLABS": "1"}):
+            res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, cr, "r", "c", "o"], capture_output=True, text=True,
+                                 timeout=300, env=dict(os.environ, **env))
+            assert res.returncode == 0 and "(device)" in res.stdout, res.stderr
+            outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
+        assert outs[0] == outs[1]
