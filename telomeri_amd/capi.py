@@ -483,6 +483,15 @@ def _records_struct(rec, anchors: bool) -> _Records:
 
 class Context:
     def __init__(self, device: int = 0) -> None:
+        # Harness detail: PyTorch's wheel carries its own copy of the HIP / HSA runtime, this library uses the system's.
+        # The two coexist in one process when PyTorch's comes up first; the other way round its device discovery fails
+        # ("No HIP GPUs are available") and the process aborts at exit.  The C++ hosts never load PyTorch.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         h = C.c_void_p()
         _check(lib().tlm_ctx_create(device, C.byref(h)), "tlm_ctx_create")
         self._h = h

@@ -322,7 +322,7 @@ def test_device_tokeniser_long_lines_and_tile_borders():
     for k in cols:
         np.testing.assert_array_equal(got[k], np.array(cols[k]), err_msg=k)
     paf = capi.PafTokens(ctx)
-    n, clean = paf.add_text((lines[0] + lines[0].replace("read", "r" * 70000, 1)).encode(), anchors=False)
+    n, clean = paf.add_text((TI.LINE + TI.LINE.replace("readA", "r" * 70000)).encode(), anchors=False)
     assert not clean
 
 
