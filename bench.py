@@ -84,9 +84,31 @@ def main() -> None:
     exchange_mode = os.environ.get("TLM_EXCHANGE", "lazy")
     use_abi_exchange = world > 1 and args.dist_backend == "nccl" and exchange_mode in ("lazy", "full")
     if use_abi_exchange:
-        box = [capi.dist_unique_id() if rank == 0 else None]
+        # every rank tries; if ANY of them cannot bring the library's communicator up, all fall back together to the
+        # harness's gather over torch.distributed (the line then says so)
+        ok, why = 1, ""
+        try:
+            box = [capi.dist_unique_id() if rank == 0 else None]
+        except Exception as e:
+            box, ok, why = [None], 0, repr(e)
         dist.broadcast_object_list(box, src=0)
-        ctx.dist_init(rank, world, box[0])
+        if ok and box[0] is not None:
+            try:
+                ctx.dist_init(rank, world, box[0])
+            except Exception as e:
+                ok, why = 0, repr(e)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            log("rank %d: library communicator unavailable (%s); falling back to torch.distributed for the exchange" % (rank, why))
+            try:
+                ctx.dist_finalize()
+            except Exception:
+                pass
+            use_abi_exchange = False
+            exchange_mode = "torch (fallback: %s)" % (why or "another rank failed")
     ds = synth.make_config(args.config, device=str(dev))
     torch.cuda.synchronize(dev)
     t_gen = time.time() - t0
