@@ -380,7 +380,9 @@ static int tokenise_on_device(tlm_paf *p, int f, uint64_t *n_records, int *clean
     TLM_CHECK(n < (1ull << 31), TLM_ELIMIT, "tlm_paf: %llu lines exceed the 2^31 record limit", (unsigned long long) n);
     // dictionary: created with the first file, sized from its record count (names are few compared with records)
     if (!p->slot) {
-        uint64_t want = std::max<uint64_t>(1u << 20, std::min<uint64_t>(n, 1ull << 27));
+        // (at least 4 M slots = 32 MB: a small first file may be followed by a large one; a table that ends up more than
+        // half full is not trusted and sends the graph to the host tokeniser)
+        uint64_t want = std::max<uint64_t>(1u << 22, std::min<uint64_t>(n, 1ull << 27));
         uint64_t cap = 1;
         while (cap < want) cap <<= 1;
         p->n_slots = cap;
