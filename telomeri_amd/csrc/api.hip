@@ -63,6 +63,24 @@ struct Workspace {   // walk scratch kept across calls (bench loops); bitmaps st
     uint64_t ar_cap = 0;
     uint2 *arena = nullptr;
     uint32_t *cursor = nullptr;              // arena cursor (u64) at [2], filter count (u64) at [4], per-XCD work cursors
+    // pinned host copy of the unit records of a call (38 MB for the whole A. thaliana config: a pageable, zero-filled
+    // std::vector cost 10 ms per call)
+    void *h_units = nullptr;
+    size_t h_units_bytes = 0;
+    int ensure_h_units(size_t bytes) {
+        if (bytes <= h_units_bytes) return TLM_OK;
+        if (h_units) (void) hipHostFree(h_units);
+        h_units = nullptr;
+        h_units_bytes = 0;
+        TLM_HIP(hipHostMalloc(&h_units, bytes, hipHostMallocDefault));
+        h_units_bytes = bytes;
+        return TLM_OK;
+    }
+    void release_host() {
+        if (h_units) (void) hipHostFree(h_units);
+        h_units = nullptr;
+        h_units_bytes = 0;
+    }
     // (the owning stream has been synchronised, or the buffers are handed back in stream order)
     void release_scratch() {
         tlm_pool_free(scratch); tlm_pool_free(bitmaps);
@@ -133,9 +151,11 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     if (c->side.stream) (void) hipStreamSynchronize(c->side.stream);
     c->ws.release_scratch();
     c->ws.release_arena();
+    c->ws.release_host();
     (void) hipFree(c->ws.cursor);
     c->side.ws.release_scratch();
     c->side.ws.release_arena();
+    c->side.ws.release_host();
     (void) hipFree(c->side.ws.cursor);
     if (c->resident_host) (void) hipHostFree(c->resident_host);
     for (hipEvent_t e : c->phase_ev) (void) hipEventDestroy(e);
@@ -501,7 +521,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
     if (int rc = pmalloc(&u.work_list, n_all, s)) return rc;
     TLM_HIP(hipMemsetAsync(u.units, 0xFF, (size_t) (n_all ? n_all : 1) * sizeof(UnitOut), s));   // status = not run
 
-    std::vector<UnitOut> h_units(n_all);
+    if (int rc = W.ensure_h_units(((size_t) n_all + 1) * sizeof(UnitOut))) return rc;
+    UnitOut *const h_units = static_cast<UnitOut *>(W.h_units);
 
     // a call that gives up between a launch and its completion leaves the per-wave visited maps in an unknown state:
     // the workspace is dropped then (after the stream has drained), the next call starts from zeroed maps
@@ -631,7 +652,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             if (lane == 0 && round == 0) tlm_ctx_start_deferred(ctx);      // the device is busy for a while: the host tidies up
             unsigned long long span[2] = {0, 0};
             TLM_HIP(hipMemcpyAsync(span, W.cursor + 6, 16, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipMemcpyAsync(h_units.data(), u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(h_units, u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipEventSynchronize(ev1));
             TLM_HIP(hipStreamSynchronize(s));
             float ms = 0;
