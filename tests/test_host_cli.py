@@ -338,3 +338,64 @@ def test_cli_text_upload_through_slabs(binary):
             assert res.returncode == 0 and "(device)" in res.stdout, res.stderr
             outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
         assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_device_tokeniser_fuzz(seed):
+    """Random 16-column text -- runs of blanks and tabs between tokens, leading blanks, CRLF, signs and leading zeros on
+    the numbers, names of 1..40 arbitrary printable characters, a few hundred to a few thousand lines so that several
+    32 KB tiles and a last line without a newline occur -- against the token-stream model; every third seed plants one
+    defect (a 15- or 17-token line, a non-number, an int overflow, a two-character strand, a blank line): refused."""
+    import test_host_ingest as TI
+    from telomeri_amd import capi
+    rng = np.random.default_rng(4000 + seed)
+    alphabet = np.array(list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_.:/|#@!-+=*"))
+    pool = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 41)))) for _ in range(int(rng.integers(3, 60)))]
+    def sep():
+        return "".join(rng.choice(np.array([" ", "\\t"]), size=int(rng.integers(1, 4))))
+    def num(lo=0, hi=2_000_000_000):
+        v = int(rng.integers(lo, hi))
+        s = str(v)
+        if rng.random() < 0.1:
+            s = "0" * int(rng.integers(1, 3)) + s
+        if rng.random() < 0.1:
+            s = "+" + s
+        return s if len(s) <= 10 or s[0] in "+-" and len(s) <= 11 else str(v)
+    lines = []
+    for i in range(int(rng.integers(300, 2500))):
+        toks = [pool[int(rng.integers(0, len(pool)))], num(), num(), num(), "+-"[int(rng.integers(0, 2))],
+                pool[int(rng.integers(0, len(pool)))], num(), num(), num(),
+                ("-" if rng.random() < 0.05 else "") + str(int(rng.integers(0, 100000))), num(), num(), "tp:A:S", "cm:i:9", "s1:i:8", "dv:f:0.01"]
+        lead = sep() if rng.random() < 0.1 else ""
+        eol = "\\r\\n" if rng.random() < 0.2 else "\\n"
+        lines.append(lead + sep().join(toks) + (sep() if rng.random() < 0.1 else "") + eol)
+    defect = seed % 3 == 2
+    if defect:
+        k = int(rng.integers(0, len(lines)))
+        kind = seed // 3 % 5
+        parts = lines[k].split()
+        if kind == 0:
+            lines[k] = "\\t".join(parts[:15]) + "\\n"
+        elif kind == 1:
+            lines[k] = "\\t".join(parts + ["extra"]) + "\\n"
+        elif kind == 2:
+            lines[k] = "\\t".join(parts[:2] + ["12x"] + parts[3:]) + "\\n"
+        elif kind == 3:
+            lines[k] = "\\t".join(parts[:1] + ["99999999999"] + parts[2:]) + "\\n"
+        else:
+            lines.insert(k, "  \\n")
+    body = "".join(lines)
+    if seed % 2:
+        body = body.rstrip("\\r\\n")
+    ctx = capi.Context(0)
+    paf = capi.PafTokens(ctx)
+    n, clean = paf.add_text(body.encode(), anchors=False)
+    assert clean == (not defect)
+    if clean:
+        cols, names = TI.stream_parse(body)
+        assert n == len(cols["q_len"]) == len(lines)
+        got_names, _ = paf.finish()
+        assert got_names == names
+        got = paf.columns(0)
+        for k in cols:
+            np.testing.assert_array_equal(got[k], np.array(cols[k]), err_msg=k)
