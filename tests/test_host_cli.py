@@ -352,7 +352,7 @@ def test_device_tokeniser_fuzz(seed):
     alphabet = np.array(list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_.:/|#@!-+=*"))
     pool = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 41)))) for _ in range(int(rng.integers(3, 60)))]
     def sep():
-        return "".join(rng.choice(np.array([" ", "\\t"]), size=int(rng.integers(1, 4))))
+        return "".join(rng.choice(np.array([" ", "\t"]), size=int(rng.integers(1, 4))))
     def num(lo=0, hi=2_000_000_000):
         v = int(rng.integers(lo, hi))
         s = str(v)
@@ -367,7 +367,7 @@ def test_device_tokeniser_fuzz(seed):
                 pool[int(rng.integers(0, len(pool)))], num(), num(), num(),
                 ("-" if rng.random() < 0.05 else "") + str(int(rng.integers(0, 100000))), num(), num(), "tp:A:S", "cm:i:9", "s1:i:8", "dv:f:0.01"]
         lead = sep() if rng.random() < 0.1 else ""
-        eol = "\\r\\n" if rng.random() < 0.2 else "\\n"
+        eol = "\r\n" if rng.random() < 0.2 else "\n"
         lines.append(lead + sep().join(toks) + (sep() if rng.random() < 0.1 else "") + eol)
     defect = seed % 3 == 2
     if defect:
@@ -375,18 +375,18 @@ def test_device_tokeniser_fuzz(seed):
         kind = seed // 3 % 5
         parts = lines[k].split()
         if kind == 0:
-            lines[k] = "\\t".join(parts[:15]) + "\\n"
+            lines[k] = "\t".join(parts[:15]) + "\n"
         elif kind == 1:
-            lines[k] = "\\t".join(parts + ["extra"]) + "\\n"
+            lines[k] = "\t".join(parts + ["extra"]) + "\n"
         elif kind == 2:
-            lines[k] = "\\t".join(parts[:2] + ["12x"] + parts[3:]) + "\\n"
+            lines[k] = "\t".join(parts[:2] + ["12x"] + parts[3:]) + "\n"
         elif kind == 3:
-            lines[k] = "\\t".join(parts[:1] + ["99999999999"] + parts[2:]) + "\\n"
+            lines[k] = "\t".join(parts[:1] + ["99999999999"] + parts[2:]) + "\n"
         else:
-            lines.insert(k, "  \\n")
+            lines.insert(k, "  \n")
     body = "".join(lines)
     if seed % 2:
-        body = body.rstrip("\\r\\n")
+        body = body.rstrip("\r\n")
     ctx = capi.Context(0)
     paf = capi.PafTokens(ctx)
     n, clean = paf.add_text(body.encode(), anchors=False)
