@@ -411,7 +411,8 @@ __global__ void invert_perm_kernel(uint32_t n_nodes, const uint32_t *__restrict_
 // walk kernel owns 4 or 8 consecutive entries), and of 24 for the degrees the kernel reads with 6 entries per lane
 // (257..384): whatever the lane width, the last lane's entries end inside the row's own padding.
 __host__ __device__ inline uint32_t tlm_padded_degree(uint32_t deg) {
-    return (deg > 256u && deg <= 384u) ? ((deg + 23u) / 24u) * 24u : (deg + 7u) & ~7u;
+    // lists read 6 or 12 entries per lane (257..384, 513..768): a lane's entries must not reach the next row
+    return ((deg > 256u && deg <= 384u) || (deg > 512u && deg <= 768u)) ? ((deg + 23u) / 24u) * 24u : (deg + 7u) & ~7u;
 }
 
 // walk layout: padded degrees in walk order, then (after an exclusive scan) the per-node record and the row copies

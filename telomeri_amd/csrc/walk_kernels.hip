@@ -397,7 +397,7 @@ __device__ __forceinline__ bool lane_load_c(const uint32_t *met, const uint16_t 
     const bool act = first < deg;
     const uint32_t off = row + (act ? first : 0u);      // rows start at multiples of 8 entries: 32-byte / 16-byte aligned
     struct alignas(K == 6 ? 8 : 16) Met { uint32_t v[K]; };
-    struct alignas(K == 6 ? 4 : 2 * K) Ids { uint32_t v[K / 2]; };
+    struct alignas(K == 6 ? 4 : K == 12 ? 8 : 2 * K) Ids { uint32_t v[K / 2]; };
     const Met m = *reinterpret_cast<const Met *>(met + off);
     const Ids w = *reinterpret_cast<const Ids *>(d16 + off);
 #pragma unroll
@@ -894,10 +894,11 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         const bool compact = ((rfl(rec.y) >> 29) & 1u) != 0;
         // ---- selection scan (:53-115)
         const Selection s = !safe        ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
-                            : __builtin_expect(compact && deg <= 512u, 1)
+                            : __builtin_expect(compact && deg <= 768u, 1)
                                 ? (deg <= 256u   ? select_short_c<4, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
                                    : deg <= 384u ? select_short_c<6, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
-                                                 : select_short_c<8, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk))
+                                   : deg <= 512u ? select_short_c<8, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                                                 : select_short_c<12, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk))
                             : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
                             : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
                             : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
@@ -1077,16 +1078,113 @@ struct DetPick {
     uint32_t pushed;        // :340-347: the FIRST entry in list order with the same (q_index, t_index) is pushed
 };
 
+// The common case of a ranked step, at a third of the vector instructions of the general form below.  When every metric
+// of the list has its sign bit clear (ES = fabsf(..) always; OS unless the record is degenerate) the fp32 BIT PATTERNS
+// order exactly as operator> orders the floats (+NaN included, as det_ord places it), so no order image is needed; and
+// the two exclusions of :299-308 are checked AFTER the choice instead of being searched for first:
+//   * rank deg-1 (smallest metric, last position): the chosen entry is not it whenever some entry of the list has a
+//     strictly smaller metric -- looked for only in lanes whose K entries all lie inside the list (no validity masks);
+//     if none is found the general form decides;
+//   * rank 0 after a go-back (skip_n_best == 1): found as the first position of the wave maximum; if the choice is that
+//     entry it is knocked out and the choice repeated.
+// No validity masks are needed for the choice itself: lanes past the list repeat lane 0's entries (same keys at larger
+// positions), and the partial lane's tail is row padding (walk_layout_kernel: the row's own node, metric +0, padded so
+// that a lane's K entries never reach the next row) -- the weakest possible candidate at positions >= deg: it is
+// chosen only when no real entry is eligible, which is the go-back.
+// Returns false when the general form has to decide (r untouched).
+template <int K, bool SQRT, bool REL>
+__device__ __forceinline__ bool det_select_fast(const uint32_t (&nb)[K], const uint32_t (&mb)[K], const uint32_t (&vis)[K],
+                                                int lane, uint32_t deg, uint32_t skip_n_best, uint32_t lo, DetPick &r) {
+    uint32_t ob[K], orr = 0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        ob[k] = SQRT ? __float_as_uint(sqrtf(__uint_as_float(mb[k]))) : mb[k];
+        orr |= SQRT ? (ob[k] | mb[k]) : ob[k];
+    }
+    if (__builtin_expect(__ballot((int) orr < 0) != 0, 0)) return false;
+    uint32_t key[K], lc = 0u, lmin = ~0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        key[k] = (ob[k] | 0x80000000u) & ~vis[k];           // 0: visited
+        lc = max(lc, key[k]);
+        lmin = min(lmin, ob[k]);
+    }
+    if ((int) deg - K * lane < K) lmin = ~0u;
+    const uint32_t omin_full = wave_min_u32(lmin);
+    uint32_t oc = wave_max_u32(lc);
+    uint32_t p = 0xFFFFFFFFu, e = 0u;
+    auto first_of = [&](uint32_t want) {
+        p = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint64_t hm = __ballot(key[k] == want);
+            const int fl = (__ffsll((unsigned long long) hm) - 1) & 63;
+            const uint32_t pk = hm ? (uint32_t) K * (uint32_t) fl + (uint32_t) k : 0xFFFFFFFFu;
+            const uint32_t ek = readlane_u32(nb[k], fl);
+            if (pk < p) {
+                p = pk;
+                e = ek;
+            }
+        }
+    };
+    if (oc != 0u) first_of(oc);
+    if (oc != 0u && skip_n_best != 0u) {                     // :299: rank 0 is skipped for the rest of the walk
+        uint32_t lall = 0u;
+#pragma unroll
+        for (int k = 0; k < K; k++) lall = max(lall, ob[k]);
+        const uint32_t omax = wave_max_u32(lall);
+        uint32_t best_i = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint64_t hm = __ballot(ob[k] == omax);
+            if (hm) best_i = min(best_i, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
+        }
+        if (p == best_i) {
+            const uint32_t bl = best_i / (uint32_t) K, bk = best_i - bl * (uint32_t) K;
+            lc = 0u;
+            const bool past = (uint32_t) (K * lane) >= deg;     // (the copies of lane 0's entries must go with it)
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (past || ((uint32_t) lane == bl && (uint32_t) k == bk)) key[k] = 0u;
+                lc = max(lc, key[k]);
+            }
+            oc = wave_max_u32(lc);
+            if (oc != 0u) first_of(oc);
+        }
+    }
+    if (oc == 0u || p >= deg) {                             // nothing unvisited but (at most) row padding: :318
+        r.go_back = true;
+        return true;
+    }
+    if (__builtin_expect(!(omin_full < (oc & 0x7FFFFFFFu)), 0)) return false;      // may be rank deg-1
+    r.chosen = p;
+    r.chosen_nbr = REL ? e + lo : e & 0x7FFFFFFFu;
+    r.chosen_anchor = REL ? false : (e >> 31) != 0;
+    // ---- :340-347 (the anchor bit belongs to the neighbour: equal words <=> equal neighbours)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t hm = __ballot(nb[k] == e);
+        if (hm) r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
+    }
+    return true;
+}
+
 // Lists of up to 64*K entries, K consecutive entries per lane, everything in registers: one read of the list per step.
-template <int K, bool SQRT>
-__device__ __forceinline__ DetPick det_select_regs(const uint2 *ents, const Visited &vs, int lane, uint32_t row,
-                                                   uint32_t deg, uint32_t skip_n_best) {
+// REL: the row is read in its compact form (metric + 16-bit relative id; `nb` then holds ids relative to the band base
+// and the list holds no anchor): `node` = the row's own node.
+template <int K, bool SQRT, bool REL = false>
+__device__ __forceinline__ DetPick det_select_regs(const WalkArgs &a, const Visited &vs, int lane, uint32_t row,
+                                                   uint32_t deg, uint32_t skip_n_best, uint32_t node) {
     DetPick r{false, 0xFFFFFFFFu, 0u, false, 0xFFFFFFFFu};
     uint32_t nb[K], mb[K], o[K], vis[K];
-    lane_load<K>(ents, row, 0u, deg, lane, nb, mb);         // lanes past the list repeat lane 0's entries: masked by cnt
+    // lanes past the list repeat lane 0's entries: masked by cnt
+    if (REL) lane_load_c<K>(a.met, a.d16, row, deg, lane, node - vs.lo - 32768u, nb, mb);
+    else lane_load<K>(a.ents, row, 0u, deg, lane, nb, mb);
     const int cnt = (int) deg - K * lane;                     // entries of this lane inside the list (<= 0: none)
     const uint32_t pos0 = (uint32_t) (K * lane);
-    lane_probe<K>(vs, nb, vis);
+    if (REL) lane_probe_rel<K>(vs, nb, vis);
+    else lane_probe<K>(vs, nb, vis);
+    if (det_select_fast<K, SQRT, REL>(nb, mb, vis, lane, deg, skip_n_best, vs.lo, r)) return r;
     // ---- rank 0 and rank deg-1 (:289-296)
     uint32_t lmax = 0u, lmin = ~0u;
 #pragma unroll
@@ -1129,15 +1227,16 @@ __device__ __forceinline__ DetPick det_select_regs(const uint2 *ents, const Visi
             if (p < r.chosen) {
                 r.chosen = p;
                 const uint32_t e = readlane_u32(nb[k], fl);
-                r.chosen_nbr = e & 0x7FFFFFFFu;
-                r.chosen_anchor = (e >> 31) != 0;
+                r.chosen_nbr = REL ? e + vs.lo : e & 0x7FFFFFFFu;
+                r.chosen_anchor = REL ? false : (e >> 31) != 0;
             }
         }
     }
     // ---- :340-347
+    const uint32_t chosen_key = REL ? r.chosen_nbr - vs.lo : r.chosen_nbr;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const uint64_t hm = __ballot(k < cnt && (nb[k] & 0x7FFFFFFFu) == r.chosen_nbr);
+        const uint64_t hm = __ballot(k < cnt && (REL ? nb[k] : nb[k] & 0x7FFFFFFFu) == chosen_key);
         if (hm) r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
     }
     return r;
@@ -1318,9 +1417,16 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
             if (deg != 0 && skip_n_best < deg - 1) {
                 evals += deg;
                 steps++;
-                pk = deg <= 256u   ? det_select_regs<4, SQRT>(a.ents, vs, lane, row, deg, skip_n_best)
-                     : deg <= 384u ? det_select_regs<6, SQRT>(a.ents, vs, lane, row, deg, skip_n_best)
-                     : deg <= 512u ? det_select_regs<8, SQRT>(a.ents, vs, lane, row, deg, skip_n_best)
+                const bool compact = ((rfl(rec.y) >> 29) & 1u) != 0;
+                pk = compact && deg <= 768u
+                         ? (deg <= 256u   ? det_select_regs<4, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
+                            : deg <= 384u ? det_select_regs<6, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
+                            : deg <= 512u ? det_select_regs<8, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
+                                          : det_select_regs<12, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node))
+                     : deg <= 256u ? det_select_regs<4, SQRT>(a, vs, lane, row, deg, skip_n_best, node)
+                     : deg <= 384u ? det_select_regs<6, SQRT>(a, vs, lane, row, deg, skip_n_best, node)
+                     : deg <= 512u ? det_select_regs<8, SQRT>(a, vs, lane, row, deg, skip_n_best, node)
+                     : deg <= 768u ? det_select_regs<12, SQRT>(a, vs, lane, row, deg, skip_n_best, node)
                                    : det_select_long<SQRT>(a.ents, vs, lane, row, deg, skip_n_best);
             }
             go_back = pk.go_back;
@@ -1446,6 +1552,7 @@ __device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, ui
     ui = cu - slot * a.n_units;
     if (slot) {
         b.ents = a.ents1;
+        b.met = a.met1;
         b.flag_bit = a.flag_bit1;
         b.metric = a.metric1;
     }

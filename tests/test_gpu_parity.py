@@ -678,6 +678,49 @@ def test_fuzz_small_graphs(ctx, seed):
         _walk_both(ctx, dg, og, metric, None, mc=False)
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_deterministic_dense(ctx, seed):
+    """The deterministic builder on lists long enough for its in-register selection (4 / 6 / 8 entries per lane, compact and
+    8-byte rows): few distinct metric values (ties between ranks, the lowest rank shared by many entries, zeros), multi-edges
+    (the pushed entry is not the ranked one), few anchors so that walks run until they have to go back (rank 0 skipped
+    afterwards), negative metrics in some graphs (the general selection), lists that end inside a lane."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(150, 260))
+    degrees = rng.integers(1, int(rng.choice([40, 300, 420, 600])), size=n).astype(np.int64)
+    anchors = np.zeros(n, np.uint8)
+    anchors[rng.choice(n, size=2, replace=False)] = 1
+    degrees[anchors != 0] = rng.integers(20, 120, size=2)
+    row_ptr = np.zeros(n + 1, np.uint64)
+    row_ptr[1:] = np.cumsum(degrees)
+    a = int(row_ptr[-1])
+    nbr = rng.integers(0, n, size=a).astype(np.uint32)
+    owner = np.repeat(np.arange(n, dtype=np.uint32), degrees)
+    nbr = np.where(nbr == owner, (nbr + 1) % n, nbr).astype(np.uint32)
+    if seed % 4 != 3:                      # an anchor among the neighbours is rare, as on generated data
+        hit = anchors[nbr] != 0
+        keep_hit = rng.random(a) < 0.02
+        repl = np.nonzero(anchors == 0)[0][rng.integers(0, n - 2, size=a)]
+        repl = np.where(repl == owner, np.nonzero(anchors == 0)[0][0 if owner[0] != np.nonzero(anchors == 0)[0][0] else 1], repl)
+        nbr = np.where(hit & ~keep_hit, repl, nbr).astype(np.uint32)
+        nbr = np.where(nbr == owner, (nbr + 1) % n, nbr).astype(np.uint32)
+    levels = int(rng.choice([3, 12, 400, 100000]))
+    es = rng.integers(0, levels, size=a).astype(np.float32)
+    os_ = (rng.integers(0, levels, size=a) / 4.0).astype(np.float32)
+    if seed % 4 == 2:
+        os_ = np.where(rng.random(a) < 0.01, -os_, os_).astype(np.float32)
+    q_start = rng.integers(0, 9000, size=a).astype(np.uint32)
+    t_start = rng.integers(0, 9000, size=a).astype(np.uint32)
+    node_len = rng.integers(1, 90000, size=n).astype(np.uint32)
+    args = (row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    dg = ctx.graph_from_csr(*args)
+    og = po.Graph.from_csr(*args)
+    steps = 0
+    for metric in (capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_OS_SQRT):
+        ps, _ = _walk_both(ctx, dg, og, metric, None, mc=False)
+        steps += int(ps.unit_stats()["steps"].sum())
+    assert steps > 3000
+
+
 def test_rng_stream_through_long_walks(ctx):
     """More than 312 draws in one walk crosses an mt19937 twist on the device."""
     row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors = _synthetic_csr(n_reads=3000, deg=40, seed=3)
