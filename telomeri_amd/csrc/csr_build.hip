@@ -410,6 +410,7 @@ __global__ void invert_perm_kernel(uint32_t n_nodes, const uint32_t *__restrict_
 // Padded length of a row of the walk layout: a multiple of 8 entries (rows start on 64-byte boundaries, a lane of the
 // walk kernel owns 4 or 8 consecutive entries), and of 24 for the degrees the kernel reads with 6 entries per lane
 // (257..384): whatever the lane width, the last lane's entries end inside the row's own padding.
+constexpr uint32_t WALK_ROW0 = 256;      // the walk layout's arrays start with this many zero entries; the first row follows
 __host__ __device__ inline uint32_t tlm_padded_degree(uint32_t deg) {
     // lists read 6 or 12 entries per lane (257..384, 513..768): a lane's entries must not reach the next row
     return ((deg > 256u && deg <= 384u) || (deg > 512u && deg <= 768u)) ? ((deg + 23u) / 24u) * 24u : (deg + 7u) & ~7u;
@@ -454,7 +455,12 @@ __global__ __launch_bounds__(256) void walk_layout_kernel(uint32_t n_nodes, cons
         }
         // bit 29: the row may be read in its compact form (metric + 16-bit relative id, no anchor among the neighbours)
         // (a node without a list has no row of its own: a lane would read its successor's relative ids against the wrong node)
+#ifdef TLM_ABLATE_NOCOMPACT     /* timing-only build (results stay right): every step reads 8-byte rows */
+        const bool compact = false;
+        (void) far_nbr;
+#else
         const bool compact = deg != 0 && !__ballot(anchor_nbr) && !__ballot(far_nbr);
+#endif
         const uint32_t fl = (uint32_t) node_flags[o] | (__ballot(anchor_nbr) ? 16u : 0u) | (compact ? 32u : 0u);
         if (lane == 0) w_row[node] = make_uint2(w0, deg | (fl << 24));
         for (uint32_t j = lane; j < pdeg; j += 64) {
@@ -680,15 +686,15 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         if (int rc = dev_alloc(ws, ((size_t) N + 1) * 4)) return rc;
         uint64_t apad = 0;
         if (N) {
-            TLM_CHECK(g->n_adj + 23ull * N < (1ull << 32) - 256, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
+            TLM_CHECK(g->n_adj + 23ull * N < (1ull << 32) - 512, TLM_ELIMIT, "graph too large for the padded u32 walk layout");
             hipLaunchKernelGGL(padded_degree_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, g->row_ptr, g->w_old_of_new,
                                pd.as<uint32_t>());
             size_t tb = 0;
-            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+            TLM_HIP(rocprim::exclusive_scan(nullptr, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), WALK_ROW0, (size_t) N,
                                             rocprim::plus<uint32_t>(), s));
             DevBuf tmp;
             if (int rc = dev_alloc(tmp, tb)) return rc;
-            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), 0u, (size_t) N,
+            TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), WALK_ROW0, (size_t) N,
                                             rocprim::plus<uint32_t>(), s));
             uint32_t last_start = 0, last_pd = 0;
             TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
@@ -718,6 +724,13 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         TLM_HIP(hipMemsetAsync(g->w_m_os + apad, 0, 256 * 4, s));
         // relative id 32768 = "the row's own node": whatever a lane reads past the last row stays a valid node id
         TLM_HIP(hipMemsetD16Async((hipDeviceptr_t) (g->w_d16 + apad), 0x8000, 256, s));
+        // the block of zero entries in front of the first row (lanes past the end of a compact list read it)
+        TLM_HIP(hipMemsetAsync(g->w_m_es, 0, WALK_ROW0 * 4, s));
+        TLM_HIP(hipMemsetAsync(g->w_m_os, 0, WALK_ROW0 * 4, s));
+        TLM_HIP(hipMemsetD16Async((hipDeviceptr_t) g->w_d16, 0x8000, WALK_ROW0, s));
+        TLM_HIP(hipMemsetAsync(g->w_ent_es, 0, WALK_ROW0 * sizeof(uint2), s));
+        TLM_HIP(hipMemsetAsync(g->w_ent_os, 0, WALK_ROW0 * sizeof(uint2), s));
+        TLM_HIP(hipMemsetAsync(g->w_qt, 0, WALK_ROW0 * sizeof(uint2), s));
         // 256 zero entries of slack after the last row: a lane's 8-entry read never leaves the buffer
         TLM_HIP(hipMemsetAsync(g->w_ent_es + apad, 0, 256 * sizeof(uint2), s));
         TLM_HIP(hipMemsetAsync(g->w_ent_os + apad, 0, 256 * sizeof(uint2), s));

@@ -387,27 +387,42 @@ __device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint3
 }
 
 // The same K entries of a COMPACT row (row flag bit 29): 4-byte metric + 2-byte neighbour id relative to the row's own
-// node -- 6 bytes per eval instead of 8, 11 instead of 15 cache lines for a list of 236 entries.  The kernel runs at
-// the rate at which gathered rows leave HBM / the Infinity Cache, so bytes are time.  Ids come out
-// relative to the visited band (`d` = id - band base), which is what the probe wants anyway: id = d + lo.
+// node -- 6 bytes per eval instead of 8, 11 instead of 15 cache lines for a list of 236 entries.  m[k] = metric bits of
+// entry K*lane + k, w[j] = the ids of entries K*lane + 2j (low half) and 2j + 1.  Lanes past the end of the list read
+// entries 0.. of the arrays: a block of 256 zero entries in front of the first row (metric 0, relative id 32768 = the
+// row's own node, which is visited while the walk stands on it) -- they need no masking afterwards.
 template <int K>
-__device__ __forceinline__ bool lane_load_c(const uint32_t *met, const uint16_t *d16, uint32_t row, uint32_t deg, int lane,
-                                            uint32_t rel_base, uint32_t (&d)[K], uint32_t (&mb)[K]) {
+__device__ __forceinline__ void lane_load_cw(const uint32_t *met, const uint16_t *d16, uint32_t row, uint32_t deg, int lane,
+                                             uint32_t (&mb)[K], uint32_t (&w)[K / 2]) {
     const uint32_t first = (uint32_t) K * (uint32_t) lane;
-    const bool act = first < deg;
-    const uint32_t off = row + (act ? first : 0u);      // rows start at multiples of 8 entries: 32-byte / 16-byte aligned
+    const uint32_t off = first < deg ? row + first : 0u;     // rows start at multiples of 8 entries: 32-byte / 16-byte aligned
     struct alignas(K == 6 ? 8 : 16) Met { uint32_t v[K]; };
     struct alignas(K == 6 ? 4 : K == 12 ? 8 : 2 * K) Ids { uint32_t v[K / 2]; };
     const Met m = *reinterpret_cast<const Met *>(met + off);
-    const Ids w = *reinterpret_cast<const Ids *>(d16 + off);
+    const Ids ww = *reinterpret_cast<const Ids *>(d16 + off);
 #pragma unroll
     for (int k = 0; k < K; k++) mb[k] = m.v[k];
 #pragma unroll
+    for (int j = 0; j < K / 2; j++) w[j] = ww.v[j];
+}
+
+// ids relative to the visited band (`d` = id - band base), which is what the probe wants: id = d + lo
+template <int K>
+__device__ __forceinline__ void unpack_rel(const uint32_t (&w)[K / 2], uint32_t rel_base, uint32_t (&d)[K]) {
+#pragma unroll
     for (int j = 0; j < K / 2; j++) {
-        d[2 * j] = (w.v[j] & 0xFFFFu) + rel_base;       // (v_add_u32 with an SDWA word select)
-        d[2 * j + 1] = (w.v[j] >> 16) + rel_base;
+        d[2 * j] = (w[j] & 0xFFFFu) + rel_base;         // (v_add_u32 with an SDWA word select)
+        d[2 * j + 1] = (w[j] >> 16) + rel_base;
     }
-    return act;
+}
+
+template <int K>
+__device__ __forceinline__ bool lane_load_c(const uint32_t *met, const uint16_t *d16, uint32_t row, uint32_t deg, int lane,
+                                            uint32_t rel_base, uint32_t (&d)[K], uint32_t (&mb)[K]) {
+    uint32_t w[K / 2];
+    lane_load_cw<K>(met, d16, row, deg, lane, mb, w);
+    unpack_rel<K>(w, rel_base, d);
+    return (uint32_t) K * (uint32_t) lane < deg;
 }
 
 // visited masks for band-relative ids (compact rows hold no anchors: every id is a plain node id)
@@ -601,22 +616,99 @@ __device__ __forceinline__ Selection select_short(const HotArgs &a, const Visite
     return s;
 }
 
-// The same on a compact row (no anchor in the list, so no forced-anchor test; `node` = the row's own node).
+// The same on a compact row (no anchor in the list, so no forced-anchor test; `node` = the row's own node), with what
+// the compact form allows left out of the common path (the kernel is bound by vector-instruction issue):
+//   * no lane is masked: lanes past the list hold zero entries (lane_load_cw), padding names the row's own node;
+//   * the running sums inside a lane are the partial sums of the lane's own total, kept from the summation: the hit is
+//     the first entry whose partial sum reaches `random - (exclusive prefix of the lane)`.  On an order-safe row (the only
+//     rows that come here) that difference is exact: every prefix is a multiple of the row's quantum q with total <
+//     2^52 q, so ulp(random) < q and random - prefix has no bit below ulp(random) -- the comparison is the reference's
+//     `sum >= random` (:110), bit for bit;
+//   * "any candidate at all?" is only asked when the total is zero, by probing again;
+//   * the chosen neighbour is read from the packed id words (K / 2 readlanes and scalar selects, no per-lane chain).
 template <int K, bool SQRT>
 __device__ __forceinline__ Selection select_short_c(const HotArgs &a, const Visited &vs, Rng &rng, int lane, uint32_t row,
                                                     uint32_t deg, uint32_t node, uint32_t &draws, StepClock &clk) {
     Selection s{-1, 0u, 0u, 0u, 0u, deg};
-    uint32_t d[K], mb[K], vis[K];
-    const bool act = lane_load_c<K>(a.met, a.d16, row, deg, lane, node - vs.lo - 32768u, d, mb);
+    uint32_t w[K / 2], mb[K];
+    lane_load_cw<K>(a.met, a.d16, row, deg, lane, mb, w);
     clk.mark(CLK_LIST_WAIT, true);
-    lane_probe_rel<K>(vs, d, vis);
-    uint32_t va = ~0u;
+    const uint32_t rel_base = node - vs.lo - 32768u;
+    {
+        uint32_t d[K], vis[K];
+        unpack_rel<K>(w, rel_base, d);
+        lane_probe_rel<K>(vs, d, vis);
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        mb[k] &= ~vis[k];
-        va &= vis[k];
+        for (int k = 0; k < K; k++) mb[k] &= ~vis[k];
     }
-    select_in_regs<K, SQRT, true>(s, vs, rng, lane, 0u, act, d, mb, va, draws);
+    // ps[k] = candidates' metrics of the lane's entries 0..k (:64); kept across the scan for the shorter lists, summed
+    // again afterwards for 8 and 12 entries per lane (registers)
+    constexpr bool KEEP = K <= 6;
+    double ps[K];
+    ps[0] = metric_f64<SQRT>(mb[0]);
+#pragma unroll
+    for (int k = 1; k < K; k++) ps[k] = ps[k - 1] + metric_f64<SQRT>(mb[k]);
+    const double ls = ps[K - 1];
+#ifdef TLM_ABLATE_NOSCAN
+    const double incl = ls * (double) (lane + 1);
+#else
+    const double incl = wave_incl_scan_f64(ls);
+#endif
+    const double total = readlane_f64(incl, 63);
+    // the unvisited entries of a lane, asked for on the two rare paths only
+    auto unvisited = [&](uint32_t (&vis)[K]) {
+        uint32_t d[K];
+        unpack_rel<K>(w, rel_base, d);
+#pragma unroll
+        for (int k = 0; k < K; k++) asm volatile("" : "+v"(d[k]));     // opaque: nothing of the first probe is kept alive
+        lane_probe_rel<K>(vs, d, vis);
+        uint32_t va = ~0u;
+#pragma unroll
+        for (int k = 0; k < K; k++) va &= vis[k];
+        return va != ~0u;
+    };
+    if (__builtin_expect(total == 0.0, 0)) {            // dead end, or candidates of metric 0
+        uint32_t vis[K];
+        if (!__ballot(unvisited(vis))) return s;        // :72
+    }
+    s.ncand = 1;
+    const double random = mt_canonical(rng, lane) * total;     // :104
+    draws++;
+    int hl, myk = K - 1;
+    if (__builtin_expect(random == 0.0, 0)) {
+        // `sum >= 0` holds at the first candidate of the list (:110)
+        uint32_t vis[K];
+        hl = __ffsll((unsigned long long) __ballot(unvisited(vis))) - 1;
+#pragma unroll
+        for (int k = K - 2; k >= 0; k--)
+            if (vis[k] == 0u) myk = k;
+    } else {
+        // the first lane whose inclusive prefix reaches `random` holds the hit
+        const uint64_t hm = __ballot(incl >= random);
+        if (!hm) return s;                              // not reachable for finite sums (u < 1)
+        hl = __ffsll((unsigned long long) hm) - 1;
+        const double rr = random - (incl - ls);
+        if (!KEEP) {
+#pragma unroll
+            for (int k = 0; k < K; k++) asm volatile("" : "+v"(mb[k]));        // (a second summation, not kept sums)
+            ps[0] = metric_f64<SQRT>(mb[0]);
+#pragma unroll
+            for (int k = 1; k < K - 1; k++) ps[k] = ps[k - 1] + metric_f64<SQRT>(mb[k]);
+        }
+#pragma unroll
+        for (int k = K - 2; k >= 0; k--)
+            if (ps[k] >= rr) myk = k;                   // :110, first k wins; entries that are no candidates add +0
+    }
+    const uint32_t k = (uint32_t) __builtin_amdgcn_readlane(myk, hl);
+    uint32_t raw = readlane_u32(w[0], hl);
+#pragma unroll
+    for (int j = 1; j < K / 2; j++) {
+        const uint32_t rj = readlane_u32(w[j], hl);
+        if ((k >> 1) == (uint32_t) j) raw = rj;
+    }
+    const uint32_t rel = (k & 1u) ? raw >> 16 : raw & 0xFFFFu;
+    s.pick = hl * K + (int) k;
+    s.nbr = node + rel - 32768u;
     return s;
 }
 
