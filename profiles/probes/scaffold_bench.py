@@ -91,6 +91,7 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
     if not os.path.exists(binary):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "telomeri_amd", "host")], check=True)
     t0 = time.time()
+    own = ds is None
     if ds is None:
         ds = synth.make_config(config, device=device)
     n_rec = len(ds.rr) + len(ds.cr)
@@ -106,13 +107,33 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
         nb += write_fasta(ds, reads, contigs)
         out["input_bytes"] = nb
         out["input_written_s"] = round(time.time() - t0, 2)
+        # nothing of this process stays on the device while the program under test runs (the generator's tensors and the
+        # allocator's cached blocks would otherwise sit scattered in the device memory the program allocates from)
+        if own:
+            del ds
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+        except ImportError:
+            pass
         t0 = time.time()
         cmd = [binary] + list(extra_args) + [rr, cr, reads, contigs, fasta]
         prof = os.environ.get("TLM_SCAFFOLD_ROCPROF")      # a directory: kernel trace + stats of the host program's run
         if prof:
             cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", prof, "--"] + cmd
+        t_spawn = time.time()
         res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, TLM_HOST_TIMING="1"))
-        out["scaffold_wall_s"] = round(time.time() - t0, 3)
+        t_done = time.time()
+        out["scaffold_wall_s"] = round(t_done - t0, 3)
+        marks = {m.group(1): float(m.group(2)) for m in re.finditer(r"\[host timing\] ([a-z ]+) at ([0-9.]+)", res.stderr)}
+        if "main entered" in marks:
+            out["marks_s"] = {k: round(v - t_spawn, 3) for k, v in sorted(marks.items(), key=lambda kv: kv[1])}
+        if "main entered" in marks and "main left" in marks:      # what the stages below do not cover
+            out["outside_stages_s"] = {"exec_to_main": round(marks["main entered"] - t_spawn, 3),
+                                       "main_to_loading": round(marks.get("loading starts", marks["main entered"]) - marks["main entered"], 3),
+                                       "main_left_to_exit": round(t_done - marks["main left"], 3)}
         out["exit"] = res.returncode
         out["host_timing"] = [ln[len("[host timing] "):] for ln in res.stderr.splitlines() if ln.startswith("[host timing]")]
         done = [float(x) for x in re.findall(r"Done \(([0-9.e+-]+)s\)", res.stdout)]

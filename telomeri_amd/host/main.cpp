@@ -9,6 +9,10 @@
 // hot path.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -17,7 +21,8 @@
 #include "../../include/telomeri_hip.h"
 
 int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vector<const Path *>> &paths_between_anchors,
-                    const char *reads_file, const char *contigs_file, const char *output_file);
+                    const char *reads_file, const char *contigs_file, const char *output_file,
+                    std::function<Scaffolder *()> loaded, bool leave_mapped);
 
 static bool parse_ulong(const char *s, ulong &v) {
     char *end = nullptr;
@@ -39,7 +44,15 @@ static unsigned bits_of(float f) {
     return u;
 }
 
+static void stamp(const char *what) {       // TLM_HOST_TIMING: where the wall-clock outside the stages goes (start-up, exit)
+    if (!std::getenv("TLM_HOST_TIMING")) return;
+    const double now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    std::fprintf(stderr, "[host timing] %s at %.3f\n", what, now);
+}
+
 int main(int argc, char **argv) {
+    stamp("main entered");
+    struct AtExit { ~AtExit() { stamp("main left"); } } at_exit;
     OverlapGraph graph;
     PathManager pm;
     const char *mode_string = "AVG";
@@ -105,6 +118,7 @@ int main(int argc, char **argv) {
         t0 = t1;
         return s;
     };
+    stamp("loading starts");
     std::cout << "\nLoading overlaps..." << std::endl;
     double parse_ms = 0, build_ms = 0, dl_ms = 0;
     // By default the adjacency and the paths' node lists stay on the device (lean graph, packed paths): the host stages
@@ -125,6 +139,23 @@ int main(int argc, char **argv) {
               << "), device graph build " << build_ms << " ms, download+materialise " << dl_ms << " ms" << std::endl;
     std::cout << "Done (" << lap() << "s)" << std::endl << graph.stats() << std::endl;
 
+    // The reads and contigs are not needed before the Scaffolder runs, and the host has nothing to do while the device
+    // walks: the FASTA files are mapped and indexed on a second thread from here on (Main.cpp:357-360 loads them after
+    // the consensus; same tables, same messages on failure, the exit code at the same place).
+    static const Path no_path;
+    std::unique_ptr<Scaffolder> fasta;
+    std::thread fasta_thread;
+    bool fasta_ok = false;
+    if (!no_scaffold && !std::getenv("TLM_NO_FASTA_AHEAD")) {
+        fasta.reset(new Scaffolder(no_path));
+        fasta_thread = std::thread([&] { fasta_ok = fasta->load(pos[2]) && fasta->load(pos[3]); });
+    }
+    struct Join {
+        std::thread &t;
+        ~Join() { if (t.joinable()) t.join(); }
+    } join_fasta{fasta_thread};
+
+    stamp("graph loaded");
     std::cout << "Calculating paths..." << std::endl;
     FILE *out = nullptr;
     if (!dump.empty()) {
@@ -199,11 +230,30 @@ int main(int argc, char **argv) {
     std::cout << "edge-extension evals: " << evals << " in " << kernel_ms << " ms of walk kernels ("
               << (kernel_ms > 0 ? evals / (kernel_ms * 1e-3) : 0.0) << " evals/s)" << std::endl;
     std::cout << "Anchor pairs with paths: " << pba.size() << std::endl;
+    stamp("paths built");
     if (no_scaffold) return 0;
     const auto t_total = std::chrono::steady_clock::now();
     static char dev_null[] = "/dev/null";
-    const int rc = run_post_stages(pm, pba, pos[2], pos[3], keeps_output ? pos[4] : dev_null);     // Main.cpp:254-388
+    std::function<Scaffolder *()> loaded;
+    if (fasta) loaded = [&]() -> Scaffolder * {
+        if (fasta_thread.joinable()) fasta_thread.join();
+        return fasta_ok ? fasta.get() : nullptr;
+    };
+    const bool fast_exit = tlm_dist_world(OverlapGraph::context()) == 1 && !std::getenv("TLM_CLEAN_EXIT");
+    const int rc = run_post_stages(pm, pba, pos[2], pos[3], keeps_output ? pos[4] : dev_null, loaded, fast_exit);     // Main.cpp:254-388
+    stamp("scaffold written");
     std::cout << "Host stages after the path build: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_total).count()
               << "s" << std::endl;
+    // The scaffold is on disk.  Tearing the process down piece by piece (unmapping 10 GB of FASTA, returning 20 GB of
+    // device memory block by block, destroying the context) took 0.5 s of the A. thaliana run; the kernel does the same
+    // for a process that simply ends.  One-process jobs only (ranks of a multi-GPU job leave their communicator in order);
+    // TLM_CLEAN_EXIT=1 keeps the destructors (leak checkers).
+    if (fast_exit) {
+        std::cout.flush();
+        std::cerr.flush();
+        std::fflush(nullptr);
+        stamp("main left");
+        std::_Exit(rc);
+    }
     return rc;
 }

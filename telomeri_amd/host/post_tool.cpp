@@ -9,10 +9,13 @@
 #include <iostream>
 #include <sstream>
 
+#include <functional>
+
 #include "telomeri_host.hpp"
 
 int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vector<const Path *>> &paths_between_anchors,
-                    const char *reads_file, const char *contigs_file, const char *output_file);
+                    const char *reads_file, const char *contigs_file, const char *output_file,
+                    std::function<Scaffolder *()> loaded, bool leave_mapped);
 
 static float bits_to_float(unsigned u) {
     float f;
@@ -122,5 +125,5 @@ int main(int argc, char **argv) {
         std::fclose(out);
         return 0;
     }
-    return run_post_stages(pm, pba, pos[1], pos[2], pos[3]);
+    return run_post_stages(pm, pba, pos[1], pos[2], pos[3], nullptr, false);
 }

@@ -315,11 +315,19 @@ class Scaffolder {                      // Scaffolder.hpp:11-34
 public:
     const Path &p_;
     std::vector<std::string> names_;
-    /** As in the reference, one string per record -- but filled on demand: load() maps the file and notes where every
-     *  sequence line lies; getSequenceFrom() copies the ones the scaffold uses (a fifth of the reads on the
-     *  A. thaliana-shaped input: 2 GB instead of 10).  materialiseAll() fills the rest (the reference's state). */
+    /** As in the reference, one string per record -- but filled on demand: load() scans the file and notes where every
+     *  sequence line lies; getSequenceFrom() reads the ones somebody asks for, write() reads the few hundred characters it
+     *  cuts from each read of the scaffold (a fifth of the reads on the A. thaliana-shaped input).  materialiseAll()
+     *  fills the rest (the reference's state). */
     std::vector<std::string> sequences_;
     explicit Scaffolder(const Path &p) : p_(p) {}
+    /** The tables of `loaded` (a Scaffolder whose load() calls ran before the scaffold path existed -- telomeri_hip reads
+     *  the FASTA files while the device walks) under the path `p`. */
+    Scaffolder(const Path &p, Scaffolder &&loaded)
+        : p_(p), names_(std::move(loaded.names_)), sequences_(std::move(loaded.sequences_)), index_(std::move(loaded.index_)),
+          where_(std::move(loaded.where_)), files_(std::move(loaded.files_)) {
+        loaded.files_.clear();
+    }
     ~Scaffolder();
     Scaffolder(const Scaffolder &) = delete;
     Scaffolder &operator=(const Scaffolder &) = delete;
@@ -332,9 +340,9 @@ public:
 
 private:
     std::unordered_map<std::string, size_t> index_;     // name -> first index (the reference scans linearly)
-    struct View { const char *p; size_t n; };
-    std::vector<View> where_;                           // sequence line of record i inside a mapped file (p = null: none)
-    std::vector<std::pair<void *, size_t>> maps_;       // the mapped files, until the Scaffolder goes
+    struct View { int file; size_t off, n; };           // file < 0: none (the string is in sequences_, or there is no such line)
+    std::vector<View> where_;                           // where the sequence line of record i lies in a loaded file
+    std::vector<int> files_;                            // the loaded files (descriptors), until the Scaffolder goes
 };
 
 #endif
