@@ -314,9 +314,15 @@ def main() -> None:
     if world == 1 and not args.no_scaffold:
         # the metric's second half: PAF + FASTA TEXT in -> scaffold FASTA out through the C++ host program, on the same
         # config, reference argv and defaults (profiles/probes/scaffold_bench.py; outside the timed region above)
+        # nothing of this process stays on the device while the program runs
         del g
+        import gc
+        gc.collect()
         ctx.trim()
         torch.cuda.empty_cache()
+        mi = ctx.memory_info()
+        out["device_memory_kept_during_scaffold_leg"] = {"library_live_bytes": int(mi.live_bytes), "library_cached_bytes": int(mi.cached_bytes),
+                                                         "torch_reserved_bytes": int(torch.cuda.memory_reserved())}
         try:
             import importlib.util
             spec = importlib.util.spec_from_file_location("scaffold_bench", os.path.join(ROOT, "profiles", "probes", "scaffold_bench.py"))
