@@ -649,12 +649,14 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));
             if (launched) launched->store(1);
-            if (lane == 0 && round == 0) tlm_ctx_start_deferred(ctx);      // the device is busy for a while: the host tidies up
+            static const bool tidy_after = [] { const char *e = std::getenv("TLM_TIDY"); return e && !std::strcmp(e, "after"); }();
+            if (lane == 0 && round == 0 && !tidy_after) tlm_ctx_start_deferred(ctx);      // the device is busy for a while: the host tidies up
             unsigned long long span[2] = {0, 0};
             TLM_HIP(hipMemcpyAsync(span, W.cursor + 6, 16, hipMemcpyDeviceToHost, s));
             TLM_HIP(hipMemcpyAsync(h_units, u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipEventSynchronize(ev1));
             TLM_HIP(hipStreamSynchronize(s));
+            if (lane == 0 && round == 0 && tidy_after) tlm_ctx_start_deferred(ctx);
             float ms = 0;
             TLM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             cnt[0].kernel_ms += ms;          // the launch is shared by the slots: it is booked on the first one

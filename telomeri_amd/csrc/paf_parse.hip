@@ -499,7 +499,15 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             for (uint64_t k = 0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);   // (instant while the device idles)
             tlm_ctx_defer(p->ctx, [m, bytes] {
                 const auto t1 = std::chrono::steady_clock::now();
-                ::munmap(m, bytes);      // (0.65 s for 15.6 GB of populated pages, serialised by the kernel whatever the thread count)
+                // 0.55 s for the 3.8 M page-table entries of a 15.6 GB file, one core, whatever the thread count.  Two
+                // things were tried against it (gpurun_out/r02_child): dropping the entries 64 MB at a time
+                // (MADV_DONTNEED) so that the address-space lock is free in between -- every call makes the driver stop
+                // and restart the process's device queues (the range had been registered with it), the walk kernels took
+                // 1.6-2.5 s instead of 0.78 s; and not mapping at all (all cores copy the file into a ring of pinned
+                // slabs, DMA per slab) -- the cores of a one-GPU box copy at 11 GB/s, 1.4 s against the 0.31 s of the
+                // registered mapping.  One munmap it stays; in about one run of four it stops the queues once, for as
+                // long as it takes (walk kernels 1.33-1.37 s), and the wall-clock is the same: the host waits either way.
+                ::munmap(m, bytes);
                 if (getenv("TLM_HOST_TIMING"))
                     fprintf(stderr, "[host timing] behind the scenes: unmapping %.0f ms\n",
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

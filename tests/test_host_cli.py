@@ -332,12 +332,12 @@ def test_cli_text_upload_through_slabs(binary):
     with tempfile.TemporaryDirectory() as tmp:
         rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
         outs = []
-        for env in ({}, {"TLM_UPLOAD_SLABS": "1"}):
+        for env in ({}, {"TLM_UPLOAD_SLABS": "1"}, {"TLM_TIDY": "after"}):
             res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, cr, "r", "c", "o"], capture_output=True, text=True,
                                  timeout=300, env=dict(os.environ, **env))
             assert res.returncode == 0 and "(device)" in res.stdout, res.stderr
             outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
-        assert outs[0] == outs[1]
+        assert outs[0] == outs[1] == outs[2]
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
