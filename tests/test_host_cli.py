@@ -128,6 +128,14 @@ def test_cli_scaffold_end_to_end(binary, name):
             assert open(out, "rb").read() == open(want, "rb").read()
             pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Consensus length", "Final consensus", "ctg", "read"))]
             assert pick(res.stdout) == pick(exp.stdout)
+            # the same program with its shortcuts off: FASTA files loaded where the reference loads them (not on a second
+            # thread during the walks), destructors instead of _Exit -- same bytes, same report
+            out2 = os.path.join(tmp, "gpu2.fa")
+            res2 = subprocess.run([binary] + _flags(meta["args"]) + [rr, cr, reads, contigs, out2], capture_output=True, text=True,
+                                  timeout=300, env=dict(os.environ, TLM_NO_FASTA_AHEAD="1", TLM_CLEAN_EXIT="1"))
+            assert res2.returncode == 0, res2.stderr
+            assert open(out2, "rb").read() == open(want, "rb").read()
+            assert pick(res2.stdout) == pick(exp.stdout)
 
 
 def test_cli_error_conventions(binary):
@@ -135,6 +143,15 @@ def test_cli_error_conventions(binary):
     assert res.returncode == 1 and "Cannot open file: /nonexistent/rr.paf" in res.stderr
     res = subprocess.run([binary, "only", "three", "args"], capture_output=True, text=True)
     assert res.returncode == 1 and "Please provide a path" in res.stderr
+    # a sequence file that cannot be opened (Scaffolder.cpp:15-18, Main.cpp:357-360): message and exit code 1, whether the
+    # files are loaded ahead on the second thread or where the reference loads them
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
+        for env in ({}, {"TLM_NO_FASTA_AHEAD": "1"}):
+            res = subprocess.run([binary, "--rb-att", "20", rr, cr, "/nonexistent/reads.fa", "/nonexistent/contigs.fa",
+                                  os.path.join(tmp, "o.fa")], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            assert res.returncode == 1, res.stdout[-500:]
+            assert "Cannot open file: /nonexistent/reads.fa" in res.stderr or "No consensus found!" in res.stderr
 
 
 def test_bundled_fixture_through_cli(binary):
