@@ -44,10 +44,16 @@ static unsigned bits_of(float f) {
     return u;
 }
 
+static bool g_context_in_use = false;       // (the context is created by the first load)
 static void stamp(const char *what) {       // TLM_HOST_TIMING: where the wall-clock outside the stages goes (start-up, exit)
     if (!std::getenv("TLM_HOST_TIMING")) return;
     const double now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
     std::fprintf(stderr, "[host timing] %s at %.3f\n", what, now);
+    tlm_memory_info mi;
+    if (g_context_in_use && tlm_ctx_memory_info(OverlapGraph::context(), &mi) == TLM_OK)
+        std::fprintf(stderr, "[host timing]   device memory so far: %llu driver allocations in %.0f ms, %llu requests served from the cache, "
+                             "%.1f GB live, %.1f GB cached\n", (unsigned long long) mi.driver_allocs, mi.driver_alloc_ms,
+                     (unsigned long long) mi.reuses, mi.live_bytes * 1e-9, mi.cached_bytes * 1e-9);
 }
 
 int main(int argc, char **argv) {
@@ -155,6 +161,7 @@ int main(int argc, char **argv) {
         ~Join() { if (t.joinable()) t.join(); }
     } join_fasta{fasta_thread};
 
+    g_context_in_use = true;
     stamp("graph loaded");
     std::cout << "Calculating paths..." << std::endl;
     FILE *out = nullptr;
@@ -204,12 +211,15 @@ int main(int argc, char **argv) {
             }
         }
     }
+    stamp("builders done");
     pm.gather();                    // multi-GPU jobs: the one exchange (nothing happens in a one-process job)
     // Every rank now knows every path (summaries; node lists come from their owners on demand, collectively): all ranks
     // run the same host stages below, rank 0 keeps the scaffold file.
     const bool keeps_output = tlm_dist_rank(OverlapGraph::context()) == 0;
     pm.filterUnique();                                                                // Main.cpp:247
+    stamp("unique filtered");
     auto pba = pm.getPathsBetweenAnchors();                                           // Main.cpp:251-252
+    stamp("anchor pairs done");
     if (out) {
         std::fprintf(out, "U %zu\n", pm.paths().size());
         for (const Path &p : pm.paths()) {

@@ -1,6 +1,8 @@
 // telomeri_amd/host/path_manager.cpp -- Path and PathManager over the C ABI.
 #include "telomeri_host.hpp"
 
+#include <chrono>
+#include <cstdio>
 #include <algorithm>
 #include <cstdlib>
 #include <iostream>
@@ -166,7 +168,9 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
     }
     tlm_pathset *sets[4] = {nullptr, nullptr, nullptr, nullptr};
     tlm_counters c[4];
+    const auto t_call = std::chrono::steady_clock::now();
     if (tlm_walk_builders(ctx, dg, (int) ma, (int) mb, &wp, mc0, mc1, d0, d1, sets, c) != TLM_OK) die_tlm("walk");
+    const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     graph_ = &g;
     last_counters = Counters{0, 0, 0, 0, 0, 0.0};
     const Utils::Metrics metric_of[4] = {ma, mb, ma, mb};
@@ -182,6 +186,11 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
         last_counters.draws += c[k].draws; last_counters.accepted += c[k].accepted;
         last_counters.kernel_ms += k < 2 ? c[k].kernel_ms : c[k].kernel_busy_ms;
     }
+    if (std::getenv("TLM_HOST_TIMING"))
+        std::fprintf(stderr, "[host timing] builders: the device call %.0f ms (Monte-Carlo launch %.0f ms; deterministic launch %.0f ms from "
+                             "queueing to its end, %.0f ms of it running), then %.0f ms for the paths' views\n", call_ms, c[0].kernel_ms,
+                     c[2].kernel_ms, c[2].kernel_busy_ms,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() - call_ms);
     if (!packed_) materialiseAll();
 }
 
