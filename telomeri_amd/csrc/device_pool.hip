@@ -7,14 +7,16 @@
 // and slow to re-use blocks freed on another stream (a second graph build took 10x the first one).  So: blocks are
 // hipMalloc'd once, kept in a size-ordered free list when released, and handed out again to requests of (nearly) the
 // same size; a request that finds no such block but a much larger one takes its share of that one (the rest stays in the
-// list as a block of its own; freed neighbours of one driver allocation grow together again when nothing is pending on
-// them).  Without that the host program allocated 30 GB afresh for its walks (0.85 s of hipMalloc, behind the
+// list as a block of its own.  Pieces are never merged again: a freed block keeps its size, so a caller that repeats its
+// requests -- a graph rebuilt, a walk call repeated -- finds every block it used the last time, whatever happened in
+// between; merged neighbours did not, and the driver call that then became necessary took a second right behind a
+// large release).  Without that the host program allocated 30 GB afresh for its walks (0.85 s of hipMalloc, behind the
 // address-space lock another thread was holding for an unmapping) while 35 GB sat in the list: the uploaded text, the
 // columns and the build's temporaries, all of other sizes.  Ordering between the old and the new user of a block:
 //   * same stream        -> stream order, nothing to do;
 //   * another stream     -> the new stream waits for an event recorded on the old stream at release time;
 //   * released "synced"  -> the caller has synchronised the device (graph / path-set destruction), nothing to wait for;
-//   * a block that is split or merged while an event is pending on it waits for that event on the host first.
+//   * a split leaves what is pending on the block pending on its rest.
 // Nothing here touches the device's default memory pool or any other process-wide HIP setting.  tlm_pool_trim returns
 // every cached block to the driver (tlm_ctx_trim in the ABI).
 #include <algorithm>
@@ -103,8 +105,7 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
     TLM_HIP(hipGetDevice(&dev));
     Pool &P = pool_of(dev);
     const size_t need = round_size(bytes);
-    Block *b = nullptr, *pending_rest = nullptr;
-    hipEvent_t wait_on_host = nullptr;      // a pending event of a block that is being split
+    Block *b = nullptr;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.cached.lower_bound(need);
@@ -119,11 +120,13 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
             // the smallest block that holds the request with a useful rest: the request takes its head
             Block *big = it->second;
             cache_remove(P, big);
-            if (big->ev_pending) wait_on_host = big->ev;
+            // what is pending on the block stays pending on its rest (the event is the rest's); the head's new user is
+            // either on the same stream (stream order) or made to wait for the event here, on the device
+            if (big->ev_pending && big->stream != s) (void) hipStreamWaitEvent(s, big->ev, 0);
             b = new Block();
             b->p = big->p;
             b->bytes = need;
-            b->stream = big->stream;
+            b->stream = s;
             b->slab = big->slab;
             b->slab->live++;
             big->p = (char *) big->p + need;
@@ -131,23 +134,9 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
             big->slab->pieces.erase(b->offset());
             big->slab->pieces[b->offset()] = b;
             big->slab->pieces[big->offset()] = big;
-            if (wait_on_host) {             // both parts are clean once the host has seen the event (below, outside the lock):
-                big->ev_pending = false;    // the rest goes back to the list only then
-            } else {
-                cache_insert(P, big);
-                big = nullptr;
-            }
+            cache_insert(P, big);
             P.info.reuses++;
-            if (big) {                      // (kept out of the list until the event has been waited for)
-                b->ev_pending = false;
-                pending_rest = big;
-            }
         }
-    }
-    if (wait_on_host) {
-        (void) hipEventSynchronize(wait_on_host);
-        std::lock_guard<std::mutex> lk(P.mu);
-        cache_insert(P, pending_rest);
     }
     if (b) {
         if (b->ev_pending && b->stream != s) TLM_HIP(hipStreamWaitEvent(s, b->ev, 0));
@@ -218,33 +207,6 @@ void tlm_pool_free(void *p, bool device_is_synced) {
         }
     }
     std::lock_guard<std::mutex> lk(P.mu);
-    // freed neighbours of the same driver allocation grow together again (only blocks nothing is pending on)
-    if (!b->ev_pending) {
-        auto &pieces = b->slab->pieces;
-        auto me = pieces.find(b->offset());
-        if (me != pieces.end()) {
-            auto nx = std::next(me);
-            if (nx != pieces.end() && nx->second->cached && !nx->second->ev_pending) {
-                Block *n = nx->second;
-                cache_remove(P, n);
-                b->bytes += n->bytes;
-                pieces.erase(nx);
-                drop_block(n);
-            }
-            if (me != pieces.begin()) {
-                auto pv = std::prev(me);
-                if (pv->second->cached && !pv->second->ev_pending) {
-                    Block *q = pv->second;
-                    cache_remove(P, q);
-                    q->bytes += b->bytes;
-                    q->stream = b->stream;
-                    pieces.erase(me);
-                    drop_block(b);
-                    b = q;
-                }
-            }
-        }
-    }
     cache_insert(P, b);
 }
 
