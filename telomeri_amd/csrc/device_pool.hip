@@ -61,7 +61,7 @@ struct Pool {
     tlm_memory_info info{};
 };
 
-constexpr size_t SPLIT_MIN = 64u << 20;       // blocks are split only into pieces of at least this size
+constexpr size_t SPLIT_MIN = 8u << 20;        // blocks are split only into pieces of at least this size
 
 constexpr int MAX_DEVICES = 64;
 
