@@ -308,6 +308,29 @@ void tlm_paf_destroy(tlm_paf *p);
 /* One file of the graph, in load order (at most 4).  `anchors` is OverlapGraph::load's second argument. */
 int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint64_t *n_records, int *clean);
 int tlm_paf_add_text(tlm_paf *p, const char *text_host, uint64_t bytes, int anchors, uint64_t *n_records, int *clean);
+
+/* The same with the text brought to the device by ANOTHER process (an upload helper: telomeri_hip starts one): the file's
+ * mapping, its registration with the device and the taking down of both belong to that process.  Unmapping 15.6 GB costs
+ * 0.55 s of one core under the process's address-space lock and disturbs the device queues of the process that does it
+ * -- the walking process pays neither.  The processes share a window of TLM_UPLOAD_SLOTS slots of 1 GiB of device memory:
+ *   this process : tlm_upload_window_create (once; the HIP IPC handle goes to the helper), then per file
+ *                  tlm_paf_text_begin, tlm_paf_text_piece(k) whenever the helper reports piece k (1 GiB) in its slot
+ *                  k mod TLM_UPLOAD_SLOTS -- copies it to its place and frees the slot --, tlm_paf_text_commit (tokenises
+ *                  like tlm_paf_add_file) or tlm_paf_text_abort;
+ *   the helper   : tlm_upload_window_open (once), then per file tlm_upload_file_window, which calls `arrived(k)` when piece
+ *                  k is in its slot and `slot_free(k)` before it overwrites a slot (to wait until the other side has
+ *                  taken piece k - TLM_UPLOAD_SLOTS over); either returning non-zero gives the upload up. */
+#define TLM_IPC_HANDLE_BYTES 64
+#define TLM_UPLOAD_SLOTS 3
+typedef int (*tlm_upload_piece_fn)(uint64_t piece, void *user);
+int tlm_upload_window_create(tlm_ctx *ctx, uint8_t *handle_out, uint64_t *bytes_out);
+int tlm_paf_text_begin(tlm_paf *p, uint64_t bytes);
+int tlm_paf_text_piece(tlm_paf *p, uint64_t piece);
+int tlm_paf_text_commit(tlm_paf *p, int anchors, uint64_t *n_records, int *clean);
+void tlm_paf_text_abort(tlm_paf *p);
+int tlm_upload_window_open(tlm_ctx *ctx, const uint8_t *handle);
+int tlm_upload_file_window(tlm_ctx *ctx, const char *path, uint64_t bytes, tlm_upload_piece_fn arrived,
+                           tlm_upload_piece_fn slot_free, void *user);
 /* After the last file: final name ids.  n_names names, blob_bytes bytes of name text in all. */
 int tlm_paf_finish(tlm_paf *p, uint32_t *n_names, uint64_t *blob_bytes);
 /* HOST buffers (any may be NULL): name i = blob[name_off[i] .. name_off[i + 1]); is_ctg[i] = Utils::startsWithInsensitive(name, "ctg") */

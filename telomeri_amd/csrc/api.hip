@@ -158,6 +158,8 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     c->side.ws.release_host();
     (void) hipFree(c->side.ws.cursor);
     if (c->resident_host) (void) hipHostFree(c->resident_host);
+    if (c->peer_window) (void) hipIpcCloseMemHandle(c->peer_window);
+    if (c->upload_window) (void) hipFree(c->upload_window);
     for (hipEvent_t e : c->phase_ev) (void) hipEventDestroy(e);
     if (c->side.ev0) (void) hipEventDestroy(c->side.ev0);
     if (c->side.ev1) (void) hipEventDestroy(c->side.ev1);

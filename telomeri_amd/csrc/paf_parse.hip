@@ -15,6 +15,7 @@
 // every line 16 tokens, plain integers, one-character strand, no blank lines; then line-wise parsing IS the token
 // stream.  Anything else raises `clean = 0` and the caller falls back to the exact operator>> reader on the host.
 // tests/test_gpu_parity.py compares columns, ids and names with the host tokeniser on every fixture and malformed input.
+#include <functional>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -320,6 +321,8 @@ struct tlm_paf {
     char *blob = nullptr;
     uint64_t blob_bytes = 0;
     double upload_ms = 0, parse_ms = 0, finish_ms = 0;
+    char *pending = nullptr;             // text buffer handed out by tlm_paf_text_alloc, not yet committed
+    uint64_t pending_bytes = 0;
 };
 
 extern "C" int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out) {
@@ -342,6 +345,7 @@ extern "C" void tlm_paf_destroy(tlm_paf *p) {
     }
     tlm_pool_free(p->slot); tlm_pool_free(p->n_names_dev); tlm_pool_free(p->is_ctg); tlm_pool_free(p->name_off);
     tlm_pool_free(p->blob);
+    tlm_pool_free(p->pending);
     delete p;
 }
 
@@ -416,26 +420,22 @@ static int tokenise_on_device(tlm_paf *p, int f, uint64_t *n_records, int *clean
     return TLM_OK;
 }
 
-extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint64_t *n_records, int *clean) {
-    TLM_CHECK(p && path && n_records && clean, TLM_EINVAL, "tlm_paf_add_file: null argument");
-    TLM_CHECK(!p->finished && p->n_files < MAX_FILES, TLM_EINVAL, "tlm_paf_add_file: at most %d files, before tlm_paf_finish", MAX_FILES);
-    TLM_HIP(hipSetDevice(p->ctx->device));
-    hipStream_t s = p->ctx->stream;
-    const int fd = ::open(path, O_RDONLY);
-    TLM_CHECK(fd >= 0, TLM_EINVAL, "Cannot open file: %s", path);
-    struct stat st;
-    ::fstat(fd, &st);
-    const uint64_t bytes = (uint64_t) st.st_size;
-    TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_add_file: file too large");
-    const int f = p->n_files;
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = tlm_pool_alloc((void **) &p->text[f], bytes + 64, s);
+// The registered-mapping upload of a file into `dst` (device memory).  Straight out of the page cache: the file is
+// mapped, and piece by piece (1 GiB) the pages are faulted in by all cores, pinned (hipHostRegister) and handed to ONE DMA
+// each; the faults of piece k+1 run while piece k crosses PCIe.  No staging copy on the host at all (measured on the
+// 15.6 GB read-read file: 0.29 s of copies at 55 GB/s, against 1.3 s of preads into pinned slabs, the fallback).
+// `defer_to`: the context that unmaps the file later; null = the mapping stays until the process ends (upload helper).
+struct PieceSink {           // where the 1 GiB pieces of an upload go (default: consecutive places of one buffer)
+    char *base = nullptr;
+    uint64_t n_slots = 0;                               // 0: piece k at base + k GiB; else at slot k % n_slots of a window
+    std::function<bool(uint64_t)> before;               // slot of piece k may be written? (waits; false = give up)
+    std::function<bool(uint64_t)> arrived;              // piece k is on the device
+    char *at(uint64_t k, uint64_t piece) const { return base + (n_slots ? k % n_slots : k) * piece; }
+};
+
+static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStream_t s, const char *path, tlm_ctx *defer_to) {
     bool uploaded = false;
-    if (rc == TLM_OK && bytes && !getenv("TLM_UPLOAD_SLABS")) {
-        // Straight out of the page cache: the file is mapped, and piece by piece (1 GiB) the pages are faulted in by all
-        // cores, pinned (hipHostRegister) and handed to ONE DMA each; the faults of piece k+1 run while piece k crosses
-        // PCIe.  No staging copy on the host at all (measured on the 15.6 GB read-read file: 0.29 s of copies at 55 GB/s,
-        // against 1.3 s of preads into pinned slabs, the fallback below).
+    {
         const auto tr = std::chrono::steady_clock::now();
         char *m = (char *) ::mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
         if (m != (char *) MAP_FAILED) {
@@ -469,18 +469,32 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             auto t0f = std::chrono::steady_clock::now();
             fault_in(0);
             t_fault += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0f).count();
+            uint64_t told = 0;                      // pieces [0, told) have been reported as arrived
+            auto report = [&](uint64_t upto, bool wait) {       // pieces < upto whose copies are complete
+                while (ok && told < upto && done[told]) {
+                    if (wait) { if (hipEventSynchronize(done[told]) != hipSuccess) ok = false; }
+                    else if (hipEventQuery(done[told]) != hipSuccess) { (void) hipGetLastError(); break; }
+                    if (ok && sink.arrived && !sink.arrived(told)) ok = false;
+                    told++;
+                }
+            };
             for (uint64_t k = 0; ok && k < n_pieces; k++) {
                 const uint64_t b0 = k * PIECE, len = std::min(bytes, b0 + PIECE) - b0;
                 if (k + 1 < n_pieces) ahead = std::thread([&, k] { fault_in(k + 1); });
                 const auto t0r = std::chrono::steady_clock::now();
                 ok = hipHostRegister(m + b0, len, hipHostRegisterDefault) == hipSuccess;
                 t_reg += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0r).count();
+                if (ok && sink.n_slots && k >= sink.n_slots) {          // the slot's previous piece must have been taken over
+                    report(k - sink.n_slots + 1, true);
+                    if (ok && sink.before && !sink.before(k)) ok = false;
+                }
                 if (ok) {
                     registered = k + 1;
-                    ok = hipMemcpyAsync(p->text[f] + b0, m + b0, len, hipMemcpyHostToDevice, s) == hipSuccess
+                    ok = hipMemcpyAsync(sink.at(k, PIECE), m + b0, len, hipMemcpyHostToDevice, s) == hipSuccess
                          && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess
                          && hipEventRecord(done[k], s) == hipSuccess;
                 }
+                report(k, false);
                 if (ahead.joinable()) {
                     const auto t0w = std::chrono::steady_clock::now();
                     ahead.join();
@@ -490,6 +504,7 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             if (!ok) (void) hipGetLastError();
             const auto t0c = std::chrono::steady_clock::now();
             (void) hipStreamSynchronize(s);
+            report(n_pieces, true);
             const double t_copy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
             for (hipEvent_t e : done)
                 if (e) (void) hipEventDestroy(e);
@@ -497,7 +512,7 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             // of the process meanwhile: deferred to the context, which does it when the device has just been given a long
             // kernel (the walks), or when it goes
             for (uint64_t k = 0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);   // (instant while the device idles)
-            tlm_ctx_defer(p->ctx, [m, bytes] {
+            if (defer_to) tlm_ctx_defer(defer_to, [m, bytes] {
                 const auto t1 = std::chrono::steady_clock::now();
                 // 0.55 s for the 3.8 M page-table entries of a 15.6 GB file, one core, whatever the thread count.  Two
                 // things were tried against it (gpurun_out/r02_child): dropping the entries 64 MB at a time
@@ -519,6 +534,29 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
                         workers, t_fault, t_reg, t_copy,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr).count());
         }
+    }
+    return uploaded;
+}
+
+extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint64_t *n_records, int *clean) {
+    TLM_CHECK(p && path && n_records && clean, TLM_EINVAL, "tlm_paf_add_file: null argument");
+    TLM_CHECK(!p->finished && p->n_files < MAX_FILES, TLM_EINVAL, "tlm_paf_add_file: at most %d files, before tlm_paf_finish", MAX_FILES);
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const int fd = ::open(path, O_RDONLY);
+    TLM_CHECK(fd >= 0, TLM_EINVAL, "Cannot open file: %s", path);
+    struct stat st;
+    ::fstat(fd, &st);
+    const uint64_t bytes = (uint64_t) st.st_size;
+    TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_add_file: file too large");
+    const int f = p->n_files;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = tlm_pool_alloc((void **) &p->text[f], bytes + 64, s);
+    bool uploaded = false;
+    if (rc == TLM_OK && bytes && !getenv("TLM_UPLOAD_SLABS")) {
+        PieceSink sink;
+        sink.base = p->text[f];
+        uploaded = upload_mapped(fd, bytes, sink, s, path, p->ctx);
     }
     if (rc == TLM_OK && bytes && !uploaded) {
         // pinned slabs filled by parallel preads (the page cache copies at memory speed), H2D copies behind them:
@@ -599,6 +637,104 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
     rc = tokenise_on_device(p, f, n_records, clean);
     if (rc != TLM_OK || !*clean) p->n_files = f;        // nothing was appended (the buffers go with the handle)
     return rc;
+}
+
+// ---- the text of a file brought to the device by ANOTHER process (an upload helper): the file's mapping, its
+// registration with the device and the taking down of both then belong to that process -- unmapping 15.6 GB costs 0.55 s
+// of one core under the address-space lock and, in the process that does it, disturbs the device queues.
+// The two processes share a small WINDOW of device memory (TLM_UPLOAD_SLOTS slots of 1 GiB, exported once through HIP IPC:
+// exporting the 61 GB text buffer of the chr1-shaped input itself took seconds): the helper DMAs piece k of the file
+// into slot k mod slots and says so, this process copies the slot to its place in the text buffer (device to device) and
+// gives the slot back.
+extern "C" int tlm_upload_window_create(tlm_ctx *ctx, uint8_t *handle_out, uint64_t *bytes_out) {
+    TLM_CHECK(ctx && handle_out && bytes_out, TLM_EINVAL, "tlm_upload_window_create: null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) <= TLM_IPC_HANDLE_BYTES, "TLM_IPC_HANDLE_BYTES too small");
+    TLM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->upload_window) TLM_HIP(hipMalloc(&ctx->upload_window, (size_t) TLM_UPLOAD_SLOTS << 30));     // (its own driver allocation)
+    hipIpcMemHandle_t h;
+    TLM_HIP(hipIpcGetMemHandle(&h, ctx->upload_window));
+    std::memset(handle_out, 0, TLM_IPC_HANDLE_BYTES);
+    std::memcpy(handle_out, &h, sizeof(h));
+    *bytes_out = (uint64_t) TLM_UPLOAD_SLOTS << 30;
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_text_begin(tlm_paf *p, uint64_t bytes) {
+    TLM_CHECK(p, TLM_EINVAL, "tlm_paf_text_begin: null argument");
+    TLM_CHECK(!p->finished && p->n_files < MAX_FILES && !p->pending, TLM_EINVAL, "tlm_paf_text_begin: no room for a file");
+    TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_text_begin: text too large");
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    if (int rc = tlm_pool_alloc((void **) &p->pending, bytes + 64, p->ctx->stream)) return rc;
+    p->pending_bytes = bytes;
+    return TLM_OK;
+}
+
+extern "C" int tlm_paf_text_piece(tlm_paf *p, uint64_t piece) {
+    TLM_CHECK(p && p->pending, TLM_EINVAL, "tlm_paf_text_piece: no text was begun");
+    const uint64_t b0 = piece << 30;
+    TLM_CHECK(p->ctx->upload_window, TLM_EINVAL, "tlm_paf_text_piece: tlm_upload_window_create has not been called");
+    TLM_CHECK(b0 < p->pending_bytes, TLM_EINVAL, "tlm_paf_text_piece: piece %llu lies beyond the text", (unsigned long long) piece);
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const uint64_t len = std::min<uint64_t>(p->pending_bytes, b0 + (1ull << 30)) - b0;
+    TLM_HIP(hipMemcpyAsync(p->pending + b0, (char *) p->ctx->upload_window + ((piece % TLM_UPLOAD_SLOTS) << 30), len,
+                           hipMemcpyDeviceToDevice, s));
+    TLM_HIP(hipStreamSynchronize(s));           // the slot may be written again
+    return TLM_OK;
+}
+
+extern "C" void tlm_paf_text_abort(tlm_paf *p) {
+    if (!p || !p->pending) return;
+    tlm_pool_free(p->pending);
+    p->pending = nullptr;
+}
+
+extern "C" int tlm_paf_text_commit(tlm_paf *p, int anchors, uint64_t *n_records, int *clean) {
+    TLM_CHECK(p && n_records && clean && p->pending, TLM_EINVAL, "tlm_paf_text_commit: no text was begun");
+    TLM_HIP(hipSetDevice(p->ctx->device));
+    const int f = p->n_files;
+    p->text[f] = p->pending;
+    p->pending = nullptr;
+    p->bytes[f] = p->pending_bytes;
+    p->anchors[f] = anchors;
+    p->n_files = f + 1;
+    const int rc = tokenise_on_device(p, f, n_records, clean);
+    if (rc != TLM_OK || !*clean) p->n_files = f;
+    return rc;
+}
+
+// the helper's side: the window of the other process, and a file through it
+extern "C" int tlm_upload_window_open(tlm_ctx *ctx, const uint8_t *handle) {
+    TLM_CHECK(ctx && handle, TLM_EINVAL, "tlm_upload_window_open: null argument");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    TLM_HIP(hipIpcOpenMemHandle(&ctx->peer_window, h, hipIpcMemLazyEnablePeerAccess));
+    return TLM_OK;
+}
+
+extern "C" int tlm_upload_file_window(tlm_ctx *ctx, const char *path, uint64_t bytes, tlm_upload_piece_fn arrived,
+                                      tlm_upload_piece_fn slot_free, void *user) {
+    TLM_CHECK(ctx && path && arrived && slot_free, TLM_EINVAL, "tlm_upload_file_window: null argument");
+    TLM_CHECK(ctx->peer_window, TLM_EINVAL, "tlm_upload_file_window: tlm_upload_window_open has not been called");
+    TLM_HIP(hipSetDevice(ctx->device));
+    const int fd = ::open(path, O_RDONLY);
+    struct stat st;
+    bool ok = fd >= 0 && ::fstat(fd, &st) == 0 && (uint64_t) st.st_size == bytes;
+    if (ok && bytes) {
+        PieceSink sink;
+        sink.base = (char *) ctx->peer_window;
+        sink.n_slots = TLM_UPLOAD_SLOTS;
+        sink.before = [&](uint64_t k) { return slot_free(k, user) == 0; };
+        sink.arrived = [&](uint64_t k) { return arrived(k, user) == 0; };
+        ok = upload_mapped(fd, bytes, sink, ctx->stream, path, nullptr);
+    }
+    if (fd >= 0) ::close(fd);
+    if (!ok) {
+        tlm_set_error("tlm_upload_file_window: reading or uploading %s failed", path);
+        return TLM_EHIP;
+    }
+    return TLM_OK;
 }
 
 extern "C" int tlm_paf_add_text(tlm_paf *p, const char *text_host, uint64_t bytes, int anchors, uint64_t *n_records, int *clean) {

@@ -43,6 +43,8 @@ struct tlm_ctx {
     std::vector<hipEvent_t> phase_ev;   // graph-build phase marks, created on first use
     void *comm = nullptr;          // ncclComm_t (exchange.hip); rank / world of the one-process-per-GPU job
     int rank = 0, world = 1;
+    void *upload_window = nullptr; // device memory shared with an upload helper process (tlm_upload_window_create)
+    void *peer_window = nullptr;   // ... and, in the helper, the other process's window (tlm_upload_window_open)
     // host-side tidying that may wait (unpinning and unmapping 15 GB of uploaded text takes 0.65 s and blocks every
     // allocation of the process meanwhile): started when the device has just been given a long kernel, or at the latest
     // when the context goes

@@ -17,6 +17,8 @@
 #include <iostream>
 #include <string>
 
+#include <unistd.h>
+
 #include "telomeri_host.hpp"
 #include "../../include/telomeri_hip.h"
 
@@ -57,6 +59,7 @@ static void stamp(const char *what) {       // TLM_HOST_TIMING: where the wall-c
 }
 
 int main(int argc, char **argv) {
+    if (argc == 2 && std::strcmp(argv[1], "--upload-helper") == 0) return OverlapGraph::upload_helper_main();
     stamp("main entered");
     struct AtExit { ~AtExit() { stamp("main left"); } } at_exit;
     OverlapGraph graph;
@@ -124,6 +127,9 @@ int main(int argc, char **argv) {
         t0 = t1;
         return s;
     };
+    // the overlap text is brought to the device by a helper process (its mappings are its own to take down); started
+    // before this process has touched the device
+    if (!materialise && dump.empty()) OverlapGraph::start_upload_helper("/proc/self/exe");
     stamp("loading starts");
     std::cout << "\nLoading overlaps..." << std::endl;
     double parse_ms = 0, build_ms = 0, dl_ms = 0;
@@ -138,6 +144,13 @@ int main(int argc, char **argv) {
         if (!graph.load(pos[k], k == 1)) return 1;
         parse_ms += graph.last_parse_ms();
     }
+    // The reads and contigs are not needed before the Scaffolder runs: the helper process scans them while the device
+    // walks (Main.cpp:357-360 loads them after the consensus; same tables, and a file that cannot be read ends the run at
+    // the same place with the same message).  In-process this cannot be had for free: a thread that maps and scans
+    // 10 GB here while the walks are launched delays them by 0.3-0.6 s.
+    int fasta_requested = 0;
+    if (!no_scaffold && !std::getenv("TLM_NO_FASTA_AHEAD"))
+        for (int k = 2; k < 4 && OverlapGraph::request_fasta_index(pos[k]); k++) fasta_requested++;
     if (!graph.end_loads()) return 1;
     build_ms = graph.last_build_ms();
     dl_ms = graph.last_download_ms();
@@ -145,16 +158,26 @@ int main(int argc, char **argv) {
               << "), device graph build " << build_ms << " ms, download+materialise " << dl_ms << " ms" << std::endl;
     std::cout << "Done (" << lap() << "s)" << std::endl << graph.stats() << std::endl;
 
-    // The reads and contigs are not needed before the Scaffolder runs, and the host has nothing to do while the device
-    // walks: the FASTA files are mapped and indexed on a second thread from here on (Main.cpp:357-360 loads them after
-    // the consensus; same tables, same messages on failure, the exit code at the same place).
     static const Path no_path;
     std::unique_ptr<Scaffolder> fasta;
-    std::thread fasta_thread;
+    std::thread fasta_thread;           // takes the helper's answers in while the device walks (a million names to look up by)
     bool fasta_ok = false;
-    if (!no_scaffold && !std::getenv("TLM_NO_FASTA_AHEAD")) {
+    if (fasta_requested == 2) {
         fasta.reset(new Scaffolder(no_path));
-        fasta_thread = std::thread([&] { fasta_ok = fasta->load(pos[2]) && fasta->load(pos[3]); });
+        fasta_thread = std::thread([&] {
+            fasta_ok = true;
+            for (int k = 2; k < 4 && fasta_ok; k++) {       // in the order of the requests; what the helper could not do is done here
+                const std::string idx = OverlapGraph::collect_fasta_index();
+                const bool got = !idx.empty() && fasta->load_index(idx.c_str(), pos[k]);
+                if (!idx.empty()) ::unlink(idx.c_str());
+                fasta_ok = got || fasta->load(pos[k]);
+            }
+        });
+    } else {
+        for (; fasta_requested > 0; fasta_requested--) {        // (half an answer is no answer: the files are loaded here)
+            const std::string idx = OverlapGraph::collect_fasta_index();
+            if (!idx.empty()) ::unlink(idx.c_str());
+        }
     }
     struct Join {
         std::thread &t;
@@ -211,6 +234,9 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // the helper is let go only now: a process that leaves gives its share of the device back, and the driver interrupts
+    // every running kernel for that (the Monte-Carlo launch took 835 ms instead of 740 ms beside a leaving helper)
+    OverlapGraph::stop_upload_helper();
     stamp("builders done");
     pm.gather();                    // multi-GPU jobs: the one exchange (nothing happens in a one-process job)
     // Every rank now knows every path (summaries; node lists come from their owners on demand, collectively): all ranks

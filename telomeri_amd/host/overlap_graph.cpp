@@ -4,7 +4,11 @@
 // the file, tokenising with operator>> semantics, and giving names ids.  Filtering, scoring, node
 // numbering and adjacency construction run on the GPU (tlm_graph_build_host); the result is downloaded
 // into the public nodes_ / edges_ so that every consumer of the reference's data members keeps working.
+#include <spawn.h>
+#include <signal.h>
 #include "telomeri_host.hpp"
+
+extern char **environ;
 
 #include <algorithm>
 #include <atomic>
@@ -87,11 +91,200 @@ static int env_int(const char *a, const char *b, int dflt) {
     return v ? std::atoi(v) : dflt;
 }
 
+int OverlapGraph::device_ordinal() {
+    const int world = env_int("TLM_WORLD", "WORLD_SIZE", 1), rank = env_int("TLM_RANK", "RANK", 0);
+    return env_int("TLM_DEVICE", "LOCAL_RANK", world > 1 ? rank : 0);
+}
+
+// ---- the upload helper (a second process; see start_upload_helper in the header) --------------------------------
+// Protocol (lines): "G" -> the helper creates its context and says "READY".  "W <ipc handle, hex>" -> "OK": the window of device
+// memory both use.  "U <bytes> <path>" -> "P <k>" for every 1 GiB piece that has arrived in its slot, answered with "A" once
+// the piece has been copied to its place when the slot will be needed again, then "OK".  "F <path>" -> "OK <index file>
+// <ms>": a sequence file scanned (answers collected later).  "ERR <message>" to anything that failed.
+namespace {
+struct UploadHelper {
+    pid_t pid = -1;
+    FILE *to = nullptr, *from = nullptr;
+    bool ready = false;
+    int pending_replies = 0;            // FASTA index requests whose answers have not been collected
+    bool window = false;                // the helper has opened this process's upload window
+} g_helper;
+
+bool helper_wait_ready();
+
+// the window of device memory the two processes share: created here, opened by the helper (once)
+bool helper_window() {
+    if (g_helper.window) return true;
+    uint8_t handle[TLM_IPC_HANDLE_BYTES];
+    uint64_t bytes = 0;
+    if (tlm_upload_window_create(OverlapGraph::context(), handle, &bytes) != TLM_OK) return false;
+    std::string req = "W ";
+    char b[3];
+    for (int i = 0; i < TLM_IPC_HANDLE_BYTES; i++) { std::snprintf(b, sizeof(b), "%02x", handle[i]); req += b; }
+    req += "\n";
+    char reply[512] = "";
+    if (std::fputs(req.c_str(), g_helper.to) < 0 || std::fflush(g_helper.to) != 0 || !std::fgets(reply, sizeof(reply), g_helper.from)
+        || std::strncmp(reply, "OK", 2) != 0) {
+        OverlapGraph::stop_upload_helper();
+        return false;
+    }
+    g_helper.window = true;
+    return true;
+}
+
+bool helper_wait_ready() {
+    if (g_helper.pid < 0) return false;
+    if (g_helper.ready) return true;
+    // "G": the helper may create its context now.  Not earlier: while a second process was coming up on the device,
+    // obtaining the 61 GB text buffer of the chr1-shaped input took this process 5.3 s instead of 11 ms.
+    if (std::fputs("G\n", g_helper.to) < 0 || std::fflush(g_helper.to) != 0) {
+        OverlapGraph::stop_upload_helper();
+        return false;
+    }
+    char line[256];
+    if (!std::fgets(line, sizeof(line), g_helper.from) || std::strncmp(line, "READY", 5) != 0) {
+        OverlapGraph::stop_upload_helper();
+        return false;
+    }
+    g_helper.ready = true;
+    return true;
+}
+}   // namespace
+
+void OverlapGraph::start_upload_helper(const char *exe) {
+    if (g_helper.pid >= 0 || std::getenv("TLM_NO_UPLOAD_HELPER")) return;
+    int down[2], up[2];
+    if (::pipe(down) != 0) return;
+    if (::pipe(up) != 0) { ::close(down[0]); ::close(down[1]); return; }
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, down[0], 0);
+    posix_spawn_file_actions_adddup2(&fa, up[1], 1);
+    // (not this process's stderr: whoever waits for the end of our output would wait for the helper's exit as well)
+    posix_spawn_file_actions_addopen(&fa, 2, "/dev/null", O_WRONLY, 0);
+    posix_spawn_file_actions_addclose(&fa, down[1]);
+    posix_spawn_file_actions_addclose(&fa, up[0]);
+    const std::string dev = std::to_string(device_ordinal());
+    ::setenv("TLM_UPLOAD_DEVICE", dev.c_str(), 1);
+    char arg0[] = "telomeri_hip", arg1[] = "--upload-helper";
+    char *argv[] = {arg0, arg1, nullptr};
+    pid_t pid = -1;
+    const int rc = ::posix_spawn(&pid, exe, &fa, nullptr, argv, environ);
+    posix_spawn_file_actions_destroy(&fa);
+    ::close(down[0]);
+    ::close(up[1]);
+    if (rc != 0) { ::close(down[1]); ::close(up[0]); return; }
+    g_helper.pid = pid;
+    g_helper.to = ::fdopen(down[1], "w");
+    g_helper.from = ::fdopen(up[0], "r");
+    ::signal(SIGPIPE, SIG_IGN);         // a helper that died is a failed upload, not the end of this process
+}
+
+void OverlapGraph::stop_upload_helper() {
+    if (g_helper.pid < 0) return;
+    if (g_helper.to) std::fclose(g_helper.to);          // end of input: the helper leaves (and takes its mappings down) on its own
+    g_helper.to = nullptr;
+    if (g_helper.pending_replies > 0) return;           // answers to queued requests are still to come (collect_fasta_index)
+    if (g_helper.from) std::fclose(g_helper.from);
+    g_helper = UploadHelper();
+}
+
+bool OverlapGraph::request_fasta_index(const char *filename) {
+    if (!helper_wait_ready() || !g_helper.to || std::strchr(filename, '\n')) return false;
+    const std::string req = std::string("F ") + filename + "\n";
+    if (std::fputs(req.c_str(), g_helper.to) < 0 || std::fflush(g_helper.to) != 0) return false;
+    g_helper.pending_replies++;
+    return true;
+}
+
+std::string OverlapGraph::collect_fasta_index() {
+    if (g_helper.pid < 0 || g_helper.pending_replies <= 0 || !g_helper.from) return std::string();
+    char reply[4200] = "";
+    g_helper.pending_replies--;
+    std::string name;
+    if (std::fgets(reply, sizeof(reply), g_helper.from) && std::strncmp(reply, "OK ", 3) == 0) {
+        name = reply + 3;
+        while (!name.empty() && (name.back() == '\n' || name.back() == '\r')) name.pop_back();
+        const size_t tab = name.find('\t');
+        if (tab != std::string::npos) {
+            if (std::getenv("TLM_HOST_TIMING"))
+                std::fprintf(stderr, "[host timing] helper process: sequence file scanned and indexed in %s ms\n", name.c_str() + tab + 1);
+            name.resize(tab);
+        }
+    }
+    if (g_helper.pending_replies == 0 && !g_helper.to) stop_upload_helper();
+    return name;
+}
+
+int OverlapGraph::upload_helper_main() {
+    {   // nothing of the device is touched before the other process says so (see helper_wait_ready)
+        char go[16];
+        if (!std::fgets(go, sizeof(go), stdin) || go[0] != 'G') std::_Exit(0);
+    }
+    tlm_ctx *ctx = nullptr;
+    const char *dev = std::getenv("TLM_UPLOAD_DEVICE");
+    if (tlm_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != TLM_OK) {
+        std::printf("ERR %s\n", tlm_last_error());
+        std::fflush(stdout);
+        return 1;
+    }
+    std::printf("READY\n");
+    std::fflush(stdout);
+    std::string line;
+    for (int c; (c = std::getchar()) != EOF;) {
+        if (c != '\n') { line.push_back((char) c); continue; }
+        unsigned long long bytes = 0;
+        char hex[2 * TLM_IPC_HANDLE_BYTES + 1];
+        int used = 0;
+        if (std::sscanf(line.c_str(), "W %128s", hex) == 1 && std::strlen(hex) == 2 * TLM_IPC_HANDLE_BYTES) {
+            uint8_t handle[TLM_IPC_HANDLE_BYTES];
+            for (int i = 0; i < TLM_IPC_HANDLE_BYTES; i++) {
+                unsigned v = 0;
+                std::sscanf(hex + 2 * i, "%2x", &v);
+                handle[i] = (uint8_t) v;
+            }
+            if (tlm_upload_window_open(ctx, handle) == TLM_OK) std::printf("OK\n");
+            else std::printf("ERR %s\n", tlm_last_error());
+        } else if (std::sscanf(line.c_str(), "U %llu %n", &bytes, &used) == 1 && used > 0) {
+            const char *path = line.c_str() + used;
+            // piece k is in its slot: say so; before a slot is written again: wait for the word that its piece was taken over
+            auto arrived = [](uint64_t k, void *) -> int {
+                std::printf("P %llu\n", (unsigned long long) k);
+                return std::fflush(stdout) == 0 ? 0 : 1;
+            };
+            auto slot_free = [](uint64_t, void *) -> int {
+                char ack[16];
+                return std::fgets(ack, sizeof(ack), stdin) && ack[0] == 'A' ? 0 : 1;
+            };
+            if (tlm_upload_file_window(ctx, path, bytes, arrived, slot_free, nullptr) == TLM_OK) std::printf("OK\n");
+            else std::printf("ERR %s\n", tlm_last_error());
+        } else if (line.size() > 2 && line[0] == 'F' && line[1] == ' ') {
+            // scan a sequence file here (the mapping and its taking down are this process's) and leave the index in a file
+            static const Path no_path;
+            static int serial = 0;
+            Scaffolder sc(no_path);
+            sc.scan_only_ = true;
+            const auto t_scan = std::chrono::steady_clock::now();
+            const char *dir = ::access("/dev/shm", W_OK) == 0 ? "/dev/shm" : "/tmp";
+            const std::string idx = std::string(dir) + "/tlm_index_" + std::to_string((long) ::getpid()) + "_" + std::to_string(serial++);
+            if (sc.load(line.c_str() + 2) && sc.save_index(idx.c_str()))
+                std::printf("OK %s\t%.0f\n", idx.c_str(),
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count());
+            else std::printf("ERR cannot index %s\n", line.c_str() + 2);
+        } else {
+            std::printf("ERR bad request\n");
+        }
+        std::fflush(stdout);
+        line.clear();
+    }
+    std::_Exit(0);      // the mappings and the context go with the process
+}
+
 tlm_ctx *OverlapGraph::context() {
     static tlm_ctx *ctx = nullptr;
     if (ctx) return ctx;
     const int world = env_int("TLM_WORLD", "WORLD_SIZE", 1), rank = env_int("TLM_RANK", "RANK", 0);
-    const int device = env_int("TLM_DEVICE", "LOCAL_RANK", world > 1 ? rank : 0);
+    const int device = device_ordinal();
     if (tlm_ctx_create(device, &ctx) != TLM_OK) die("no usable gfx950 device (there is no CPU fallback)");
     if (world > 1) {
         const char *rv = std::getenv("TLM_RENDEZVOUS");
@@ -478,7 +671,51 @@ bool OverlapGraph::tokenize_on_device(char *filepath, bool anchors, ulong &recor
     if (!paf_ && tlm_paf_create(context(), &paf_) != TLM_OK) die("tlm_paf_create");
     uint64_t n = 0;
     int clean = 0;
-    if (tlm_paf_add_file(paf_, filepath, anchors ? 1 : 0, &n, &clean) != TLM_OK) {
+    bool through_helper = false;
+    struct stat st;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    const auto t_h0 = std::chrono::steady_clock::now();
+    // (the text buffer first: obtaining 61 GB of device memory took 5 s once the window had been exported)
+    bool helper_ok = g_helper.pid >= 0 && ::stat(filepath, &st) == 0 && st.st_size > 0 && !std::strchr(filepath, '\n')
+                     && tlm_paf_text_begin(paf_, (uint64_t) st.st_size) == TLM_OK;
+    const double ms_ready = since(t_h0);
+    const auto t_h1 = std::chrono::steady_clock::now();
+    if (helper_ok && !(helper_wait_ready() && helper_window())) {
+        tlm_paf_text_abort(paf_);
+        helper_ok = false;
+    }
+    if (helper_ok) {
+        if (std::getenv("TLM_HOST_TIMING"))
+            std::fprintf(stderr, "[host timing] upload helper: context + paf handle %.0f ms, text buffer %.0f ms, ready + window %.0f ms\n",
+                         std::chrono::duration<double, std::milli>(t_h0 - t_begin).count(), ms_ready, since(t_h1));
+        const auto t_up = std::chrono::steady_clock::now();
+        const uint64_t bytes = (uint64_t) st.st_size, n_pieces = (bytes + (1ull << 30) - 1) >> 30;
+        const std::string req = "U " + std::to_string(bytes) + " " + filepath + "\n";
+        bool ok = std::fputs(req.c_str(), g_helper.to) >= 0 && std::fflush(g_helper.to) == 0;
+        char reply[512] = "";
+        while (ok) {                        // "P <k>": piece k is in its slot; "OK": the file is through
+            if (!std::fgets(reply, sizeof(reply), g_helper.from)) { ok = false; break; }
+            if (std::strncmp(reply, "OK", 2) == 0) break;
+            unsigned long long k = 0;
+            if (std::sscanf(reply, "P %llu", &k) != 1 || tlm_paf_text_piece(paf_, k) != TLM_OK) { ok = false; break; }
+            if (k + TLM_UPLOAD_SLOTS < n_pieces) ok = std::fputs("A\n", g_helper.to) >= 0 && std::fflush(g_helper.to) == 0;
+        }
+        if (ok) {
+            if (std::getenv("TLM_HOST_TIMING"))
+                std::fprintf(stderr, "[host timing] text upload of %s by the helper process: %.0f ms\n", filepath,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count());
+            const auto t_c = std::chrono::steady_clock::now();
+            if (tlm_paf_text_commit(paf_, anchors ? 1 : 0, &n, &clean) != TLM_OK) clean = 0;
+            if (std::getenv("TLM_HOST_TIMING")) std::fprintf(stderr, "[host timing] upload helper: commit (tokenise) %.0f ms\n", since(t_c));
+            through_helper = true;
+        } else {
+            if (std::getenv("TLM_HOST_TIMING")) std::fprintf(stderr, "[host timing] upload helper failed (%s): uploading in-process\n", reply);
+            tlm_paf_text_abort(paf_);
+            g_helper.pending_replies = 0;
+            stop_upload_helper();
+        }
+    }
+    if (!through_helper && tlm_paf_add_file(paf_, filepath, anchors ? 1 : 0, &n, &clean) != TLM_OK) {
         // (a file that cannot be opened is reported by the host tokeniser with the reference's message)
         clean = 0;
     }

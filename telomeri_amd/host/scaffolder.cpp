@@ -4,9 +4,11 @@
 // reversed at the end, the node-name chain printed on stdout.
 #include <algorithm>
 #include <cctype>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -115,8 +117,74 @@ bool Scaffolder::load(const char *filename) {
     // The mapping goes again, here (telomeri_hip loads on a second thread while the device walks): 2.6 million page-table
     // entries of the 10 GB A. thaliana-shaped reads cost 0.4 s to take down, wherever that happens.  What the scaffold
     // needs of the sequences is read from the descriptor.
-    ::munmap((void *) data, size);
+    if (!scan_only_) ::munmap((void *) data, size);
     files_.push_back(fd);
+    if (scan_only_) return true;
+    for (size_t i = name_base; i < names_.size(); i++) index_.emplace(names_[i], i);     // keeps the first index of a name
+    return true;
+}
+
+// index file: "TLMIDX1\n", u64 names, then per name u32 length + bytes; u64 sequence slots, then per slot u64 offset,
+// u64 length, u8 present
+bool Scaffolder::save_index(const char *index_file) const {
+    FILE *f = std::fopen(index_file, "wb");
+    if (!f) return false;
+    std::fputs("TLMIDX1\n", f);
+    const uint64_t nn = names_.size(), ns = where_.size();
+    std::fwrite(&nn, 8, 1, f);
+    for (const std::string &n : names_) {
+        const uint32_t len = (uint32_t) n.size();
+        std::fwrite(&len, 4, 1, f);
+        std::fwrite(n.data(), 1, len, f);
+    }
+    std::fwrite(&ns, 8, 1, f);
+    for (const View &v : where_) {
+        const uint64_t rec[2] = {(uint64_t) v.off, (uint64_t) v.n};
+        const uint8_t present = v.file >= 0;
+        std::fwrite(rec, 8, 2, f);
+        std::fwrite(&present, 1, 1, f);
+    }
+    return std::fclose(f) == 0;
+}
+
+bool Scaffolder::load_index(const char *index_file, const char *filename) {
+    FILE *f = std::fopen(index_file, "rb");
+    if (!f) return false;
+    char magic[8];
+    uint64_t nn = 0, ns = 0;
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "TLMIDX1\n", 8) == 0 && std::fread(&nn, 8, 1, f) == 1;
+    std::vector<std::string> names;
+    std::vector<View> where;
+    if (ok) names.resize(nn);
+    for (uint64_t i = 0; ok && i < nn; i++) {
+        uint32_t len = 0;
+        ok = std::fread(&len, 4, 1, f) == 1;
+        if (ok) {
+            names[i].resize(len);
+            ok = len == 0 || std::fread(&names[i][0], 1, len, f) == len;
+        }
+    }
+    ok = ok && std::fread(&ns, 8, 1, f) == 1;
+    const int fd = ok ? ::open(filename, O_RDONLY) : -1;
+    ok = ok && (fd >= 0 || ns == 0);
+    const int file = (int) files_.size();
+    if (ok) where.resize(ns);
+    for (uint64_t i = 0; ok && i < ns; i++) {
+        uint64_t rec[2];
+        uint8_t present = 0;
+        ok = std::fread(rec, 8, 2, f) == 2 && std::fread(&present, 1, 1, f) == 1;
+        where[i] = View{present ? file : -1, (size_t) rec[0], (size_t) rec[1]};
+    }
+    std::fclose(f);
+    if (!ok) {
+        if (fd >= 0) ::close(fd);
+        return false;
+    }
+    if (fd >= 0) files_.push_back(fd);
+    const size_t name_base = names_.size();
+    names_.insert(names_.end(), std::make_move_iterator(names.begin()), std::make_move_iterator(names.end()));
+    sequences_.resize(sequences_.size() + where.size());
+    where_.insert(where_.end(), where.begin(), where.end());
     for (size_t i = name_base; i < names_.size(); i++) index_.emplace(names_[i], i);     // keeps the first index of a name
     return true;
 }

@@ -97,6 +97,20 @@ public:
     // --- device side (not in the reference) ---
     tlm_graph *device_graph() const { return dev_; }
     static tlm_ctx *context();          // one context per process, device $TLM_DEVICE (default 0)
+    /** The device the context is (or will be) created on: $TLM_DEVICE / $LOCAL_RANK / the rank of a multi-process job. */
+    static int device_ordinal();
+    /** Starts `exe --upload-helper`: a second process that brings the overlap files' text to the device for this one
+     *  (tokenize_on_device), so that mapping, pinning and -- above all -- unmapping 15 GB of text happen in ITS address
+     *  space.  To be called before this process touches the device.  Without a helper the text is uploaded in-process. */
+    static void start_upload_helper(const char *exe);
+    static void stop_upload_helper();   // no more requests: the helper leaves on its own (after the ones still queued)
+    /** Asks the helper to scan a FASTA / FASTQ file (Scaffolder::load there, save_index to a temporary file); the answer
+     *  -- the index file's name, to be read with Scaffolder::load_index and deleted -- is collected later, in the order
+     *  of the requests.  false / empty name: no helper, or it failed (the caller loads the file itself). */
+    static bool request_fasta_index(const char *filename);
+    static std::string collect_fasta_index();
+    /** The helper's side (main() of `--upload-helper`): serves upload requests on stdin / stdout until end of input. */
+    static int upload_helper_main();
     double last_build_ms() const { return build_ms_; }      // device time of the last graph build
     double last_parse_ms() const { return parse_ms_; }      // host tokenising + interning of the last load
     double last_download_ms() const { return download_ms_; }
@@ -333,6 +347,15 @@ public:
     Scaffolder &operator=(const Scaffolder &) = delete;
     void materialiseAll();
     bool load(const char *filename);                    // Scaffolder.cpp:12-41
+    /** What the load() calls so far have found (names; where every sequence line lies), written to `index_file` -- and
+     *  read back by ANOTHER process's Scaffolder, which then stands as if it had loaded `filename` itself
+     *  (telomeri_hip's helper process scans the 10 GB of reads while the device walks; the scan maps the whole file, and
+     *  taking such a mapping down again costs 0.35 s under a lock the walking process needs). */
+    /** A Scaffolder that only scans for save_index(): load() then neither builds the name lookup nor takes the file's
+     *  mapping down (the helper process ends right after; both cost as much as the scan itself). */
+    bool scan_only_ = false;
+    bool save_index(const char *index_file) const;
+    bool load_index(const char *index_file, const char *filename);
     bool write(const char *filename);                   // Scaffolder.cpp:43-102
     std::string substring(std::string &str, ulong start, ulong end);   // inclusive ends (:114-117)
     std::string &getSequenceFrom(const std::string &name);              // :104-112 (first match)

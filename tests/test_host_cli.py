@@ -3,6 +3,7 @@ PAF text in -> graph + paths out, compared with the UNMODIFIED reference's commi
 everything that does not involve the random stream (graph bits, node names and order, both deterministic
 builders), and with the oracle under per-walk seeding for the Monte-Carlo builders."""
 import os
+import re
 import subprocess
 import tempfile
 
@@ -128,11 +129,12 @@ def test_cli_scaffold_end_to_end(binary, name):
             assert open(out, "rb").read() == open(want, "rb").read()
             pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Consensus length", "Final consensus", "ctg", "read"))]
             assert pick(res.stdout) == pick(exp.stdout)
-            # the same program with its shortcuts off: FASTA files loaded where the reference loads them (not on a second
-            # thread during the walks), destructors instead of _Exit -- same bytes, same report
+            # the same program with its shortcuts off: no helper process (overlap text uploaded and sequence files scanned
+            # by this process, the latter where the reference loads them), destructors instead of _Exit -- same bytes,
+            # same report
             out2 = os.path.join(tmp, "gpu2.fa")
             res2 = subprocess.run([binary] + _flags(meta["args"]) + [rr, cr, reads, contigs, out2], capture_output=True, text=True,
-                                  timeout=300, env=dict(os.environ, TLM_NO_FASTA_AHEAD="1", TLM_CLEAN_EXIT="1"))
+                                  timeout=300, env=dict(os.environ, TLM_NO_FASTA_AHEAD="1", TLM_CLEAN_EXIT="1", TLM_NO_UPLOAD_HELPER="1"))
             assert res2.returncode == 0, res2.stderr
             assert open(out2, "rb").read() == open(want, "rb").read()
             assert pick(res2.stdout) == pick(exp.stdout)
@@ -144,10 +146,10 @@ def test_cli_error_conventions(binary):
     res = subprocess.run([binary, "only", "three", "args"], capture_output=True, text=True)
     assert res.returncode == 1 and "Please provide a path" in res.stderr
     # a sequence file that cannot be opened (Scaffolder.cpp:15-18, Main.cpp:357-360): message and exit code 1, whether the
-    # files are loaded ahead on the second thread or where the reference loads them
+    # files are scanned ahead by the helper process or loaded where the reference loads them
     with tempfile.TemporaryDirectory() as tmp:
         rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
-        for env in ({}, {"TLM_NO_FASTA_AHEAD": "1"}):
+        for env in ({}, {"TLM_NO_FASTA_AHEAD": "1"}, {"TLM_NO_UPLOAD_HELPER": "1"}):
             res = subprocess.run([binary, "--rb-att", "20", rr, cr, "/nonexistent/reads.fa", "/nonexistent/contigs.fa",
                                   os.path.join(tmp, "o.fa")], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
             assert res.returncode == 1, res.stdout[-500:]
@@ -344,17 +346,47 @@ def test_device_tokeniser_long_lines_and_tile_borders():
 
 
 def test_cli_text_upload_through_slabs(binary):
-    """The fallback of the text upload (pread into pinned slabs, for files that cannot be mapped and pinned) feeds the
+    """The forms of the text upload -- by the helper process through the shared window of device memory (the default), by
+    this process out of its own registered mapping, by pread into pinned slabs (files that cannot be mapped) -- feed the
     tokeniser the same bytes."""
     with tempfile.TemporaryDirectory() as tmp:
         rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
         outs = []
-        for env in ({}, {"TLM_UPLOAD_SLABS": "1"}, {"TLM_TIDY": "after"}):
+        for env in ({}, {"TLM_NO_UPLOAD_HELPER": "1"}, {"TLM_NO_UPLOAD_HELPER": "1", "TLM_UPLOAD_SLABS": "1"},
+                    {"TLM_NO_UPLOAD_HELPER": "1", "TLM_TIDY": "after"}):
             res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, cr, "r", "c", "o"], capture_output=True, text=True,
                                  timeout=300, env=dict(os.environ, **env))
             assert res.returncode == 0 and "(device)" in res.stdout, res.stderr
             outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
-        assert outs[0] == outs[1] == outs[2]
+        assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+def test_cli_upload_through_the_window_reuses_its_slots(binary):
+    """A text of four 1 GiB pieces goes through the three slots of the window the program shares with its helper process:
+    piece 3 waits for the word that piece 0 has been copied to its place.  Every line arrives (record count as written)
+    and the run equals the one without a helper."""
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=scratch) as tmp:
+        rr, cr = os.path.join(tmp, "rr.paf"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
+        lines = []
+        for k in range(4096):
+            lines.append("r%d\t9000\t10\t8000\t+\tr%d\t9500\t20\t8100\t7000\t8100\t60\ta\tb\tc\td\n" % (k, k + 1))
+        block = "".join(lines).encode()
+        reps = (3300 << 20) // len(block) + 1
+        with open(rr, "wb") as fh:
+            for _ in range(reps):
+                fh.write(block)
+        assert os.path.getsize(rr) > 3 * (1 << 30)
+        outs = []
+        for env in ({}, {"TLM_NO_UPLOAD_HELPER": "1"}):
+            res = subprocess.run([binary, "--no-scaffold", "--rb-att", "2", rr, cr, "r", "c", "o"], capture_output=True, text=True,
+                                 timeout=900, env=dict(os.environ, TLM_HOST_TIMING="1", **env))
+            assert res.returncode == 0 and "(device)" in res.stdout, res.stderr[-2000:]
+            assert ("by the helper process" in res.stderr) == (not env), res.stderr[-2000:]
+            m = re.search(r"Loaded (\d+)/(\d+) edges from \S*rr\.paf", res.stdout)
+            assert m and int(m.group(2)) == reps * 4096, res.stdout[:2000]
+            outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
+        assert outs[0] == outs[1]
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
