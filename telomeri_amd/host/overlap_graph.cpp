@@ -256,7 +256,8 @@ int OverlapGraph::upload_helper_main() {
                 char ack[16];
                 return std::fgets(ack, sizeof(ack), stdin) && ack[0] == 'A' ? 0 : 1;
             };
-            if (tlm_upload_file_window(ctx, path, bytes, arrived, slot_free, nullptr) == TLM_OK) std::printf("OK\n");
+            if (std::getenv("TLM_HELPER_FAIL")) std::printf("ERR refused (TLM_HELPER_FAIL: tests of the fallback)\n");
+            else if (tlm_upload_file_window(ctx, path, bytes, arrived, slot_free, nullptr) == TLM_OK) std::printf("OK\n");
             else std::printf("ERR %s\n", tlm_last_error());
         } else if (line.size() > 2 && line[0] == 'F' && line[1] == ' ') {
             // scan a sequence file here (the mapping and its taking down are this process's) and leave the index in a file

@@ -353,12 +353,12 @@ def test_cli_text_upload_through_slabs(binary):
         rr, cr = G.gunzip_to(tmp, "tiny_rr.paf.gz"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
         outs = []
         for env in ({}, {"TLM_NO_UPLOAD_HELPER": "1"}, {"TLM_NO_UPLOAD_HELPER": "1", "TLM_UPLOAD_SLABS": "1"},
-                    {"TLM_NO_UPLOAD_HELPER": "1", "TLM_TIDY": "after"}):
+                    {"TLM_NO_UPLOAD_HELPER": "1", "TLM_TIDY": "after"}, {"TLM_HELPER_FAIL": "1"}):       # (a helper that refuses)
             res = subprocess.run([binary, "--no-scaffold", "--rb-att", "20", rr, cr, "r", "c", "o"], capture_output=True, text=True,
                                  timeout=300, env=dict(os.environ, **env))
             assert res.returncode == 0 and "(device)" in res.stdout, res.stderr
             outs.append([ln for ln in res.stdout.splitlines() if ln.startswith(("Loaded", "-", "Found", "Anchor pairs"))])
-        assert outs[0] == outs[1] == outs[2] == outs[3]
+        assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
 
 
 def test_cli_upload_through_the_window_reuses_its_slots(binary):
