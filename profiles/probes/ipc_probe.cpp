@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 -o ipc_probe ipc_probe.cpp (run on the GPU box)
 // profiles/probes/ipc_probe.cpp -- can a second process write into device memory of the first (hipIpc*)?
 //   ipc_probe            parent: allocates, spawns itself as child with the handle, checks what the child wrote
 #include <hip/hip_runtime.h>
