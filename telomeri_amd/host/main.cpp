@@ -19,6 +19,8 @@
 
 #include <unistd.h>
 
+#include <sys/stat.h>
+
 #include "telomeri_host.hpp"
 #include "../../include/telomeri_hip.h"
 
@@ -129,7 +131,14 @@ int main(int argc, char **argv) {
     };
     // the overlap text is brought to the device by a helper process (its mappings are its own to take down); started
     // before this process has touched the device
-    if (!materialise && dump.empty()) OverlapGraph::start_upload_helper("/proc/self/exe");
+    if (!materialise && dump.empty()) {
+        uint64_t text = 0;
+        for (int k = 0; k < 2; k++) {
+            struct stat st;
+            if (::stat(pos[k], &st) == 0) text += (uint64_t) st.st_size;
+        }
+        OverlapGraph::start_upload_helper("/proc/self/exe", text < (24ull << 30));
+    }
     stamp("loading starts");
     std::cout << "\nLoading overlaps..." << std::endl;
     double parse_ms = 0, build_ms = 0, dl_ms = 0;

@@ -108,9 +108,11 @@ struct UploadHelper {
     bool ready = false;
     int pending_replies = 0;            // FASTA index requests whose answers have not been collected
     bool window = false;                // the helper has opened this process's upload window
+    bool told_to_go = false;            // "G" has been sent
 } g_helper;
 
 bool helper_wait_ready();
+bool helper_go();
 
 // the window of device memory the two processes share: created here, opened by the helper (once)
 bool helper_window() {
@@ -132,15 +134,24 @@ bool helper_window() {
     return true;
 }
 
-bool helper_wait_ready() {
+// "G": the helper may create its context now.  For large inputs not before this process has obtained its text buffer:
+// while a second process was coming up on the device, the 61 GB buffer of the chr1-shaped input took 5.3 s to obtain
+// instead of 11 ms (start_upload_helper sends it at once when the overlap files are small: 0.1 s less to wait for).
+bool helper_go() {
     if (g_helper.pid < 0) return false;
-    if (g_helper.ready) return true;
-    // "G": the helper may create its context now.  Not earlier: while a second process was coming up on the device,
-    // obtaining the 61 GB text buffer of the chr1-shaped input took this process 5.3 s instead of 11 ms.
+    if (g_helper.told_to_go) return true;
     if (std::fputs("G\n", g_helper.to) < 0 || std::fflush(g_helper.to) != 0) {
         OverlapGraph::stop_upload_helper();
         return false;
     }
+    g_helper.told_to_go = true;
+    return true;
+}
+
+bool helper_wait_ready() {
+    if (g_helper.pid < 0) return false;
+    if (g_helper.ready) return true;
+    if (!helper_go()) return false;
     char line[256];
     if (!std::fgets(line, sizeof(line), g_helper.from) || std::strncmp(line, "READY", 5) != 0) {
         OverlapGraph::stop_upload_helper();
@@ -151,7 +162,7 @@ bool helper_wait_ready() {
 }
 }   // namespace
 
-void OverlapGraph::start_upload_helper(const char *exe) {
+void OverlapGraph::start_upload_helper(const char *exe, bool context_at_once) {
     if (g_helper.pid >= 0 || std::getenv("TLM_NO_UPLOAD_HELPER")) return;
     int down[2], up[2];
     if (::pipe(down) != 0) return;
@@ -178,6 +189,7 @@ void OverlapGraph::start_upload_helper(const char *exe) {
     g_helper.to = ::fdopen(down[1], "w");
     g_helper.from = ::fdopen(up[0], "r");
     ::signal(SIGPIPE, SIG_IGN);         // a helper that died is a failed upload, not the end of this process
+    if (context_at_once) helper_go();
 }
 
 void OverlapGraph::stop_upload_helper() {

@@ -101,8 +101,9 @@ public:
     static int device_ordinal();
     /** Starts `exe --upload-helper`: a second process that brings the overlap files' text to the device for this one
      *  (tokenize_on_device), so that mapping, pinning and -- above all -- unmapping 15 GB of text happen in ITS address
-     *  space.  To be called before this process touches the device.  Without a helper the text is uploaded in-process. */
-    static void start_upload_helper(const char *exe);
+     *  space.  To be called before this process touches the device.  Without a helper the text is uploaded in-process.
+     *  `context_at_once`: the helper may come up on the device beside this process (small inputs; see helper_go). */
+    static void start_upload_helper(const char *exe, bool context_at_once);
     static void stop_upload_helper();   // no more requests: the helper leaves on its own (after the ones still queued)
     /** Asks the helper to scan a FASTA / FASTQ file (Scaffolder::load there, save_index to a temporary file); the answer
      *  -- the index file's name, to be read with Scaffolder::load_index and deleted -- is collected later, in the order
