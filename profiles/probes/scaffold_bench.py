@@ -153,7 +153,7 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
         m = re.search(r"- total_num: (\d+)", res.stdout)
         if m:
             out["paths"] = int(m.group(1))
-        if res.returncode == 0:
+        if res.returncode == 0 and os.path.exists(fasta):       # (no file with --no-scaffold in extra_args)
             out["scaffold_bytes"] = os.path.getsize(fasta)
             chain = [ln for ln in res.stdout.splitlines() if ln.startswith("ctg") and "-" in ln]
             out["scaffold_nodes"] = chain[-1].count("-") + 1 if chain else 0
