@@ -4,6 +4,7 @@
 // the file, tokenising with operator>> semantics, and giving names ids.  Filtering, scoring, node
 // numbering and adjacency construction run on the GPU (tlm_graph_build_host); the result is downloaded
 // into the public nodes_ / edges_ so that every consumer of the reference's data members keeps working.
+#include <mutex>
 #include <spawn.h>
 #include <signal.h>
 #include "telomeri_host.hpp"
@@ -192,7 +193,10 @@ void OverlapGraph::start_upload_helper(const char *exe, bool context_at_once) {
     if (context_at_once) helper_go();
 }
 
-void OverlapGraph::stop_upload_helper() {
+// (the program's main thread lets the helper go while another thread may be waiting for its last answers)
+static std::mutex g_helper_mu;
+
+static void stop_upload_helper_locked() {
     if (g_helper.pid < 0) return;
     if (g_helper.to) std::fclose(g_helper.to);          // end of input: the helper leaves (and takes its mappings down) on its own
     g_helper.to = nullptr;
@@ -201,8 +205,15 @@ void OverlapGraph::stop_upload_helper() {
     g_helper = UploadHelper();
 }
 
+void OverlapGraph::stop_upload_helper() {
+    std::lock_guard<std::mutex> lk(g_helper_mu);
+    stop_upload_helper_locked();
+}
+
 bool OverlapGraph::request_fasta_index(const char *filename) {
-    if (!helper_wait_ready() || !g_helper.to || std::strchr(filename, '\n')) return false;
+    if (!helper_wait_ready() || std::strchr(filename, '\n')) return false;
+    std::lock_guard<std::mutex> lk(g_helper_mu);
+    if (!g_helper.to) return false;
     const std::string req = std::string("F ") + filename + "\n";
     if (std::fputs(req.c_str(), g_helper.to) < 0 || std::fflush(g_helper.to) != 0) return false;
     g_helper.pending_replies++;
@@ -210,11 +221,18 @@ bool OverlapGraph::request_fasta_index(const char *filename) {
 }
 
 std::string OverlapGraph::collect_fasta_index() {
-    if (g_helper.pid < 0 || g_helper.pending_replies <= 0 || !g_helper.from) return std::string();
+    FILE *from = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_helper_mu);
+        if (g_helper.pid < 0 || g_helper.pending_replies <= 0 || !g_helper.from) return std::string();
+        from = g_helper.from;           // (stays open while an answer is pending)
+    }
     char reply[4200] = "";
+    const bool got = std::fgets(reply, sizeof(reply), from) != nullptr;
+    std::lock_guard<std::mutex> lk(g_helper_mu);
     g_helper.pending_replies--;
     std::string name;
-    if (std::fgets(reply, sizeof(reply), g_helper.from) && std::strncmp(reply, "OK ", 3) == 0) {
+    if (got && std::strncmp(reply, "OK ", 3) == 0) {
         name = reply + 3;
         while (!name.empty() && (name.back() == '\n' || name.back() == '\r')) name.pop_back();
         const size_t tab = name.find('\t');
@@ -224,7 +242,7 @@ std::string OverlapGraph::collect_fasta_index() {
             name.resize(tab);
         }
     }
-    if (g_helper.pending_replies == 0 && !g_helper.to) stop_upload_helper();
+    if (g_helper.pending_replies == 0 && !g_helper.to) stop_upload_helper_locked();
     return name;
 }
 

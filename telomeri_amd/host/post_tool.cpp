@@ -43,8 +43,17 @@ int main(int argc, char **argv) {
     if (!pos.empty() && std::string(pos[0]) == "--list-sequences") {      // Scaffolder::load alone: what it makes of the files
         Path none;
         Scaffolder sc(none);
-        for (size_t i = 1; i < pos.size(); i++)
-            if (!sc.load(pos[i])) return 1;
+        for (size_t i = 1; i < pos.size(); i++) {
+            if (std::getenv("TLM_POST_VIA_INDEX")) {       // scanned by one Scaffolder, read from its index by this one
+                Scaffolder scan(none);
+                scan.scan_only_ = true;
+                const std::string idx = std::string(pos[i]) + ".index";
+                if (!scan.load(pos[i]) || !scan.save_index(idx.c_str()) || !sc.load_index(idx.c_str(), pos[i])) return 1;
+                std::remove(idx.c_str());
+            } else if (!sc.load(pos[i])) {
+                return 1;
+            }
+        }
         sc.materialiseAll();
         std::printf("names %zu sequences %zu\n", sc.names_.size(), sc.sequences_.size());
         for (size_t i = 0; i < sc.names_.size(); i++) {
@@ -124,6 +133,25 @@ int main(int argc, char **argv) {
         }
         std::fclose(out);
         return 0;
+    }
+    if (std::getenv("TLM_POST_VIA_INDEX")) {
+        // the sequence files as telomeri_hip gets them from its helper process: scanned by one Scaffolder, whose index
+        // (Scaffolder::save_index) another one reads (load_index)
+        static const Path no_path;
+        static Scaffolder tables(no_path);
+        auto loaded = [&]() -> Scaffolder * {
+            for (int k = 1; k <= 2; k++) {
+                Scaffolder scan(no_path);
+                scan.scan_only_ = true;
+                const std::string idx = std::string(pos[3]) + ".index" + std::to_string(k);
+                if (!scan.load(pos[k]) || !scan.save_index(idx.c_str())) return nullptr;
+                const bool ok = tables.load_index(idx.c_str(), pos[k]);
+                std::remove(idx.c_str());
+                if (!ok) return nullptr;
+            }
+            return &tables;
+        };
+        return run_post_stages(pm, pba, pos[1], pos[2], pos[3], loaded, false);
     }
     return run_post_stages(pm, pba, pos[1], pos[2], pos[3], nullptr, false);
 }

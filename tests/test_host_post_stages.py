@@ -43,6 +43,13 @@ def test_scaffold_and_groups_against_golden(post, name):
         assert res.returncode == want["exit"], res.stderr
         body = open(out, "rb").read()
         assert len(body) == want["bytes"] and hashlib.md5(body).hexdigest() == want["md5"]
+        # the sequence files as telomeri_hip gets them from its helper process (scanned by one Scaffolder, read from its
+        # index by another): the same scaffold
+        out2 = os.path.join(tmp, "out2.fa")
+        res2 = subprocess.run([post, dump, reads, contigs, out2], capture_output=True, text=True, timeout=120,
+                              env=dict(os.environ, TLM_POST_VIA_INDEX="1"))
+        assert res2.returncode == want["exit"], res2.stderr
+        assert open(out2, "rb").read() == body
         chain = [ln for ln in res.stdout.splitlines() if ln.startswith(("ctg", "read")) and "-" in ln]
         assert hashlib.md5(chain[-1].encode()).hexdigest() == want["chain_md5"]
         got_lines = [ln for ln in res.stdout.splitlines() if ln.startswith(("Consensus length", "Final consensus"))]
@@ -146,8 +153,8 @@ def test_scaffolder_load_roles_by_line_number(post, name, fastq, text):
         with open(big, "w") as fh:
             for i in range(120_000):
                 fh.write(">read%d tail\n%s\n" % (i, "ACGT" * (5 + i % 37)))
-        for paths in ([p], [big, p]):
-            res = subprocess.run([post, "--list-sequences"] + paths, capture_output=True, timeout=120)
+        for paths, env in (([p], {}), ([big, p], {}), ([big, p], {"TLM_POST_VIA_INDEX": "1"})):
+            res = subprocess.run([post, "--list-sequences"] + paths, capture_output=True, timeout=120, env=dict(os.environ, **env))
             assert res.returncode == 0, res.stderr
             res.stdout = res.stdout.decode()            # (no newline translation: a sequence may end in \r)
             names, seqs = [], []
