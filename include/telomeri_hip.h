@@ -135,8 +135,8 @@ typedef struct {
     double driver_alloc_ms;        /* host time spent in those hipMalloc calls */
 } tlm_memory_info;
 int tlm_ctx_memory_info(tlm_ctx *ctx, tlm_memory_info *out);
-/* Give the walk workspaces of the context and the cached blocks of its device back to the driver (graphs and path sets
- * stay; so does a cached block that shares its driver allocation with a block in use).  Waits for the device. */
+/* Give the walk workspaces of the context and every cached block of its device back to the driver (graphs and path
+ * sets stay).  Waits for the device. */
 int tlm_ctx_trim(tlm_ctx *ctx);
 
 /* ---- a2 + a3: filter decision and SI/OS/ES per record -------------------------------------- */

@@ -404,60 +404,10 @@ def test_memory_is_reused_and_trimmed(ctx):
     assert gi.build_alloc_ms == 0.0 and gi.host_syncs <= first.host_syncs
     assert abs(sum(gi.phases().values()) - gi.build_ms) < 0.25 * gi.build_ms + 1.0     # the phases cover the build
     del g
-    before = c2.memory_info().cached_bytes
-    assert before > 0
+    assert c2.memory_info().cached_bytes > 0
     c2.trim()
     m2 = c2.memory_info()
-    # (what stays cached shares its driver allocation with a block that is in use -- here: of other tests' graphs)
-    assert m2.cached_bytes < before and m2.cached_bytes <= (64 << 20)
-
-
-def test_cache_shares_out_large_blocks(ctx):
-    """A request that finds no cached block of its size takes its share of a much larger one instead of going to the
-    driver, the graph built in that share is the right one, and a repeated request sequence still finds its blocks."""
-    def chain(n, deg, seed):
-        rng = np.random.default_rng(seed)
-        row_ptr = (np.arange(n + 1, dtype=np.uint64) * deg)
-        a = n * deg
-        owner = np.repeat(np.arange(n, dtype=np.int64), deg)
-        nbr = ((owner + rng.integers(1, 200, size=a)) % n).astype(np.uint32)
-        z = np.zeros(a, np.uint32)
-        metric = rng.integers(1, 4000, size=a).astype(np.float32)
-        anchors = np.zeros(n, np.uint8)
-        anchors[[5, n // 2]] = 1
-        return row_ptr, nbr, z, z, metric, metric, np.full(n, 1000, np.uint32), anchors
-
-    c2 = capi.Context(0)
-    big = chain(400_000, 64, 1)          # 25.6 M entries: 200 MB per 8-byte-entry array
-    g = c2.graph_from_csr(*big)
-    assert g.info().n_adj == 400_000 * 64
-    del g
-    m0 = c2.memory_info()
-    assert m0.cached_bytes > (600 << 20)
-    small = chain(150_000, 64, 2)        # 9.6 M entries: 77 MB arrays -- nothing of that size is cached
-    g = c2.graph_from_csr(*small)
-    m1 = c2.memory_info()
-    gi = g.info()
-    assert gi.n_adj == 150_000 * 64 and gi.n_anchors == 2
-    h = g.download()
-    np.testing.assert_array_equal(h.nbr & 0x7FFFFFFF, small[1])
-    # the large arrays of the smaller graph came out of the cache (a handful of small buffers may not have): the graph
-    # is 0.5 GB of live memory that the driver was not asked for
-    assert m1.live_bytes - m0.live_bytes > (400 << 20)
-    assert m1.reuses > m0.reuses
-    assert (m1.driver_allocs - m0.driver_allocs) <= 20, (m0.driver_allocs, m1.driver_allocs)       # (buffers below 8 MB)
-    assert m1.live_bytes + m1.cached_bytes < m0.live_bytes + m0.cached_bytes + (64 << 20)
-    ps = g.walk_det(capi.METRIC_ES)
-    assert ps.n_units > 0
-    del ps, g
-    # the same requests again: every block is found again, nothing new from the driver
-    m2 = c2.memory_info()
-    g = c2.graph_from_csr(*small)
-    m3 = c2.memory_info()
-    assert m3.driver_allocs == m2.driver_allocs
-    del g
-    c2.trim()
-    assert c2.memory_info().cached_bytes <= (64 << 20)
+    assert m2.cached_bytes == 0
 
 
 def test_pathset_summary_and_fetch(ctx):
