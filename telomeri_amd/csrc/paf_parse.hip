@@ -91,14 +91,20 @@ struct Dict {
 // The text of the file being parsed, as a workgroup sees it: its tile (+ overhang) staged in LDS by coalesced loads,
 // everything else in HBM.  Per-thread byte-wise reads of lines ~100 bytes apart touch 64 cache lines per wave
 // instruction; out of LDS they are conflict-free.
+// The LDS image is PADDED: 4 bytes after every 128 -- byte o of the tile lies at o + (o / 128) * 4.  Threads own
+// consecutive 128-byte stretches when the line starts are counted, and lines lie ~100 bytes apart when they are parsed:
+// unpadded, the 64 lanes of such a byte read fell into 2 of the 64 banks (stride 32 words); with a stride of 33 words
+// they fall into 64.
+__device__ __forceinline__ uint32_t lds_at(uint32_t o) { return o + ((o >> 7) << 2); }
+
 struct TileText {
-    const char *lds;        // bytes [begin, begin + size) of the text
+    const char *lds;        // bytes [begin, begin + size) of the text (padded image, lds_at)
     const char *global;
     uint64_t begin;
     uint32_t size;
     __device__ __forceinline__ char operator[](uint64_t pos) const {
         const uint64_t d = pos - begin;
-        return d < size ? lds[d] : global[pos];
+        return d < size ? lds[lds_at((uint32_t) d)] : global[pos];
     }
 };
 
@@ -163,7 +169,7 @@ constexpr uint32_t TILE_OVERHANG = 4096;        // bytes after the tile staged w
 __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uint32_t file, uint64_t bytes, uint64_t n_tiles,
                                                                    const uint64_t *__restrict__ tile_base, Dict dict,
                                                                    Columns out, uint32_t *__restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) char s_text[TILE + TILE_OVERHANG];
+    __shared__ __attribute__((aligned(16))) char s_text[TILE + TILE_OVERHANG + (TILE + TILE_OVERHANG) / 128 * 4 + 16];
     __shared__ uint16_t s_start[TILE_MAX_LINES];
     __shared__ uint32_t s_scan[TILE_THREADS];
     const char *text = tx.p[file];
@@ -171,16 +177,29 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
         const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
         // the tile and its overhang into LDS, 16 bytes per lane and load (the buffer is 64 bytes longer than the text)
         const uint32_t staged = (uint32_t) min((uint64_t) (TILE + TILE_OVERHANG), bytes - b);
-        for (uint32_t o = threadIdx.x * 16u; o < staged; o += TILE_THREADS * 16u)
-            *reinterpret_cast<uint4 *>(s_text + o) = *reinterpret_cast<const uint4 *>(text + b + o);
+        for (uint32_t o = threadIdx.x * 16u; o < staged; o += TILE_THREADS * 16u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(text + b + o);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(s_text + lds_at(o));      // (a 16-byte piece never crosses a pad)
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
         const char before = b ? text[b - 1] : '\n';
         __syncthreads();
         const TileText t{s_text, text, b, staged};
         // line starts of the tile, in order: every thread owns 128 consecutive bytes
         constexpr uint32_t PER = TILE / TILE_THREADS;
         const uint32_t m0 = threadIdx.x * PER, m1 = (uint32_t) min((uint64_t) (m0 + PER), e - b);
-        uint32_t n = 0;
-        for (uint32_t o = m0; o < m1; o++) n += (o ? s_text[o - 1] : before) == '\n';
+        // a line starts after every newline (and at the tile's first byte when the byte before the tile is one; a start
+        // at the tile's end belongs to the next tile).  Newlines are looked for a 32-bit word at a time: 0x80 in every
+        // byte of `z` that holds one.
+        auto newlines_of = [&](uint32_t o) {        // of the word at tile offset o (a multiple of 4), bytes inside [0, e - b - 1)
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(s_text + lds_at(o)) ^ 0x0A0A0A0Au;
+            uint32_t z = ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w | 0x7F7F7F7Fu);
+            const uint32_t last = (uint32_t) (e - b) - 1u;      // a newline in the tile's last byte starts nothing here
+            if (o + 4u > last) z &= o >= last ? 0u : (0xFFFFFFFFu >> (8u * (o + 4u - last)));
+            return z;
+        };
+        uint32_t n = threadIdx.x == 0 && before == '\n';
+        for (uint32_t o = m0; o < m1; o += 4) n += __popc(newlines_of(o));
         s_scan[threadIdx.x] = n;
         __syncthreads();
         for (uint32_t d = 1; d < TILE_THREADS; d <<= 1) {
@@ -194,8 +213,9 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
         if (total > TILE_MAX_LINES) {
             if (threadIdx.x == 0) atomicOr(flags, 2u);
         } else {
-            for (uint32_t o = m0; o < m1; o++)
-                if ((o ? s_text[o - 1] : before) == '\n') s_start[at++] = (uint16_t) o;
+            if (threadIdx.x == 0 && before == '\n') s_start[at++] = 0;
+            for (uint32_t o = m0; o < m1; o += 4)
+                for (uint32_t z = newlines_of(o); z; z &= z - 1u) s_start[at++] = (uint16_t) (o + (uint32_t) (__ffs((int) z) >> 3));
         }
         __syncthreads();
         if (total <= TILE_MAX_LINES) {
