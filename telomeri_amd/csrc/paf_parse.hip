@@ -39,7 +39,8 @@ namespace {
 
 constexpr uint32_t TILE = 32u << 10;            // bytes of text per workgroup
 constexpr uint32_t TILE_THREADS = 256;
-constexpr uint32_t TILE_MAX_LINES = 4096;       // more line starts than this in one tile: not a PAF file (blank lines)
+// more line starts than this in one tile: not a PAF file (a line of 16 tokens is 32 bytes at least, a tile holds 1024 of those)
+constexpr uint32_t TILE_MAX_LINES = 1040;
 constexpr int MAX_FILES = 4;
 constexpr unsigned long long EMPTY = ~0ull;
 
@@ -63,16 +64,31 @@ struct Tmp {
 
 __device__ inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
-// ---- pass A: line starts per tile
+// 0x80 in every byte of the result whose byte of `w` is a newline
+__device__ __forceinline__ uint32_t newline_bytes(uint32_t w) {
+    w ^= 0x0A0A0A0Au;
+    return ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w | 0x7F7F7F7Fu);
+}
+
+// ---- pass A: line starts per tile.  A line starts at the text's first byte and after every newline: the tile [b, e) holds
+// (b == 0 or a newline at b - 1) + the newlines of [b, e - 1).  16 bytes per lane and load (the buffer is 64 bytes longer than
+// the text and 16-byte aligned).
 __global__ __launch_bounds__(TILE_THREADS) void count_lines_kernel(const char *__restrict__ text, uint64_t bytes,
                                                                    uint64_t n_tiles, uint32_t *__restrict__ tile_lines) {
     __shared__ uint32_t s_cnt;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
-        const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
-        uint32_t n = 0;
-        for (uint64_t p = b + threadIdx.x; p < e; p += TILE_THREADS) n += p == 0 || text[p - 1] == '\n';
+        const uint64_t b = tile * TILE, last = min(bytes, b + TILE) - 1;
+        uint32_t n = threadIdx.x == 0 && (b == 0 || text[b - 1] == '\n');
+        for (uint64_t p = b + threadIdx.x * 16u; p < last; p += TILE_THREADS * 16u) {
+            if (p + 16 <= last) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(text + p);
+                n += __popc(newline_bytes(v.x)) + __popc(newline_bytes(v.y)) + __popc(newline_bytes(v.z)) + __popc(newline_bytes(v.w));
+            } else {
+                for (uint64_t q = p; q < last; q++) n += text[q] == '\n';
+            }
+        }
         for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d);
         if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, n);
         __syncthreads();
@@ -86,6 +102,8 @@ struct Dict {
     unsigned long long *slot;       // first occurrence of the slot's name, or EMPTY
     uint32_t mask;
     uint32_t *n_names;              // occupied slots; n_names[1] = flags of the parse
+    uint32_t *inserted;             // the occupied slots in the order they were taken, [n_slots / 2] (a table fuller than that
+                                    // is refused): tlm_paf_finish reads these instead of searching the table
 };
 
 // The text of the file being parsed, as a workgroup sees it: its tile (+ overhang) staged in LDS by coalesced loads,
@@ -124,7 +142,8 @@ __device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const Til
         if (cur == EMPTY) {
             cur = atomicCAS(&d.slot[j], EMPTY, mine);
             if (cur == EMPTY) {
-                atomicAdd(d.n_names, 1u);
+                const uint32_t k = atomicAdd(d.n_names, 1u);
+                if (k <= d.mask / 2u) d.inserted[k] = j;
                 return j;
             }
         }
@@ -145,26 +164,71 @@ struct Columns {
     uint8_t *strand;
 };
 
-__device__ inline bool strict_int(const TileText &t, uint64_t s, uint64_t e, int32_t &v) {
-    if (s >= e) return false;
-    bool neg = false;
-    const char c0 = t[s];
-    if (c0 == '+' || c0 == '-') { neg = c0 == '-'; s++; }
-    if (s >= e || e - s > 10) return false;
-    long long acc = 0;
-    for (; s < e; s++) {
-        const char c = t[s];
-        if (c < '0' || c > '9') return false;
-        acc = acc * 10 + (c - '0');
+// One line of PAF text.  The tokens are consumed as they come, every lane of a wavefront at its line's k-th token at the
+// same time (PAF lines have the same number of tokens, so the lanes stay together): the two names are kept as (start,
+// length); every token is accumulated as a decimal integer WHILE its end is looked for -- the strict integer of the host
+// tokeniser: an optional sign, then 1..10 digits and nothing else, inside the int32 range.
+struct Line {
+    uint64_t q_name = 0, t_name = 0;
+    uint32_t q_n = 0, t_n = 0;
+    int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;
+    bool ok = true, minus = false;
+    int nt = 0;
+};
+
+// `rd(p)` = the byte at position p; [p, end) holds no newline; `origin` = file offset of position 0.
+template <class Pos, class Read>
+__device__ __forceinline__ void parse_line(const Read &rd, Pos p, const Pos end, uint64_t origin, Line &L) {
+    auto ws = [](char c) { return c == ' ' || (unsigned char) (c - 9) < 5; };       // (no newline in here)
+    for (;;) {
+        char c = 0;
+        while (p < end && ws(c = rd(p))) p++;
+        if (p >= end) break;
+        const Pos ts = p;
+        bool neg = false, bad = false, more = true;
+        uint32_t nd = 0;
+        unsigned long long acc = 0;
+        if (c == '+' || c == '-') {
+            neg = c == '-';
+            p++;
+            more = p < end && !ws(c = rd(p));
+        }
+        while (more) {
+            const uint32_t d = (uint32_t) (unsigned char) c - (uint32_t) '0';
+            bad |= d > 9u;
+            acc = acc * 10u + d;            // (wraps on a long name: `nd` refuses those as integers)
+            nd++;
+            p++;
+            more = p < end && !ws(c = rd(p));
+        }
+        const uint64_t len = (uint64_t) (p - ts);
+        const long long a = neg ? -(long long) acc : (long long) acc;
+        const bool int_ok = !bad && nd >= 1 && nd <= 10 && a <= 2147483647ll && a >= -2147483648ll;
+        const int32_t v = (int32_t) a;
+        switch (L.nt) {
+            case 0: L.q_name = origin + ts; L.q_n = (uint32_t) min(len, (uint64_t) 0x10000); break;
+            case 1: L.ok = L.ok && int_ok; L.v0 = v; break;
+            case 2: L.ok = L.ok && int_ok; L.v1 = v; break;
+            case 3: L.ok = L.ok && int_ok; L.v2 = v; break;
+            case 4: L.ok = L.ok && len == 1; L.minus = neg; break;
+            case 5: L.t_name = origin + ts; L.t_n = (uint32_t) min(len, (uint64_t) 0x10000); break;
+            case 6: L.ok = L.ok && int_ok; L.v3 = v; break;
+            case 7: L.ok = L.ok && int_ok; L.v4 = v; break;
+            case 8: L.ok = L.ok && int_ok; L.v5 = v; break;
+            case 9: L.ok = L.ok && int_ok; L.v6 = v; break;
+            case 10:                        // alignment block length and mapping quality: must be integers, never used
+            case 11: L.ok = L.ok && int_ok; break;
+            default: break;                 // 12..15: discarded tokens; 16 and beyond: counted, refused by the caller
+        }
+        L.nt++;
     }
-    if (neg) acc = -acc;
-    if (acc > 2147483647ll || acc < -2147483648ll) return false;
-    v = (int32_t) acc;
-    return true;
 }
 
 // flags: 1 = a line is not 16 clean tokens, 2 = too many line starts in a tile, 4 = a name of 65 535 bytes or more
-constexpr uint32_t TILE_OVERHANG = 4096;        // bytes after the tile staged with it: the tile's last line ends in there
+// bytes after the tile staged with it: the tile's last line ends in there (a longer one is parsed out of HBM).  With the
+// line starts and the scan buffer the workgroup stays below 40 KB of LDS: four of them on a CU.
+constexpr uint32_t TILE_OVERHANG = 2048;
+static_assert(TILE_OVERHANG % TILE_THREADS == 0, "the search for the last line's end gives every thread the same share");
 
 __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uint32_t file, uint64_t bytes, uint64_t n_tiles,
                                                                    const uint64_t *__restrict__ tile_base, Dict dict,
@@ -172,6 +236,7 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
     __shared__ __attribute__((aligned(16))) char s_text[TILE + TILE_OVERHANG + (TILE + TILE_OVERHANG) / 128 * 4 + 16];
     __shared__ uint16_t s_start[TILE_MAX_LINES];
     __shared__ uint32_t s_scan[TILE_THREADS];
+    __shared__ uint32_t s_end;          // tile offset of the newline that ends the tile's last line (or ~0: not staged)
     const char *text = tx.p[file];
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
@@ -183,6 +248,7 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
         const char before = b ? text[b - 1] : '\n';
+        if (threadIdx.x == 0) s_end = 0xFFFFFFFFu;
         __syncthreads();
         const TileText t{s_text, text, b, staged};
         // line starts of the tile, in order: every thread owns 128 consecutive bytes
@@ -192,8 +258,7 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
         // at the tile's end belongs to the next tile).  Newlines are looked for a 32-bit word at a time: 0x80 in every
         // byte of `z` that holds one.
         auto newlines_of = [&](uint32_t o) {        // of the word at tile offset o (a multiple of 4), bytes inside [0, e - b - 1)
-            const uint32_t w = *reinterpret_cast<const uint32_t *>(s_text + lds_at(o)) ^ 0x0A0A0A0Au;
-            uint32_t z = ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w | 0x7F7F7F7Fu);
+            uint32_t z = newline_bytes(*reinterpret_cast<const uint32_t *>(s_text + lds_at(o)));
             const uint32_t last = (uint32_t) (e - b) - 1u;      // a newline in the tile's last byte starts nothing here
             if (o + 4u > last) z &= o >= last ? 0u : (0xFFFFFFFFu >> (8u * (o + 4u - last)));
             return z;
@@ -201,6 +266,13 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
         uint32_t n = threadIdx.x == 0 && before == '\n';
         for (uint32_t o = m0; o < m1; o += 4) n += __popc(newlines_of(o));
         s_scan[threadIdx.x] = n;
+        // the tile's last line ends at the first newline at or after the tile's last byte: a few bytes per thread from there
+        constexpr uint32_t SHARE = TILE_OVERHANG / TILE_THREADS;
+        for (uint32_t o = (uint32_t) (e - b) - 1u + threadIdx.x * SHARE, k = 0; k < SHARE && o < staged; k++, o++)
+            if (s_text[lds_at(o)] == '\n') {
+                atomicMin(&s_end, o);
+                break;
+            }
         __syncthreads();
         for (uint32_t d = 1; d < TILE_THREADS; d <<= 1) {
             const uint32_t a = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0u;
@@ -221,38 +293,24 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
         if (total <= TILE_MAX_LINES) {
             for (uint32_t l = threadIdx.x; l < total; l += TILE_THREADS) {
                 const uint64_t r = tile_base[tile] + l;
-                uint64_t p = b + s_start[l];
-                // the tokens are consumed as they come: two names as (start, length), nine integers, the strand
-                uint64_t q_name = 0, t_name = 0;
-                uint32_t q_n = 0, t_n = 0;
-                int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
-                bool ok = true, minus = false;
-                int nt = 0;
-                for (;;) {
-                    char c = 0;
-                    while (p < bytes && (c = t[p]) != '\n' && is_ws(c)) p++;
-                    if (p >= bytes || c == '\n') break;
-                    const uint64_t ts = p;
-                    while (p < bytes && (c = t[p]) != '\n' && !is_ws(c)) p++;
-                    const uint64_t te = p;
-                    switch (nt) {
-                        case 0: q_name = ts; q_n = (uint32_t) min(te - ts, (uint64_t) 0x10000); break;
-                        case 1: ok = ok && strict_int(t, ts, te, v0); break;
-                        case 2: ok = ok && strict_int(t, ts, te, v1); break;
-                        case 3: ok = ok && strict_int(t, ts, te, v2); break;
-                        case 4: ok = ok && te - ts == 1; minus = t[ts] == '-'; break;
-                        case 5: t_name = ts; t_n = (uint32_t) min(te - ts, (uint64_t) 0x10000); break;
-                        case 6: ok = ok && strict_int(t, ts, te, v3); break;
-                        case 7: ok = ok && strict_int(t, ts, te, v4); break;
-                        case 8: ok = ok && strict_int(t, ts, te, v5); break;
-                        case 9: ok = ok && strict_int(t, ts, te, v6); break;
-                        case 10: ok = ok && strict_int(t, ts, te, v7); break;
-                        case 11: ok = ok && strict_int(t, ts, te, v8); break;
-                        default: break;         // 12..15: discarded tokens; 16 and beyond: counted, refused below
-                    }
-                    nt++;
+                const uint32_t start = s_start[l];
+                // the line ends before the next line's start; the tile's last line at the newline found above, or with the text
+                uint32_t end = l + 1 < total ? (uint32_t) s_start[l + 1] - 1u : s_end;
+                if (end == 0xFFFFFFFFu && b + staged == bytes) end = staged;
+                Line L;
+                if (end != 0xFFFFFFFFu) {
+                    parse_line<uint32_t>([&](uint32_t o) { return s_text[lds_at(o)]; }, start, end, b, L);
+                } else {                // (a line that runs past the staged bytes: out of HBM)
+                    uint64_t q = b + start;
+                    while (q < bytes && t[q] != '\n') q++;
+                    parse_line<uint64_t>([&](uint64_t o) { return t[o]; }, b + start, q, 0, L);
                 }
-                (void) v7; (void) v8;           // alignment block length and mapping quality: must be integers, never used
+                const bool ok = L.ok;
+                const int nt = L.nt;
+                const uint64_t q_name = L.q_name, t_name = L.t_name;
+                const uint32_t q_n = L.q_n, t_n = L.t_n;
+                const int32_t v0 = L.v0, v1 = L.v1, v2 = L.v2, v3 = L.v3, v4 = L.v4, v5 = L.v5, v6 = L.v6;
+                const bool minus = L.minus;
                 if (!ok || nt != 16) {
                     atomicOr(flags, 1u);
                     continue;
@@ -274,17 +332,13 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
 }
 
 // ---- finish
-__global__ void collect_slots_kernel(const unsigned long long *__restrict__ slot, uint64_t n_slots,
-                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals,
-                                     uint32_t *__restrict__ counter) {
-    for (uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (uint64_t) gridDim.x * blockDim.x) {
-        const unsigned long long k = slot[s];
-        if (k != EMPTY) {
-            const uint32_t i = atomicAdd(counter, 1u);
-            keys[i] = k;
-            vals[i] = (uint32_t) s;
-        }
-    }
+__global__ void collect_slots_kernel(const unsigned long long *__restrict__ slot, const uint32_t *__restrict__ inserted, uint32_t n,
+                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = inserted[i];
+    keys[i] = slot[j];
+    vals[i] = j;
 }
 
 __global__ void names_kernel(uint32_t n, const unsigned long long *__restrict__ occ, const uint32_t *__restrict__ slot_of,
@@ -333,7 +387,8 @@ struct tlm_paf {
     Columns cols[MAX_FILES] = {};
     unsigned long long *slot = nullptr;
     uint64_t n_slots = 0;
-    uint32_t *n_names_dev = nullptr;     // [0] occupied slots, [1] flags, [2] collect counter
+    uint32_t *n_names_dev = nullptr;     // [0] occupied slots, [1] flags
+    uint32_t *inserted = nullptr;        // Dict::inserted
     bool finished = false;
     uint32_t n_names = 0;
     uint8_t *is_ctg = nullptr;
@@ -363,7 +418,7 @@ extern "C" void tlm_paf_destroy(tlm_paf *p) {
                      p->cols[f].t_start, p->cols[f].t_end, p->cols[f].matches, p->cols[f].strand};
         for (void *b : c) tlm_pool_free(b);
     }
-    tlm_pool_free(p->slot); tlm_pool_free(p->n_names_dev); tlm_pool_free(p->is_ctg); tlm_pool_free(p->name_off);
+    tlm_pool_free(p->slot); tlm_pool_free(p->inserted); tlm_pool_free(p->n_names_dev); tlm_pool_free(p->is_ctg); tlm_pool_free(p->name_off);
     tlm_pool_free(p->blob);
     tlm_pool_free(p->pending);
     delete p;
@@ -411,6 +466,7 @@ static int tokenise_on_device(tlm_paf *p, int f, uint64_t *n_records, int *clean
         while (cap < want) cap <<= 1;
         p->n_slots = cap;
         if (int rc = tlm_pool_alloc((void **) &p->slot, cap * 8, s)) return rc;
+        if (int rc = tlm_pool_alloc((void **) &p->inserted, (cap / 2 + 1) * 4, s)) return rc;
         if (int rc = tlm_pool_alloc((void **) &p->n_names_dev, 16, s)) return rc;
         TLM_HIP(hipMemsetAsync(p->slot, 0xFF, cap * 8, s));
         TLM_HIP(hipMemsetAsync(p->n_names_dev, 0, 16, s));
@@ -422,7 +478,7 @@ static int tokenise_on_device(tlm_paf *p, int f, uint64_t *n_records, int *clean
     if (int rc = tlm_pool_alloc((void **) &c.strand, n ? n : 1, s)) return rc;
     Texts tx;
     for (int k = 0; k < MAX_FILES; k++) tx.p[k] = p->text[k];
-    Dict d{p->slot, (uint32_t) (p->n_slots - 1), p->n_names_dev};
+    Dict d{p->slot, (uint32_t) (p->n_slots - 1), p->n_names_dev, p->inserted};
     TLM_HIP(hipMemsetAsync(p->n_names_dev + 1, 0, 4, s));
     hipLaunchKernelGGL(parse_tiles_kernel, dim3(grid_of(n_tiles, 1)), dim3(TILE_THREADS), 0, s, tx, (uint32_t) f, bytes, n_tiles,
                        (const uint64_t *) tile_base.p, d, c, p->n_names_dev + 1);
@@ -786,6 +842,7 @@ extern "C" int tlm_paf_finish(tlm_paf *p, uint32_t *n_names_out, uint64_t *blob_
         TLM_HIP(hipMemcpyAsync(&n, p->n_names_dev, 4, hipMemcpyDeviceToHost, s));
         TLM_HIP(hipStreamSynchronize(s));
     }
+    TLM_CHECK((uint64_t) n * 2 <= p->n_slots || !p->slot, TLM_EINVAL, "tlm_paf_finish: the dictionary of a refused parse");
     p->n_names = n;
     if (int rc = tlm_pool_alloc((void **) &p->is_ctg, n ? n : 1, s)) return rc;
     if (int rc = tlm_pool_alloc((void **) &p->name_off, ((size_t) n + 1) * 4, s)) return rc;
@@ -798,9 +855,8 @@ extern "C" int tlm_paf_finish(tlm_paf *p, uint32_t *n_names_out, uint64_t *blob_
         if (int rc = tlm_pool_alloc(&vals2.p, (size_t) n * 4, s)) return rc;
         if (int rc = tlm_pool_alloc(&id_of_slot.p, p->n_slots * 4, s)) return rc;
         if (int rc = tlm_pool_alloc(&lens.p, ((size_t) n + 1) * 4, s)) return rc;
-        TLM_HIP(hipMemsetAsync(p->n_names_dev + 2, 0, 4, s));
-        hipLaunchKernelGGL(collect_slots_kernel, dim3(grid_of(p->n_slots)), dim3(256), 0, s, p->slot, p->n_slots,
-                           (unsigned long long *) keys.p, (uint32_t *) vals.p, p->n_names_dev + 2);
+        hipLaunchKernelGGL(collect_slots_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p->slot, (const uint32_t *) p->inserted, n,
+                           (unsigned long long *) keys.p, (uint32_t *) vals.p);
         size_t tb = 0;
         TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *) keys.p, (unsigned long long *) keys2.p,
                                           (uint32_t *) vals.p, (uint32_t *) vals2.p, (size_t) n, 0, 64, s));
@@ -838,7 +894,9 @@ extern "C" int tlm_paf_finish(tlm_paf *p, uint32_t *n_names_out, uint64_t *blob_
         p->text[f] = nullptr;
     }
     tlm_pool_free(p->slot);
+    tlm_pool_free(p->inserted);
     p->slot = nullptr;
+    p->inserted = nullptr;
     p->finished = true;
     p->finish_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *n_names_out = n;
