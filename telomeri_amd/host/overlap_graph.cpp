@@ -15,6 +15,8 @@ extern char **environ;
 #include <atomic>
 #include <cfloat>
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <thread>
 #include <unordered_map>
 #include <fcntl.h>
@@ -775,6 +777,7 @@ bool OverlapGraph::tokenize_on_device(char *filepath, bool anchors, ulong &recor
 }
 
 bool OverlapGraph::load(char *filepath, bool anchors) {
+    ensure_names();
     ulong ctr = 0;
     if (tokenize_on_device(filepath, anchors, ctr)) {
         pending_.emplace_back(filepath, ctr);
@@ -821,6 +824,7 @@ uint64_t OverlapGraph::parse_checksum() const {
             mix(col->data(), col->size() * 4);
         mix(f.strand.data(), f.strand.size());
     }
+    ensure_names();
     for (const std::string &n : names_) mix(n.data(), n.size() + 1);
     return h;
 }
@@ -953,6 +957,16 @@ bool OverlapGraph::tokenize(char *filepath, bool anchors, ulong &ctr) {
     return true;
 }
 
+void OverlapGraph::ensure_names() const {
+    if (!names_pending_) return;
+    names_pending_ = false;
+    const size_t n = name_off_.empty() ? 0 : name_off_.size() - 1;
+    names_.resize(n);
+    for (size_t i = 0; i < n; i++) names_[i].assign(name_blob_.data() + name_off_[i], name_off_[i + 1] - name_off_[i]);
+    name_off_ = {};
+    name_blob_ = {};
+}
+
 bool OverlapGraph::rebuild() {
     tlm_ctx *ctx = context();
     tlm_filter_params dfp;
@@ -964,21 +978,39 @@ bool OverlapGraph::rebuild() {
     if (paf_) {         // the files were tokenised on the device: names from there, the columns never leave it
         uint32_t n_names = 0;
         uint64_t blob_bytes = 0;
+        const auto t_fin = std::chrono::steady_clock::now();
+        auto since = [](std::chrono::steady_clock::time_point t) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        };
         if (tlm_paf_finish(paf_, &n_names, &blob_bytes) != TLM_OK) die("tlm_paf_finish");
+        const double fin_ms = since(t_fin);
+        const auto t_nm = std::chrono::steady_clock::now();
         std::vector<uint32_t> off((size_t) n_names + 1);
         std::vector<char> blob(blob_bytes ? blob_bytes : 1);
         if (tlm_paf_names(paf_, off.data(), blob.data(), nullptr) != TLM_OK) die("tlm_paf_names");
-        names_.resize(n_names);
-        for (uint32_t i = 0; i < n_names; i++) names_[i].assign(blob.data() + off[i], off[i + 1] - off[i]);
+        // names_ itself is not filled here: the nodes below take their names straight from the blob, and the table of
+        // ALL names (a million and more strings, 80 ms of this thread) is only read again by the host tokeniser and the
+        // tests' checksum -- ensure_names() makes it then.  (Made on a second thread beside the walks instead, its
+        // allocations slowed the Monte-Carlo kernel from 785 to 910 ms: every growth of the address space goes through the
+        // driver's notifier; made by all cores here, the process took 90 ms longer to leave.)
+        names_.clear();
+        name_off_ = std::move(off);
+        name_blob_ = std::move(blob);
+        names_pending_ = true;
+        const double names_ms = since(t_nm);
+        const auto t_bg = std::chrono::steady_clock::now();
         if (dev_) { tlm_graph_destroy(dev_); dev_ = nullptr; }
         if (tlm_paf_build_graph(paf_, &dfp, &dev_) != TLM_OK) die("tlm_paf_build_graph");
+        const double bg_ms = since(t_bg);
         double up = 0, pa = 0, fi = 0;
         tlm_paf_timing(paf_, &up, &pa, &fi);
         if (getenv("TLM_HOST_TIMING"))
             std::cerr << "[host timing] device tokeniser: text upload " << up << " ms, tokenise " << pa << " ms, names " << fi
                       << " ms" << std::endl;
+        const auto t_ds = std::chrono::steady_clock::now();
         tlm_paf_destroy(paf_);
         paf_ = nullptr;
+        const double ds_ms = since(t_ds);
         tlm_graph_info gi;
         tlm_graph_get_info(dev_, &gi);
         build_ms_ = gi.build_ms;
@@ -990,19 +1022,31 @@ bool OverlapGraph::rebuild() {
         if (tlm_graph_download(dev_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                node_len.data(), anchor.data(), name_id.data()) != TLM_OK)
             die("tlm_graph_download");
+        const double dl_ms = since(t_dl);
         nodes_.clear();
         nodes_.resize(N);
         edges_.clear();
+        const double rs_ms = since(t_dl) - dl_ms;
+        // (one thread: filled by 8, the table took 40 ms less and the process 0.1 s longer to leave)
         for (size_t i = 0; i < N; i++) {
             Node &n = nodes_[i];
             n.anchor = anchor[i] != 0;
             n.index = (uint) i;
             n.length = node_len[i];
-            n.name = names_[(size_t) name_id[i]];
+            const size_t id = (size_t) name_id[i];
+            n.name.assign(name_blob_.data() + name_off_[id], name_off_[id + 1] - name_off_[id]);
         }
+        if (getenv("TLM_HOST_TIMING"))
+            std::cerr << "[host timing] node table: " << N << " nodes, download " << dl_ms << " ms, resize " << rs_ms << " ms, fill "
+                      << since(t_dl) - dl_ms - rs_ms << " ms" << std::endl;
         download_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dl).count();
+        if (getenv("TLM_HOST_TIMING"))
+            std::cerr << "[host timing] after the text: tlm_paf_finish " << fin_ms << " ms, names to host " << names_ms
+                      << " ms, tlm_paf_build_graph " << bg_ms << " ms (device build " << build_ms_ << "), tlm_paf_destroy " << ds_ms
+                      << " ms, node table " << download_ms_ << " ms" << std::endl;
         return true;
     }
+    ensure_names();
     std::vector<tlm_records> recs(files_.size());
     for (size_t i = 0; i < files_.size(); i++) {
         const File &f = files_[i];

@@ -121,7 +121,7 @@ public:
     /** The host half of load alone (no GPU needed): tokenise `filepath` into the pending columns. */
     bool tokenize(char *filepath, bool anchors, ulong &records);
     uint64_t parse_checksum() const;    // FNV-1a over every tokenised column and the name table (tests)
-    size_t parsed_names() const { return names_.size(); }
+    size_t parsed_names() const { ensure_names(); return names_.size(); }
 
 private:
     // A column of a tokenised file: a vector whose resize does NOT zero-fill (the parser threads write every element;
@@ -166,7 +166,12 @@ private:
         bool anchors = false;
     };
     std::vector<File> files_;
-    std::vector<std::string> names_;    // name table shared by all files (ids in first-seen order)
+    mutable std::vector<std::string> names_;    // name table shared by all files (ids in first-seen order)
+    // after a load of device-tokenised text the table is still the device's blob; ensure_names() turns it into names_
+    mutable std::vector<uint32_t> name_off_;
+    mutable std::vector<char> name_blob_;
+    mutable bool names_pending_ = false;
+    void ensure_names() const;
     struct NameIndex;                   // names_ by name (overlap_graph.cpp)
     NameIndex *index_ = nullptr;
     tlm_graph *dev_ = nullptr;
