@@ -29,6 +29,7 @@
 #include <cstring>
 #include <thread>
 
+#include "cpu_share.h"
 #include "tlm_common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -515,12 +516,7 @@ static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStre
         const auto tr = std::chrono::steady_clock::now();
         char *m = (char *) ::mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
         if (m != (char *) MAP_FAILED) {
-            unsigned workers = std::thread::hardware_concurrency();
-            {
-                cpu_set_t set;
-                if (sched_getaffinity(0, sizeof(set), &set) == 0) workers = std::min<unsigned>(workers ? workers : 1, (unsigned) CPU_COUNT(&set));
-            }
-            workers = std::max(1u, std::min(workers, 32u));
+            const unsigned workers = std::max(1u, std::min(tlm_cpu_share(), 32u));
             constexpr uint64_t PIECE = 1ull << 30;
             const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
             auto fault_in = [&](uint64_t k) {        // touch one byte of every page of piece k, all cores
@@ -640,12 +636,7 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
         constexpr size_t PIECE = 4u << 20;
         constexpr int N_SLABS = 3;
         const size_t SLAB = (size_t) std::min<uint64_t>(256u << 20, std::max<uint64_t>(PIECE, (bytes + 2) / 3));
-        unsigned readers = std::thread::hardware_concurrency();
-        {
-            cpu_set_t set;
-            if (sched_getaffinity(0, sizeof(set), &set) == 0) readers = std::min<unsigned>(readers ? readers : 1, (unsigned) CPU_COUNT(&set));
-        }
-        readers = std::max(1u, std::min(readers, 32u));
+        const unsigned readers = std::max(1u, std::min(tlm_cpu_share(), 32u));
         char *slab[N_SLABS] = {nullptr, nullptr, nullptr};
         hipEvent_t done[N_SLABS] = {nullptr, nullptr, nullptr};
         bool ok = true;

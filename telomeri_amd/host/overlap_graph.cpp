@@ -21,6 +21,7 @@ extern char **environ;
 #include <unordered_map>
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/resource.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -33,6 +34,7 @@ extern char **environ;
 #include <sstream>
 
 #include "../../include/telomeri_hip.h"
+#include "../csrc/cpu_share.h"
 
 namespace {
 
@@ -295,6 +297,8 @@ int OverlapGraph::upload_helper_main() {
             // scan a sequence file here (the mapping and its taking down are this process's) and leave the index in a file
             static const Path no_path;
             static int serial = 0;
+            // (the scan runs beside the other process's load: low priority, and fewer threads than the CPU share -- cpu_share.h)
+            (void) ::setpriority(PRIO_PROCESS, 0, 19);
             Scaffolder sc(no_path);
             sc.scan_only_ = true;
             const auto t_scan = std::chrono::steady_clock::now();
@@ -536,12 +540,7 @@ void parse_range(Chunk &c, const Columns &out) {
     c.records = r;
 }
 
-unsigned host_threads() {
-    unsigned nt = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = std::min<unsigned>(nt ? nt : 1, (unsigned) CPU_COUNT(&set));
-    return std::max(1u, std::min(nt, 64u));
-}
+unsigned host_threads() { return std::max(1u, std::min(tlm_cpu_share(), 64u)); }
 
 }   // namespace
 
@@ -1112,7 +1111,7 @@ bool OverlapGraph::rebuild() {
     nodes_.resize(N);
     std::vector<uint32_t> node_of_name(names_.size(), 0xFFFFFFFFu);
     {
-        unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        unsigned nt = std::max(1u, std::min(32u, tlm_cpu_share()));
         if (N < 4096) nt = 1;
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
@@ -1145,7 +1144,7 @@ bool OverlapGraph::rebuild() {
     edges_.clear();
     edges_.resize(K);
     {
-        unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        unsigned nt = std::max(1u, std::min(32u, tlm_cpu_share()));
         if (K < 65536) nt = 1;
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)

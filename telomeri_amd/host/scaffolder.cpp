@@ -12,6 +12,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include "../csrc/cpu_share.h"
 #include <vector>
 
 #include <fcntl.h>
@@ -69,9 +70,8 @@ bool Scaffolder::load(const char *filename) {
         std::cerr << "Cannot open file: " << filename << std::endl;
         return false;
     }
-    unsigned nt = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = std::min<unsigned>(nt ? nt : 1, (unsigned) CPU_COUNT(&set));
+    // (a scan in the helper process runs beside the other process's load: it leaves a quarter of the CPU share alone)
+    unsigned nt = scan_only_ ? std::max(1u, tlm_cpu_share() * 3 / 4) : tlm_cpu_share();
     nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min(nt, 64u), size / (4u << 20) + 1));
     std::vector<const char *> cut(nt + 1);
     cut[0] = data;
@@ -306,9 +306,7 @@ public:
         for (int c = 0; c < 256; c++) swap[c] = (char) c;
         swap[(unsigned char) 'A'] = 'T'; swap[(unsigned char) 'T'] = 'A';
         swap[(unsigned char) 'G'] = 'C'; swap[(unsigned char) 'C'] = 'G';
-        unsigned nt = std::thread::hardware_concurrency();
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = std::min<unsigned>(nt ? nt : 1, (unsigned) CPU_COUNT(&set));
+        unsigned nt = tlm_cpu_share();
         nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min(nt, 16u), n / 4096 + 1));
         std::vector<char> good(nt, 1);
         auto work = [&](unsigned t) {
