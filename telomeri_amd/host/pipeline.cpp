@@ -2,6 +2,7 @@
 // (src/Main.cpp:254-388): groups, consensus, scaffold path, FASTA.  Shared by telomeri_hip (paths from the GPU) and
 // telomeri_post (paths from a dump file; CPU-only validation of these host stages against the reference).
 #include <chrono>
+#include <cstdlib>
 #include <functional>
 #include <iostream>
 
@@ -22,14 +23,20 @@ int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vect
     };
     std::map<PathManager::AnchorPair, std::vector<PathGroup>> groups_for_anchors;
     std::map<PathManager::AnchorPair, const Path *> consensus_for_anchors;
+    const auto t_c = std::chrono::steady_clock::now();
     const long consensus_num = PathManager::selectConsensus(paths_between_anchors, groups_for_anchors, consensus_for_anchors,
                                                             pm.params_);
+    const double select_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count();
     if (consensus_num == 0) {
         std::cerr << "No consensus found!" << std::endl;                    // Main.cpp:344-347
         return 1;
     }
     std::cout << "Building the scaffold..." << std::endl;
     const Path scaffold = pm.constructConsensusPath(paths_between_anchors, consensus_for_anchors, 10);   // Main.cpp:352
+    if (std::getenv("TLM_HOST_TIMING"))
+        std::cerr << "[host timing] consensus: groups + consensus per anchor pair " << select_ms << " ms, scaffold path "
+                  << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count() - select_ms << " ms"
+                  << std::endl;
     std::cout << "Done (" << lap() << "s)" << std::endl;
     std::cout << "\nLoading files for scaffolding..." << std::endl;
     Scaffolder *ahead = loaded ? loaded() : nullptr;

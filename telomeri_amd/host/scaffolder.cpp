@@ -4,6 +4,7 @@
 // reversed at the end, the node-name chain printed on stdout.
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -344,6 +345,8 @@ Piece cut(const Piece &whole, ulong start, ulong end, bool complement) {
 }   // namespace
 
 bool Scaffolder::write(const char *filename) {
+    const auto t_w = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w).count(); };
     std::ofstream out(filename);
     if (!out) {
         std::cerr << "Cannot write file: " << filename << std::endl;
@@ -364,25 +367,51 @@ bool Scaffolder::write(const char *filename) {
     }
     // The pieces are views: a read contributes a couple of hundred characters of its ten thousand, so the sequences stay
     // where they are (the mapped file, or sequences_[i] once somebody has asked for the string) until the final write.
-    auto view_of = [&](const std::string &name) -> Piece {
-        auto it = index_.find(name);
-        if (it == index_.end() || it->second >= sequences_.size()) {
-            std::cerr << "Scaffolder: no sequence named '" << name << "'" << std::endl;
-            std::exit(1);
-        }
-        const size_t i = it->second;
-        if (where_[i].file >= 0) return Piece{nullptr, files_[(size_t) where_[i].file], where_[i].off, where_[i].n, false};
-        return Piece{sequences_[i].data(), -1, 0, sequences_[i].size(), false};
-    };
+    // The sequences of the nodes that contribute text are looked up by name first, by all cores (455 000 finds in a table
+    // of a million names on the A. thaliana-shaped input: 86 ms of cache misses on one core); a name that is missing is
+    // reported for the first node in path order, as the serial loop did.
+    std::vector<size_t> wanted;                 // node positions whose sequence is cut below
+    wanted.push_back(0);
+    for (size_t k = 1; k < n_edges; k++)
+        if ((ulong) p_.edges_[k]->t_end < (ulong) p_.edges_[k - 1]->q_end) wanted.push_back(k);
+    wanted.push_back(n_nodes - 1);
+    std::vector<Piece> views(wanted.size());
+    {
+        constexpr size_t MISSING = (size_t) -1;
+        unsigned nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min(tlm_cpu_share(), 16u), wanted.size() / 4096 + 1));
+        std::vector<size_t> first_missing(nt, MISSING);
+        auto work = [&](unsigned t) {
+            for (size_t j = wanted.size() * t / nt; j < wanted.size() * (t + 1) / nt; j++) {
+                auto it = index_.find(name_of(wanted[j]));
+                if (it == index_.end() || it->second >= sequences_.size()) {
+                    if (first_missing[t] == MISSING) first_missing[t] = j;
+                    continue;
+                }
+                const size_t i = it->second;
+                views[j] = where_[i].file >= 0 ? Piece{nullptr, files_[(size_t) where_[i].file], where_[i].off, where_[i].n, false}
+                                               : Piece{sequences_[i].data(), -1, 0, sequences_[i].size(), false};
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        for (size_t j : first_missing)
+            if (j != MISSING) {
+                std::cerr << "Scaffolder: no sequence named '" << name_of(wanted[j]) << "'" << std::endl;
+                std::exit(1);
+            }
+    }
+    size_t next_view = 0;
     PieceStack scaffold;
     std::string chain = name_of(0);         // the node-name chain the reference prints piece by piece
-    Piece seq = view_of(name_of(0));
+    Piece seq = views[next_view++];
     scaffold.push(cut(seq, (ulong) p_.edges_[0]->t_end + 1, seq.n, false));
     for (size_t k = 1; k < n_edges; k++) {
         const OverlapGraph::Edge &arriving = *p_.edges_[k - 1], &leaving = *p_.edges_[k];
         const ulong from = leaving.t_end, to = arriving.q_end;
         if (from < to) {
-            seq = view_of(name_of(k));
+            seq = views[next_view++];
             chain += '-';
             chain += name_of(k);
             scaffold.push(cut(seq, from + 1, to, arriving.relative_strand));
@@ -393,12 +422,16 @@ bool Scaffolder::write(const char *filename) {
     chain += '-';
     chain += name_of(n_nodes - 1);
     std::cout << chain << std::endl;
-    seq = view_of(name_of(n_nodes - 1));
+    seq = views[next_view++];
     scaffold.push(cut(seq, 0, p_.edges_[n_edges - 1]->q_end, false));
+    const double pieces_ms = since();
     if (!scaffold.write_newest_first(out)) {
         std::cerr << "Cannot read a sequence file again" << std::endl;
         return false;
     }
     out << std::endl;
+    if (std::getenv("TLM_HOST_TIMING"))
+        std::cerr << "[host timing] scaffold write: " << n_nodes << " nodes looked up and cut in " << pieces_ms
+                  << " ms, text assembled and written in " << since() - pieces_ms << " ms" << std::endl;
     return true;
 }
