@@ -1,5 +1,7 @@
 #!/bin/bash
-# profiles/probes/tok_ablate.sh -- the load phase of the host program on the A. thaliana-shaped text under TLM_TOK_ABLATE values
+# profiles/probes/tok_ablate.sh <values...> -- the load phase of the host program on the A. thaliana-shaped text under TLM_TOK_ABLATE
+# values (1 = no dictionary probes, 2 = no token loops; 0 = timing only).  The switch is NOT in the shipped library: apply
+# profiles/experiments/r02_tokeniser_ablation.patch to csrc/paf_parse.hip and rebuild first.  TOK_TRACE=1 adds a rocprofv3 kernel trace.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_tokabl; mkdir -p $O
 D=$(python3 - <<PY
 import sys, json
