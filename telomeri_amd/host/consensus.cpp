@@ -37,7 +37,14 @@ std::pair<ulong, int> PathWindow::getHighestFrequencyEntry() const {    // first
 // ---- PathGroup (src/PathGroup.cpp) --------------------------------------------------------------------
 PathGroup::PathGroup(std::vector<const Path *>::const_iterator begin, std::vector<const Path *>::const_iterator end)
     : pig_(begin, end), consensus(nullptr), valid_path_number(0) {
-    for (const Path *p : pig_) frqs[(ulong) p->length()] += 1;
+    // (groups come sorted by length: a length is the map's last key or a new last key, no search; any other order
+    // takes the general way to the same map)
+    for (const Path *p : pig_) {
+        const ulong len = (ulong) p->length();
+        if (!frqs.empty() && frqs.rbegin()->first == len) frqs.rbegin()->second += 1;
+        else if (frqs.empty() || frqs.rbegin()->first < len) frqs.emplace_hint(frqs.end(), len, 1);
+        else frqs[len] += 1;
+    }
 }
 
 std::pair<ulong, int> PathGroup::getHighestFrequencyEntry() const {
