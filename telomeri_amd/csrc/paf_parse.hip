@@ -6,11 +6,15 @@
 // the 5.5 GB of columns it produces.  Here the TEXT goes to HBM instead (pinned slabs filled by parallel preads, H2D
 // copies behind them) and is tokenised where the graph build wants its input:
 //   pass A  line starts per 32 KB tile (a line starts at byte 0 and after every '\n')   -> record index of every tile
-//   pass B  one thread per line: 16 tokens, the nine numeric ones as strict [+-]digits inside int range, the strand as
-//           one character; the two names go through a device dictionary (open addressing over the text itself: a slot
-//           holds WHERE a name occurs first, an equal name is recognised by comparing bytes) and come out as slot numbers
-//   finish  occupied slots sorted by first occurrence (file, offset) = first-seen order, the numbering a sequential reader
-//           assigns; slot numbers in the columns become those ids; name bytes gathered into one blob for the host
+//   pass B  the tile (+ overhang) staged in LDS, padded against bank conflicts; one thread per line, its end known from the
+//           next line's start: 16 tokens, every token accumulated as a strict [+-]digits integer inside int range WHILE
+//           its end is looked for (one pass over the bytes; the lanes of a wave stay at the same token), the strand as one
+//           character; the two names go through a device dictionary (open addressing over the text itself: a slot holds
+//           WHERE a name occurs first, an equal name is recognised by comparing bytes) and come out as slot numbers
+//   finish  occupied slots (listed as they were taken) sorted by first occurrence (file, offset) = first-seen order, the
+//           numbering a sequential reader assigns; slot numbers in the columns become those ids; name bytes gathered into
+//           one blob for the host
+// 15.6 GB / 150.8 M lines of the A. thaliana-shaped input: 56 ms (pass A 3 ms, pass B 42 ms), finish 4 ms.
 // Exactly like the host's parallel tokeniser (telomeri_amd/host/overlap_graph.cpp) this is only valid on CLEAN text --
 // every line 16 tokens, plain integers, one-character strand, no blank lines; then line-wise parsing IS the token
 // stream.  Anything else raises `clean = 0` and the caller falls back to the exact operator>> reader on the host.
