@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
 #include <thread>
 
 inline unsigned tlm_cpu_share() {
@@ -37,6 +38,14 @@ inline unsigned tlm_cpu_share() {
             }
         }
         if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned) std::max<long long>(1, (quota + period - 1) / period));
+        // one process per GPU: the ranks of a node share all of the above (LOCAL_WORLD_SIZE is set by torch.distributed.run,
+        // TLM_WORLD by the host program's own launcher; both mean ranks of ONE node here)
+        for (const char *var : {"LOCAL_WORLD_SIZE", "TLM_WORLD"})
+            if (const char *v = std::getenv(var)) {
+                const long ranks = std::atol(v);
+                if (ranks > 1) n = std::max(1u, n / (unsigned) ranks);
+                break;
+            }
         return std::max(1u, n);
     }();
     return share;

@@ -35,9 +35,17 @@ def test_cpu_share_follows_affinity_and_quota(tmp_path):
     exe = tmp_path / "share"
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(REPO, "telomeri_amd", "csrc"), str(src), "-o", str(exe),
                     "-pthread"], check=True)
-    got = int(subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout)
+    base_env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "TLM_WORLD")}
+    got = int(subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=base_env).stdout)
     assert got == expected_share()
     assert 1 <= got <= (os.cpu_count() or 1)
+    # the ranks of a node share it
+    if got >= 2:
+        env = dict(os.environ, LOCAL_WORLD_SIZE="2")
+        assert int(subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env).stdout) == got // 2
+        env = dict(os.environ, TLM_WORLD=str(4 * got))
+        env.pop("LOCAL_WORLD_SIZE", None)
+        assert int(subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env).stdout) == 1
     # a narrower affinity mask narrows the answer
     one = sorted(os.sched_getaffinity(0))[:1]
     got1 = int(subprocess.run(["taskset", "-c", str(one[0]), str(exe)], check=True, capture_output=True, text=True).stdout)
