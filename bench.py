@@ -31,6 +31,50 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n: int) -> int:
+    """`bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): this process becomes the launcher.  It never
+    touches a GPU (nothing that initialises HIP has been imported yet): it starts N fresh children of this same command, one
+    rank per GPU, with the rendezvous variables torch.distributed.run would set, lets rank 0 write the JSON line straight to
+    this process's stdout, ends the others as soon as one of them fails, and returns the first non-zero status."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    try:
+        while live and rc == 0:
+            for r in sorted(live):
+                st = procs[r].poll()
+                if st is None:
+                    continue
+                live.discard(r)
+                if st != 0:
+                    rc = st if st > 0 else 128 - st
+                    log("bench.py: rank %d ended with status %d; ending the other ranks" % (r, st))
+                    break
+            time.sleep(0.05)
+    finally:
+        for r in live:
+            if procs[r].poll() is None:
+                procs[r].send_signal(signal.SIGTERM)
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +98,14 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (reported as cores)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if os.environ.get("TLM_BENCH_LAUNCH_ECHO"):      # launcher test (CPU tier): what a rank was started with, nothing else
+        status = int(os.environ.get("TLM_BENCH_LAUNCH_ECHO_FAIL", "-1")) == int(os.environ.get("RANK", "0"))
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        if os.environ.get("TLM_BENCH_LAUNCH_ECHO_FAIL") and not status:
+            time.sleep(30)      # the launcher must end this rank when the failing one has gone
+        sys.exit(7 if status else 0)
 
     import numpy as np
     import torch
@@ -64,7 +116,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world))
+        log("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -82,7 +134,10 @@ def main() -> None:
     # TLM_EXCHANGE: "lazy" (default: path summaries to every rank, node lists on demand -- what the host stages consume),
     # "full" (every node list to every rank), "torch" (the harness's gather over torch.distributed)
     exchange_mode = os.environ.get("TLM_EXCHANGE", "lazy")
-    use_abi_exchange = world > 1 and args.dist_backend == "nccl" and exchange_mode in ("lazy", "full")
+    # (with TLM_RCCL_LIB -- tests/fake_rccl, several ranks on one GPU -- the library's exchange also runs in a gloo rehearsal)
+    use_abi_exchange = (world > 1 and exchange_mode in ("lazy", "full")
+                        and (args.dist_backend == "nccl" or bool(os.environ.get("TLM_RCCL_LIB"))))
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # where the harness's own small collectives live
     if use_abi_exchange:
         # every rank tries; if ANY of them cannot bring the library's communicator up, all fall back together to the
         # harness's gather over torch.distributed (the line then says so)
@@ -99,7 +154,7 @@ def main() -> None:
                 ok, why = 0, repr(e)
         else:
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             log("rank %d: library communicator unavailable (%s); falling back to torch.distributed for the exchange" % (rank, why))
@@ -209,7 +264,7 @@ def main() -> None:
     sync()
     elapsed = time.time() - t0
     if world > 1:
-        t = torch.tensor([elapsed, float(evals)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, float(evals)], dtype=torch.float64, device=cdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()

@@ -41,7 +41,9 @@ enum {
     TLM_EINVAL = -1,     /* bad argument */
     TLM_EHIP = -2,       /* a HIP runtime call failed (no device, out of memory, launch failure) */
     TLM_ELIMIT = -3,     /* a size limit of the device layout was exceeded */
-    TLM_EINTERNAL = -4
+    TLM_EINTERNAL = -4,
+    TLM_EPEER = -5       /* multi-GPU: ANOTHER rank of the job failed (or the communicator has been given up after a failure
+                            of this rank); every rank of an exchange call fails together instead of waiting for ever */
 };
 
 /* OverlapGraph::LengthCalculationMode (include/OverlapGraph.hpp:56-65), same numbering */
@@ -352,7 +354,14 @@ int tlm_paf_timing(const tlm_paf *p, double *upload_ms, double *parse_ms, double
 #define TLM_UNIQUE_ID_BYTES 128
 #define TLM_EXCHANGE_MAX_BLOCKS 64
 /* Rank 0 makes the id (ncclGetUniqueId); the host hands the 128 bytes to the other ranks (a file, a socket, the
- * launcher); then every rank calls tlm_dist_init with the same bytes.  One communicator per context. */
+ * launcher); then every rank calls tlm_dist_init with the same bytes.  One communicator per context.
+ * The library binds RCCL at run time: librccl.so.1, or the library the environment variable TLM_RCCL_LIB names (tests use
+ * it to put a stand-in underneath that lets several ranks share one GPU, which RCCL refuses: tests/fake_rccl/).
+ * FAILING TOGETHER: the exchange calls below are collectives.  A rank that cannot go on (out of memory, a HIP error)
+ * tells its peers before any data moves -- the ranks swap their status in a 4-byte-per-rank all-gather ahead of every data
+ * collective -- and then ALL ranks return: the failing one its own code, the others TLM_EPEER.  A failure in the middle of
+ * a collective sequence closes the open group, aborts the communicator (ncclCommAbort) and leaves the context out of the
+ * job: its later exchange calls return TLM_EPEER at once; the launcher ends the remaining ranks (run.sh does). */
 int tlm_dist_unique_id(uint8_t id_out[TLM_UNIQUE_ID_BYTES]);
 int tlm_dist_init(tlm_ctx *ctx, int rank, int world, const uint8_t id[TLM_UNIQUE_ID_BYTES]);
 void tlm_dist_finalize(tlm_ctx *ctx);

@@ -61,18 +61,41 @@ then
     exec "$bin" "$@" "$rr_file" "$cr_file" "$reads_file" "$contigs_file" "$out_file"
 fi
 
-# one process per GPU; rank 0 writes the scaffold and its log goes to the terminal
+# one process per GPU; rank 0 writes the scaffold and its log goes to the terminal.  TLM_DEVICES="d0 d1 ..." names the device
+# of every rank (default: rank r on device r).  The ranks meet in collectives: when one of them ends with an error the
+# others are ended too instead of being left waiting for it.
 rendezvous=$(mktemp -u "${TMPDIR:-/tmp}/telomeri_rccl_id.XXXXXX")
-pids=""
+devices=(${TLM_DEVICES:-$(seq 0 $((gpus - 1)))})
+if [ ${#devices[@]} -lt "$gpus" ]
+then
+    echo "TLM_DEVICES names ${#devices[@]} devices for $gpus ranks" >&2
+    exit 1
+fi
+pids=()
 for r in $(seq 1 $((gpus - 1)))
 do
-    TLM_WORLD=$gpus TLM_RANK=$r TLM_DEVICE=$r TLM_RENDEZVOUS=$rendezvous \
+    TLM_WORLD=$gpus TLM_RANK=$r TLM_DEVICE=${devices[$r]} TLM_RENDEZVOUS=$rendezvous \
         "$bin" "$@" "$rr_file" "$cr_file" "$reads_file" "$contigs_file" "$out_file" > "$dir/telomeri_rank$r.log" 2>&1 &
-    pids="$pids $!"
+    pids+=($!)
 done
-TLM_WORLD=$gpus TLM_RANK=0 TLM_DEVICE=0 TLM_RENDEZVOUS=$rendezvous \
-    "$bin" "$@" "$rr_file" "$cr_file" "$reads_file" "$contigs_file" "$out_file"
-rc=$?
-for p in $pids; do wait $p || rc=1; done
-rm -f "$rendezvous"
+TLM_WORLD=$gpus TLM_RANK=0 TLM_DEVICE=${devices[0]} TLM_RENDEZVOUS=$rendezvous \
+    "$bin" "$@" "$rr_file" "$cr_file" "$reads_file" "$contigs_file" "$out_file" &
+pids+=($!)
+rc=0
+left=$gpus
+while [ $left -gt 0 ]
+do
+    wait -n
+    st=$?
+    left=$((left - 1))
+    if [ $st -ne 0 ]
+    then
+        rc=$st
+        echo "run.sh: a rank ended with status $st; ending the other ranks" >&2
+        kill "${pids[@]}" 2> /dev/null
+        break
+    fi
+done
+wait
+rm -f "$rendezvous" "$rendezvous.tmp"
 exit $rc

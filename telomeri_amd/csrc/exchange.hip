@@ -12,7 +12,16 @@
 // On the wire a path node costs 6 bytes (u32 node + u16 edge slot; a slot is a position inside a neighbour list, and
 // only graphs with lists of 65 535 entries or more need 32 bits) instead of the 8 it occupies in HBM.
 // RCCL is loaded on first use (dlopen of librccl.so.1, the copy the process already holds if it has one): the library
-// itself does not depend on it, and single-GPU hosts never load its half gigabyte.
+// itself does not depend on it, and single-GPU hosts never load its half gigabyte.  TLM_RCCL_LIB names another library
+// with the same entry points (tests/fake_rccl: several ranks on ONE GPU, which RCCL refuses).
+//
+// FAILING TOGETHER.  Every exchange call is a sequence of collectives; a rank that leaves it alone leaves its peers
+// waiting in RCCL for ever.  So (i) whatever can fail locally -- allocations, local kernels -- happens in stages whose
+// outcome the ranks SWAP (agree(): a 4-byte-per-rank ncclAllGather through a buffer the context owns since tlm_dist_init)
+// before the next data collective: one failure and everybody returns, the failing rank its own code, the others
+// TLM_EPEER; (ii) the stretches in which peers wait for this rank are bracketed by a Collective guard: any early return
+// inside closes an open group (ncclGroupEnd) and aborts the communicator (ncclCommAbort), after which the context is
+// out of the job (comm_broken) and the launcher ends the other ranks.
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -38,6 +47,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;      // optional
 };
 
 RcclApi *rccl_api() {
@@ -45,7 +55,15 @@ RcclApi *rccl_api() {
     static bool tried = false;
     if (tried) return api.handle ? &api : nullptr;
     tried = true;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);         // the copy already in the process (PyTorch's)
+    void *h = nullptr;
+    if (const char *named = getenv("TLM_RCCL_LIB")) {                 // an explicit choice is never silently replaced
+        h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            tlm_set_error("TLM_RCCL_LIB=%s cannot be loaded: %s", named, dlerror());
+            return nullptr;
+        }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);       // the copy already in the process (PyTorch's)
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) {
@@ -69,9 +87,10 @@ RcclApi *rccl_api() {
     api.GroupEnd = (decltype(api.GroupEnd)) sym("ncclGroupEnd");
     api.Broadcast = (decltype(api.Broadcast)) sym("ncclBroadcast");
     if (!ok) {
-        tlm_set_error("librccl.so.1 lacks an expected symbol");
+        tlm_set_error("the RCCL library lacks an expected symbol");
         return nullptr;
     }
+    api.CommAbort = (decltype(api.CommAbort)) dlsym(h, "ncclCommAbort");
     api.handle = h;
     return &api;
 }
@@ -89,6 +108,79 @@ struct Tmp {
     void *p = nullptr;
     ~Tmp() { tlm_pool_free(p); }
 };
+
+// the communicator is given up: peers that still wait for this rank are ended by the launcher
+void break_comm(tlm_ctx *ctx, RcclApi *api) {
+    if (!ctx->comm) return;
+    if (api && api->CommAbort) (void) api->CommAbort((ncclComm_t) ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_broken = true;
+}
+
+// A stretch of an exchange call in which peers wait for this rank.  Leaving it early (the TLM_HIP / TLM_NCCL macros
+// return) closes an open group and gives the communicator up; done() marks the regular end.
+struct Collective {
+    tlm_ctx *ctx;
+    RcclApi *api;
+    bool group_open = false, finished = false;
+    int group_start() {
+        TLM_NCCL(api, api->GroupStart());
+        group_open = true;
+        return TLM_OK;
+    }
+    int group_end() {
+        group_open = false;
+        TLM_NCCL(api, api->GroupEnd());
+        return TLM_OK;
+    }
+    void done() { finished = true; }
+    ~Collective() {
+        if (finished) return;
+        std::string why = tlm_last_error();         // keep the message of what went wrong, not of the tidying
+        if (group_open) (void) api->GroupEnd();
+        break_comm(ctx, api);
+        tlm_set_error("%s [the communicator has been aborted]", why.c_str());
+    }
+};
+
+// test hook: TLM_EXCHANGE_FAULT="<rank>:<point>" makes that rank behave as if a local step had failed at <point>
+// (prep, alloc, group, fetch); tests/test_exchange_world2.py checks that every rank then fails, none hangs
+bool fault_here(const tlm_ctx *ctx, const char *point) {
+    const char *f = getenv("TLM_EXCHANGE_FAULT");
+    if (!f) return false;
+    char *colon = nullptr;
+    const long r = std::strtol(f, &colon, 10);
+    if (!colon || *colon != ':' || r != ctx->rank || std::strcmp(colon + 1, point) != 0) return false;
+    tlm_set_error("injected failure at '%s' on rank %d (TLM_EXCHANGE_FAULT)", point, ctx->rank);
+    return true;
+}
+
+// Swap the ranks' local status; TLM_OK only if every rank is fine.  With a failure somewhere every rank returns: the
+// failing one(s) their own code, the others TLM_EPEER.  Scratch words [0] = mine, [64 .. 64 + world) = everybody's.
+int agree(tlm_ctx *ctx, RcclApi *api, int local_rc, const char *where) {
+    std::string my_error = local_rc ? tlm_last_error() : "";
+    hipStream_t s = ctx->stream;
+    int32_t *d = (int32_t *) ctx->xchg_scratch;
+    int32_t mine = local_rc, all[TLM_EXCHANGE_MAX_BLOCKS] = {0};
+    {
+        Collective col{ctx, api};
+        TLM_HIP(hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, s));
+        TLM_NCCL(api, api->AllGather(d, d + 64, 1, ncclInt32, (ncclComm_t) ctx->comm, s));
+        TLM_HIP(hipMemcpyAsync(all, d + 64, 4 * (size_t) ctx->world, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        col.done();
+    }
+    if (local_rc) {
+        tlm_set_error("%s", my_error.c_str());
+        return local_rc;
+    }
+    for (int r = 0; r < ctx->world; r++)
+        if (all[r] != 0) {
+            tlm_set_error("rank %d failed in %s (code %d); rank %d leaves the exchange with it", r, where, all[r], ctx->rank);
+            return TLM_EPEER;
+        }
+    return TLM_OK;
+}
 
 // slots -> 16 bits (0xFFFF = the end-of-path sentinel 0xFFFFFFFF); *wide is set if a real slot does not fit
 __global__ void narrow_slots_kernel(uint64_t n, const uint32_t *__restrict__ slots, uint16_t *__restrict__ out,
@@ -184,21 +276,32 @@ extern "C" int tlm_dist_init(tlm_ctx *ctx, int rank, int world, const uint8_t *i
     TLM_HIP(hipSetDevice(ctx->device));
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
+    if (!ctx->xchg_scratch) {
+        if (int rc = tlm_pool_alloc(&ctx->xchg_scratch, TLM_XCHG_SCRATCH_BYTES, ctx->stream)) return rc;
+        TLM_HIP(hipMemsetAsync(ctx->xchg_scratch, 0, TLM_XCHG_SCRATCH_BYTES, ctx->stream));
+        TLM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     ncclComm_t comm = nullptr;
     TLM_NCCL(api, api->CommInitRank(&comm, world, id, rank));
     ctx->comm = comm;
+    ctx->comm_broken = false;
     ctx->rank = rank;
     ctx->world = world;
     return TLM_OK;
 }
 
 extern "C" void tlm_dist_finalize(tlm_ctx *ctx) {
-    if (!ctx || !ctx->comm) return;
-    RcclApi *api = rccl_api();
+    if (!ctx || (!ctx->comm && !ctx->comm_broken)) return;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
-    if (api) (void) api->CommDestroy((ncclComm_t) ctx->comm);
+    if (ctx->comm) {
+        RcclApi *api = rccl_api();
+        if (api) (void) api->CommDestroy((ncclComm_t) ctx->comm);
+    }
+    tlm_pool_free(ctx->xchg_scratch, true);
+    ctx->xchg_scratch = nullptr;
     ctx->comm = nullptr;
+    ctx->comm_broken = false;
     ctx->rank = 0;
     ctx->world = 1;
 }
@@ -231,22 +334,25 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
         if (info) info->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
         return rc;
     }
+    TLM_CHECK(!ctx->comm_broken, TLM_EPEER, "tlm_pathset_allgather: the communicator was aborted after an earlier failure");
     RcclApi *api = rccl_api();
     if (!api) return TLM_EHIP;
     TLM_CHECK(ctx->comm, TLM_EINVAL, "tlm_pathset_allgather: tlm_dist_init has not been called");
     ncclComm_t comm = (ncclComm_t) ctx->comm;
     TLM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    TLM_HIP(hipEventRecord(ctx->ev0, s));
 
-    // ---- 0. my slots in 16 bits
+    // ---- 0. local: my slots in 16 bits (anything that fails here is reported to the peers with the sizes)
     uint64_t my_nodes = 0;
     for (int b = 0; b < n_sets; b++) my_nodes += sets[b]->n_nodes_total;
     Tmp s16, wide_flag;
-    if (int rc = tlm_pool_alloc(&s16.p, (my_nodes ? my_nodes : 1) * 2, s)) return rc;
-    if (int rc = tlm_pool_alloc(&wide_flag.p, 4, s)) return rc;
-    TLM_HIP(hipMemsetAsync(wide_flag.p, 0, 4, s));
-    {
+    uint32_t my_wide = 0;
+    auto prep = [&]() -> int {
+        if (fault_here(ctx, "prep")) return TLM_EHIP;
+        TLM_HIP(hipEventRecord(ctx->ev0, s));
+        if (int rc = tlm_pool_alloc(&s16.p, (my_nodes ? my_nodes : 1) * 2, s)) return rc;
+        if (int rc = tlm_pool_alloc(&wide_flag.p, 4, s)) return rc;
+        TLM_HIP(hipMemsetAsync(wide_flag.p, 0, 4, s));
         uint64_t at = 0;
         for (int b = 0; b < n_sets; b++) {
             const uint64_t n = sets[b]->n_nodes_total;
@@ -254,36 +360,49 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
                                       (uint16_t *) s16.p + at, (uint32_t *) wide_flag.p);
             at += n;
         }
-    }
-    uint32_t my_wide = 0;
-    TLM_HIP(hipMemcpyAsync(&my_wide, wide_flag.p, 4, hipMemcpyDeviceToHost, s));
-    TLM_HIP(hipStreamSynchronize(s));
+        TLM_HIP(hipMemcpyAsync(&my_wide, wide_flag.p, 4, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        TLM_HIP(hipGetLastError());
+        return TLM_OK;
+    };
+    const int rc_prep = prep();
+    const std::string prep_error = rc_prep ? tlm_last_error() : "";
 
-    // ---- 1. sizes
-    const size_t per_rank = (size_t) n_sets * 2 + 1;
+    // ---- 1. sizes + status of every rank, through the context's scratch: [status, (paths, nodes) x n_sets, wide]
+    const size_t per_rank = (size_t) n_sets * 2 + 2;
     std::vector<uint64_t> mine(per_rank), all(per_rank * world);
+    mine[0] = (uint64_t) (int64_t) rc_prep;
     for (int b = 0; b < n_sets; b++) {
-        mine[2 * b] = sets[b]->n_paths;
-        mine[2 * b + 1] = sets[b]->n_nodes_total;
+        mine[1 + 2 * b] = sets[b]->n_paths;
+        mine[2 + 2 * b] = sets[b]->n_nodes_total;
     }
-    mine[2 * n_sets] = my_wide;
-    Tmp d_mine, d_all;
-    if (int rc = tlm_pool_alloc(&d_mine.p, per_rank * 8, s)) return rc;
-    if (int rc = tlm_pool_alloc(&d_all.p, per_rank * 8 * world, s)) return rc;
-    TLM_HIP(hipMemcpyAsync(d_mine.p, mine.data(), per_rank * 8, hipMemcpyHostToDevice, s));
-    TLM_NCCL(api, api->AllGather(d_mine.p, d_all.p, per_rank, ncclUint64, comm, s));
-    TLM_HIP(hipMemcpyAsync(all.data(), d_all.p, per_rank * 8 * world, hipMemcpyDeviceToHost, s));
-    TLM_HIP(hipStreamSynchronize(s));
+    mine[per_rank - 1] = my_wide;
+    {
+        Collective col{ctx, api};
+        uint64_t *d_mine = (uint64_t *) ((char *) ctx->xchg_scratch + 1024), *d_all = (uint64_t *) ((char *) ctx->xchg_scratch + 2048);
+        static_assert(2048 + (TLM_EXCHANGE_MAX_BLOCKS / 4) * (8 * 2 + 2) * 8 <= TLM_XCHG_SCRATCH_BYTES, "scratch holds the sizes of 16 ranks");
+        TLM_HIP(hipMemcpyAsync(d_mine, mine.data(), per_rank * 8, hipMemcpyHostToDevice, s));
+        TLM_NCCL(api, api->AllGather(d_mine, d_all, per_rank, ncclUint64, comm, s));
+        TLM_HIP(hipMemcpyAsync(all.data(), d_all, per_rank * 8 * world, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        col.done();
+    }
+    if (rc_prep) {
+        tlm_set_error("%s", prep_error.c_str());
+        return rc_prep;
+    }
     bool wide = false;
     std::vector<uint64_t> counts((size_t) world * n_sets * 2), path_base((size_t) world * n_sets), node_base((size_t) world * n_sets);
     for (int r = 0; r < world; r++) {
-        for (int k = 0; k < 2 * n_sets; k++) counts[(size_t) r * n_sets * 2 + k] = all[r * per_rank + k];
-        wide |= all[r * per_rank + 2 * n_sets] != 0;
+        TLM_CHECK(all[r * per_rank] == 0, TLM_EPEER, "rank %d failed before the exchange (code %lld); rank %d leaves it too", r,
+                  (long long) (int64_t) all[r * per_rank], rank);
+        for (int k = 0; k < 2 * n_sets; k++) counts[(size_t) r * n_sets * 2 + k] = all[r * per_rank + 1 + k];
+        wide |= all[r * per_rank + per_rank - 1] != 0;
     }
     uint64_t totals[2];
     tlm_exchange_layout(world, n_sets, counts.data(), path_base.data(), node_base.data(), totals);
 
-    // ---- 2. the result, and every block straight into its place
+    // ---- 2. the result (local allocations: agreed on before any block moves), and every block straight into its place
     tlm_pathset *ps = new tlm_pathset();
     ps->ctx = ctx;
     ps->device = ctx->device;
@@ -293,19 +412,26 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
         tlm_pathset *p;
         ~Guard() { if (p) tlm_pathset_destroy(p); }
     } guard{ps};
-    auto palloc = [&](void **p, size_t bytes) { return tlm_pool_alloc(p, bytes ? bytes : 8, s); };
-    if (int rc = palloc((void **) &ps->unit, totals[0] * 8)) return rc;
-    if (int rc = palloc((void **) &ps->length, totals[0] * 8)) return rc;
-    if (int rc = palloc((void **) &ps->off, (totals[0] + 1) * 8)) return rc;
-    if (int rc = palloc((void **) &ps->nodes, totals[1] * 4)) return rc;
-    if (int rc = palloc((void **) &ps->slots, totals[1] * 4)) return rc;
     Tmp r16;            // received 16-bit slots, result layout
-    if (!wide)
-        if (int rc = tlm_pool_alloc(&r16.p, (totals[1] ? totals[1] : 1) * 2, s)) return rc;
+    auto alloc_result = [&]() -> int {
+        if (fault_here(ctx, "alloc")) return TLM_EHIP;
+        auto palloc = [&](void **p, size_t bytes) { return tlm_pool_alloc(p, bytes ? bytes : 8, s); };
+        if (int rc = palloc((void **) &ps->unit, totals[0] * 8)) return rc;
+        if (int rc = palloc((void **) &ps->length, totals[0] * 8)) return rc;
+        if (int rc = palloc((void **) &ps->off, (totals[0] + 1) * 8)) return rc;
+        if (int rc = palloc((void **) &ps->nodes, totals[1] * 4)) return rc;
+        if (int rc = palloc((void **) &ps->slots, totals[1] * 4)) return rc;
+        if (!wide)
+            if (int rc = tlm_pool_alloc(&r16.p, (totals[1] ? totals[1] : 1) * 2, s)) return rc;
+        return TLM_OK;
+    };
+    if (int rc = agree(ctx, api, alloc_result(), "tlm_pathset_allgather (result buffers)")) return rc;
     const size_t slot_bytes = wide ? 4 : 2;
     uint64_t sent = 0, received = 0;
-    TLM_NCCL(api, api->GroupStart());
+    Collective col{ctx, api};
+    if (int rc = col.group_start()) return rc;
     uint64_t my_node_at = 0;
+    bool first_send = true;
     for (int b = 0; b < n_sets; b++) {
         const tlm_pathset *q = sets[b];
         const void *my_slots = wide ? (const void *) q->slots : (const void *) ((const uint16_t *) s16.p + my_node_at);
@@ -329,6 +455,8 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
             const uint64_t mp = q->n_paths, mn = q->n_nodes_total;
             if (mp) {
                 TLM_NCCL(api, api->Send(q->unit, mp * 8, ncclUint8, r, comm, s));
+                if (first_send && fault_here(ctx, "group")) return TLM_EHIP;
+                first_send = false;
                 TLM_NCCL(api, api->Send(q->length, mp * 8, ncclUint8, r, comm, s));
                 TLM_NCCL(api, api->Send(q->off, mp * 8, ncclUint8, r, comm, s));
                 sent += mp * 24;
@@ -352,7 +480,8 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
         }
         my_node_at += q->n_nodes_total;
     }
-    TLM_NCCL(api, api->GroupEnd());
+    if (int rc = col.group_end()) return rc;
+    col.done();
 
     // ---- 3. fix-up
     BlockTable t;
@@ -431,6 +560,7 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
     TLM_CHECK(ctx && sets && out && n_sets >= 1 && n_sets <= 8, TLM_EINVAL, "tlm_pathset_gather_summaries: bad argument");
     const int world = ctx->world, rank = ctx->rank;
     TLM_CHECK(world * n_sets <= TLM_EXCHANGE_MAX_BLOCKS, TLM_ELIMIT, "tlm_pathset_gather_summaries: %d blocks", world * n_sets);
+    TLM_CHECK(!ctx->comm_broken, TLM_EPEER, "tlm_pathset_gather_summaries: the communicator was aborted after an earlier failure");
     const bool single = world == 1 && !(ctx->comm && getenv("TLM_EXCHANGE_SELFTEST"));
     RcclApi *api = single ? nullptr : rccl_api();
     if (!single && !api) return TLM_EHIP;
@@ -439,7 +569,6 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
     const auto t_wall = std::chrono::steady_clock::now();
     TLM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    TLM_HIP(hipEventRecord(ctx->ev0, s));
     tlm_gathered *g = new tlm_gathered();
     struct Guard {
         tlm_gathered *p;
@@ -449,27 +578,45 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
     g->world = world;
     g->rank = rank;
     g->n_sets = n_sets;
-    if (int rc = tlm_pathset_concat(ctx, n_sets, sets, &g->local)) return rc;
-    const uint64_t mine = g->local->n_paths;
+    // local: this rank's sets as one (what fails here is reported to the peers with the sizes)
+    auto prep = [&]() -> int {
+        if (fault_here(ctx, "prep")) return TLM_EHIP;
+        TLM_HIP(hipEventRecord(ctx->ev0, s));
+        return tlm_pathset_concat(ctx, n_sets, sets, &g->local);
+    };
+    const int rc_prep = prep();
+    const std::string prep_error = rc_prep ? tlm_last_error() : "";
+    if (single && rc_prep) return rc_prep;
+    const uint64_t mine = rc_prep ? 0 : g->local->n_paths;
 
-    // ---- sizes: (paths, nodes) of every block
-    const size_t per_rank = (size_t) n_sets * 2;
-    std::vector<uint64_t> my_counts(per_rank);
+    // ---- sizes: [status, (paths, nodes) of every block]
+    const size_t per_rank = (size_t) n_sets * 2, wire = per_rank + 1;
+    std::vector<uint64_t> my_counts(wire), all_counts(wire * world);
+    my_counts[0] = (uint64_t) (int64_t) rc_prep;
     g->counts.assign(per_rank * world, 0);
     for (int b = 0; b < n_sets; b++) {
-        my_counts[2 * b] = sets[b]->n_paths;
-        my_counts[2 * b + 1] = sets[b]->n_nodes_total;
+        my_counts[1 + 2 * b] = sets[b]->n_paths;
+        my_counts[2 + 2 * b] = sets[b]->n_nodes_total;
     }
     if (single) {
-        g->counts = my_counts;
+        for (size_t k = 0; k < per_rank; k++) g->counts[k] = my_counts[1 + k];
     } else {
-        Tmp d_mine, d_all;
-        if (int rc = tlm_pool_alloc(&d_mine.p, per_rank * 8, s)) return rc;
-        if (int rc = tlm_pool_alloc(&d_all.p, per_rank * 8 * world, s)) return rc;
-        TLM_HIP(hipMemcpyAsync(d_mine.p, my_counts.data(), per_rank * 8, hipMemcpyHostToDevice, s));
-        TLM_NCCL(api, api->AllGather(d_mine.p, d_all.p, per_rank, ncclUint64, (ncclComm_t) ctx->comm, s));
-        TLM_HIP(hipMemcpyAsync(g->counts.data(), d_all.p, per_rank * 8 * world, hipMemcpyDeviceToHost, s));
+        Collective col{ctx, api};
+        uint64_t *d_mine = (uint64_t *) ((char *) ctx->xchg_scratch + 1024), *d_all = (uint64_t *) ((char *) ctx->xchg_scratch + 2048);
+        TLM_HIP(hipMemcpyAsync(d_mine, my_counts.data(), wire * 8, hipMemcpyHostToDevice, s));
+        TLM_NCCL(api, api->AllGather(d_mine, d_all, wire, ncclUint64, (ncclComm_t) ctx->comm, s));
+        TLM_HIP(hipMemcpyAsync(all_counts.data(), d_all, wire * 8 * world, hipMemcpyDeviceToHost, s));
         TLM_HIP(hipStreamSynchronize(s));
+        col.done();
+        if (rc_prep) {
+            tlm_set_error("%s", prep_error.c_str());
+            return rc_prep;
+        }
+        for (int r = 0; r < world; r++) {
+            TLM_CHECK(all_counts[r * wire] == 0, TLM_EPEER, "rank %d failed before the exchange (code %lld); rank %d leaves it too", r,
+                      (long long) (int64_t) all_counts[r * wire], rank);
+            for (size_t k = 0; k < per_rank; k++) g->counts[(size_t) r * per_rank + k] = all_counts[r * wire + 1 + k];
+        }
     }
     uint64_t max_paths = 0;
     std::vector<uint64_t> rank_paths(world, 0);
@@ -477,36 +624,47 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
         for (int b = 0; b < n_sets; b++) rank_paths[r] += g->counts[(size_t) r * per_rank + 2 * b];
         max_paths = std::max(max_paths, rank_paths[r]);
     }
-    TLM_CHECK(rank_paths[rank] == mine, TLM_EINTERNAL, "tlm_pathset_gather_summaries: local count mismatch");
 
     // ---- summaries: this rank's columns, padded to the longest rank, one all-gather
     // slab of a rank: [unit u64 x P][length i64 x P][hash u64 x P][front u32 x P][back u32 x P][n_nodes u32 x P][dup u8 x P]
     const uint64_t P = std::max<uint64_t>(max_paths, 1);
     const size_t slab = (size_t) P * SummaryRow::BYTES;
     Tmp d_slab, d_allslabs;
-    if (int rc = tlm_pool_alloc(&d_slab.p, slab, s)) return rc;
-    if (int rc = tlm_pool_alloc(&d_allslabs.p, slab * world, s)) return rc;
-    char *base = (char *) d_slab.p;
-    uint64_t *d_unit = (uint64_t *) base;
-    int64_t *d_len = (int64_t *) (base + 8 * P);
-    uint64_t *d_hash = (uint64_t *) (base + 16 * P);
-    uint32_t *d_front = (uint32_t *) (base + 24 * P), *d_back = (uint32_t *) (base + 28 * P), *d_cnt = (uint32_t *) (base + 32 * P);
-    uint8_t *d_dup = (uint8_t *) (base + 36 * P);
-    TLM_HIP(hipMemsetAsync(base, 0, slab, s));
-    if (mine) {
-        TLM_HIP(hipMemcpyAsync(d_unit, g->local->unit, mine * 8, hipMemcpyDeviceToDevice, s));
-        TLM_HIP(hipMemcpyAsync(d_len, g->local->length, mine * 8, hipMemcpyDeviceToDevice, s));
-        if (int rc = tlm_pathset_summary_dev(g->local, s, d_front, d_back, d_cnt, d_hash, d_dup)) return rc;
-    }
+    auto fill = [&]() -> int {
+        if (fault_here(ctx, "alloc")) return TLM_EHIP;
+        TLM_CHECK(rank_paths[rank] == mine, TLM_EINTERNAL, "tlm_pathset_gather_summaries: local count mismatch");
+        if (int rc = tlm_pool_alloc(&d_slab.p, slab, s)) return rc;
+        if (!single)
+            if (int rc = tlm_pool_alloc(&d_allslabs.p, slab * world, s)) return rc;
+        char *base = (char *) d_slab.p;
+        uint64_t *d_unit = (uint64_t *) base;
+        int64_t *d_len = (int64_t *) (base + 8 * P);
+        uint64_t *d_hash = (uint64_t *) (base + 16 * P);
+        uint32_t *d_front = (uint32_t *) (base + 24 * P), *d_back = (uint32_t *) (base + 28 * P), *d_cnt = (uint32_t *) (base + 32 * P);
+        uint8_t *d_dup = (uint8_t *) (base + 36 * P);
+        TLM_HIP(hipMemsetAsync(base, 0, slab, s));
+        if (mine) {
+            TLM_HIP(hipMemcpyAsync(d_unit, g->local->unit, mine * 8, hipMemcpyDeviceToDevice, s));
+            TLM_HIP(hipMemcpyAsync(d_len, g->local->length, mine * 8, hipMemcpyDeviceToDevice, s));
+            if (int rc = tlm_pathset_summary_dev(g->local, s, d_front, d_back, d_cnt, d_hash, d_dup)) return rc;
+        }
+        return TLM_OK;
+    };
     std::vector<char> h_all(slab * world);
     if (single) {
+        if (int rc = fill()) return rc;
         TLM_HIP(hipMemcpyAsync(h_all.data(), d_slab.p, slab, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipEventRecord(ctx->ev1, s));
+        TLM_HIP(hipStreamSynchronize(s));
     } else {
+        if (int rc = agree(ctx, api, fill(), "tlm_pathset_gather_summaries (summary buffers)")) return rc;
+        Collective col{ctx, api};
         TLM_NCCL(api, api->AllGather(d_slab.p, d_allslabs.p, slab, ncclUint8, (ncclComm_t) ctx->comm, s));
         TLM_HIP(hipMemcpyAsync(h_all.data(), d_allslabs.p, slab * world, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipEventRecord(ctx->ev1, s));
+        TLM_HIP(hipStreamSynchronize(s));
+        col.done();
     }
-    TLM_HIP(hipEventRecord(ctx->ev1, s));
-    TLM_HIP(hipStreamSynchronize(s));
 
     // ---- paths_ order on the host: builder by builder, rank order inside
     uint64_t total = 0;
@@ -583,9 +741,11 @@ extern "C" int tlm_gathered_fetch(tlm_ctx *ctx, const tlm_gathered *g, uint64_t 
         TLM_CHECK(index[k] < total_paths, TLM_EINVAL, "tlm_gathered_fetch: path %llu of %llu", (unsigned long long) index[k],
                   (unsigned long long) total_paths);
     const int world = g->world, rank = g->rank;
+    TLM_CHECK(!ctx->comm_broken, TLM_EPEER, "tlm_gathered_fetch: the communicator was aborted after an earlier failure");
     const bool single = world == 1 && !(ctx->comm && getenv("TLM_EXCHANGE_SELFTEST"));
     RcclApi *api = single ? nullptr : rccl_api();
     if (!single && !api) return TLM_EHIP;
+    TLM_CHECK(single || ctx->comm, TLM_EINVAL, "tlm_gathered_fetch: the context has no communicator");
     TLM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     // staging layout: owner by owner, inside an owner in request order
@@ -604,10 +764,13 @@ extern "C" int tlm_gathered_fetch(tlm_ctx *ctx, const tlm_gathered *g, uint64_t 
     owner_begin[world] = at;
     const uint64_t total = at;
     Tmp st_nodes, st_slots, d_idx, d_dst;
-    if (int rc = tlm_pool_alloc(&st_nodes.p, (total ? total : 1) * 4, s)) return rc;
-    if (int rc = tlm_pool_alloc(&st_slots.p, (total ? total : 1) * 4, s)) return rc;
-    const std::vector<uint64_t> &mine = req_of[rank];
-    if (!mine.empty()) {
+    // local: my share of the request gathered into the staging buffer (its outcome is swapped before anybody broadcasts)
+    auto stage = [&]() -> int {
+        if (fault_here(ctx, "fetch")) return TLM_EHIP;
+        if (int rc = tlm_pool_alloc(&st_nodes.p, (total ? total : 1) * 4, s)) return rc;
+        if (int rc = tlm_pool_alloc(&st_slots.p, (total ? total : 1) * 4, s)) return rc;
+        const std::vector<uint64_t> &mine = req_of[rank];
+        if (mine.empty()) return TLM_OK;
         std::vector<uint64_t> li(mine.size()), ld(mine.size() + 1);
         for (size_t j = 0; j < mine.size(); j++) {
             li[j] = g->local_index[index[mine[j]]];
@@ -622,9 +785,14 @@ extern "C" int tlm_gathered_fetch(tlm_ctx *ctx, const tlm_gathered *g, uint64_t 
                                             (uint32_t *) st_nodes.p, (uint32_t *) st_slots.p))
             return rc;
         TLM_HIP(hipStreamSynchronize(s));       // li / ld go out of scope
-    }
-    if (!single) {
-        TLM_NCCL(api, api->GroupStart());
+        return TLM_OK;
+    };
+    if (single) {
+        if (int rc = stage()) return rc;
+    } else {
+        if (int rc = agree(ctx, api, stage(), "tlm_gathered_fetch (staging)")) return rc;
+        Collective col{ctx, api};
+        if (int rc = col.group_start()) return rc;
         for (int o = 0; o < world; o++) {
             const uint64_t len = owner_begin[o + 1] - owner_begin[o];
             if (!len) continue;
@@ -632,7 +800,8 @@ extern "C" int tlm_gathered_fetch(tlm_ctx *ctx, const tlm_gathered *g, uint64_t 
             TLM_NCCL(api, api->Broadcast(pn, pn, len * 4, ncclUint8, o, (ncclComm_t) ctx->comm, s));
             TLM_NCCL(api, api->Broadcast(psl, psl, len * 4, ncclUint8, o, (ncclComm_t) ctx->comm, s));
         }
-        TLM_NCCL(api, api->GroupEnd());
+        if (int rc = col.group_end()) return rc;
+        col.done();
     }
     std::vector<uint32_t> hn(total), hs(total);
     if (total) {

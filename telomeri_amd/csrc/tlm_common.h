@@ -43,6 +43,9 @@ struct tlm_ctx {
     std::vector<hipEvent_t> phase_ev;   // graph-build phase marks, created on first use
     void *comm = nullptr;          // ncclComm_t (exchange.hip); rank / world of the one-process-per-GPU job
     int rank = 0, world = 1;
+    void *xchg_scratch = nullptr;  // device, TLM_XCHG_SCRATCH_BYTES: status words and block sizes of the exchange calls; owned
+                                   // since tlm_dist_init so that telling the peers "I failed" never needs an allocation
+    bool comm_broken = false;      // the communicator was aborted after a failure inside a collective sequence
     void *upload_window = nullptr; // device memory shared with an upload helper process (tlm_upload_window_create)
     void *peer_window = nullptr;   // ... and, in the helper, the other process's window (tlm_upload_window_open)
     // host-side tidying that may wait (unpinning and unmapping 15 GB of uploaded text takes 0.65 s and blocks every
@@ -52,6 +55,7 @@ struct tlm_ctx {
     std::vector<std::function<void()>> deferred;
     std::vector<std::thread> deferred_running;
 };
+#define TLM_XCHG_SCRATCH_BYTES 16384
 void tlm_ctx_defer(tlm_ctx *ctx, std::function<void()> fn);
 void tlm_ctx_start_deferred(tlm_ctx *ctx);      // run what has been deferred so far, in background threads
 void tlm_ctx_join_deferred(tlm_ctx *ctx);       // start the rest and wait for all of it

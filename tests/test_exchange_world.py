@@ -1,0 +1,219 @@
+"""The product's multi-rank exchange (csrc/exchange.hip) EXECUTED with more than one rank on one GPU.
+
+Several processes (tests/exchange_worker.py) share cuda:0; each builds the same graph, walks its anchor bundle and joins
+tlm_pathset_allgather and tlm_pathset_gather_summaries / tlm_gathered_fetch through the library's own communicator.  RCCL
+refuses two ranks on one device, so the ten RCCL entry points the library binds are provided by tests/fake_rccl (test
+infrastructure, selected with TLM_RCCL_LIB): the library's code -- block placement, grouped send / receive pairing with
+its skipping of empty blocks, 16-bit slots and the fall-back to 32 bits, the owners' broadcasts, the fail-together
+protocol -- is what runs.  The result of every rank is compared with the one-process result byte for byte
+(reference consumer: Main.cpp:237-252, paths_ after the four builder calls).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import exchange_worker as W
+from telomeri_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fake_rccl():
+    if not os.path.exists(FAKE):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(FAKE)], check=True)
+    return FAKE
+
+
+def run_ranks(fake, dataset, world, tmp, extra_env=None, timeout=420):
+    env = dict(os.environ, TLM_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_S="90", **(extra_env or {}))
+    env.pop("TLM_EXCHANGE_SELFTEST", None)
+    idfile = os.path.join(tmp, "id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), dataset, str(r), str(world),
+                               idfile, tmp], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)         # a rank that hangs fails the test here
+            outs.append((p.returncode, out))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return outs
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return capi.Context(0)
+
+
+def one_process(ctx, dataset):
+    dg, wp = W.make_graph(ctx, dataset)
+    sets = W.rank_sets(dg, wp, 0, 1)
+    want = capi.PathSet.concat(sets)
+    return dg, wp, sets, want
+
+
+@pytest.mark.parametrize("dataset,world", [("toy", 2), ("quirks", 2), ("toy", 4), ("quirks", 3), ("hub", 2)])
+def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world):
+    dg, wp, sets, want = one_process(ctx, dataset)
+    h = want.to_host()
+    front, back, count, hsh = want.summary()
+    off = h.off.astype(np.int64)
+    n = len(h)
+    assert n > 0
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = run_ranks(fake_rccl, dataset, world, tmp)
+        for r, (rc, out) in enumerate(outs):
+            err = os.path.join(tmp, "rank%d.err" % r)
+            assert rc == 0, "rank %d: %s\n%s" % (r, open(err).read() if os.path.exists(err) else "", out[-2000:])
+        res = [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(world)]
+    # which rank owns which path: MC unit -> anchor -> bundle; DET unit -> anchor through det_off
+    _, det_off = dg.anchor_table()
+    builder = (h.unit >> np.uint64(56)).astype(np.int64)
+    unit = (h.unit & np.uint64((1 << 56) - 1)).astype(np.int64)
+    anchor = np.where(builder < 2, unit // wp.rebuild_attempts, np.searchsorted(det_off.astype(np.int64), unit, side="right") - 1)
+    ranges = [dg.anchor_range(r, world) for r in range(world)]
+    owner = np.array([next(r for r, (a0, a1) in enumerate(ranges) if a0 <= a < a1) for a in anchor], np.uint32)
+    seqs = [h.nodes[off[i]:off[i + 1]].tobytes() for i in range(n)]
+    first = np.r_[True, (builder[1:] != builder[:-1]) | (owner[1:] != owner[:-1])]
+    dup = np.array([(not first[i]) and seqs[i] == seqs[i - 1] for i in range(n)])
+    pick = W.pick_indices(n).astype(np.int64)
+    total_local = np.zeros(4, np.int64)
+    for r, e in enumerate(res):
+        # ---- the full exchange: paths_ of one PathManager, element for element
+        np.testing.assert_array_equal(e["full_unit"], h.unit, err_msg="rank %d" % r)
+        np.testing.assert_array_equal(e["full_length"], h.length)
+        np.testing.assert_array_equal(e["full_off"], h.off)
+        np.testing.assert_array_equal(e["full_nodes"], h.nodes)
+        np.testing.assert_array_equal(e["full_slots"], h.slots)
+        # ---- the lazy exchange
+        assert int(e["lazy_info"][2]) == n and int(e["lazy_info"][3]) == int(e["local_paths"].sum())
+        for k, w in (("unit", h.unit), ("length", h.length), ("front", front), ("back", back), ("n_nodes", count), ("hash", hsh),
+                     ("owner", owner)):
+            np.testing.assert_array_equal(e["lazy_" + k], w, err_msg="rank %d %s" % (r, k))
+        np.testing.assert_array_equal(e["lazy_block_first"].astype(bool), first)
+        np.testing.assert_array_equal(e["lazy_dup_of_prev"].astype(bool), dup)
+        np.testing.assert_array_equal(e["fetch_nodes"], np.concatenate([h.nodes[off[i]:off[i + 1]] for i in pick]))
+        np.testing.assert_array_equal(e["fetch_slots"], np.concatenate([h.slots[off[i]:off[i + 1]] for i in pick]))
+        total_local += e["local_paths"]
+        # bytes on the wire: everything but this rank's own blocks, 24 B a path + (4 + slot bytes) a path node
+        mine = owner == r
+        slot_bits = int(e["full_info"][2])
+        other_nodes = int((count[~mine]).sum())
+        assert int(e["full_info"][1]) == 24 * int((~mine).sum()) + (4 + slot_bits // 8) * other_nodes
+        assert int(e["full_info"][0]) == (world - 1) * (24 * int(mine.sum()) + (4 + slot_bits // 8) * int(count[mine].sum()))
+    np.testing.assert_array_equal(total_local, [s.n_paths for s in sets])
+    wide = bool(((h.slots != 0xFFFFFFFF) & (h.slots >= 0xFFFF)).any())
+    assert all(int(e["full_info"][2]) == (32 if wide else 16) for e in res)
+    if dataset == "hub":
+        assert wide, "the hub graph is there to force 32-bit slots"
+        # only the first rank's paths hold such a slot: the others learn it from the sizes exchange
+        assert not ((h.slots != 0xFFFFFFFF) & (h.slots >= 0xFFFF))[np.repeat(owner != 0, count)].any()
+    if dataset == "quirks":
+        assert dup.any(), "quirks is there for its runs of identical paths"
+    if (dataset, world) == ("toy", 4):
+        assert any(e["local_paths"].sum() == 0 for e in res), "4 ranks over 3 anchors: one rank has nothing to send"
+
+
+@pytest.mark.parametrize("point", ["prep", "alloc", "group", "fetch"])
+def test_ranks_fail_together(fake_rccl, point):
+    """One rank pretends a local step failed (TLM_EXCHANGE_FAULT): the call ends on EVERY rank -- the failing one with
+    its own error, the other with TLM_EPEER (-5) -- nobody hangs; after a failure inside the grouped transfers the
+    communicator is aborted and later calls fail at once."""
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = run_ranks(fake_rccl, "toy", 2, tmp, {"TLM_EXCHANGE_FAULT": "1:" + point}, timeout=300)
+        logs = []
+        for r, (rc, out) in enumerate(outs):
+            assert rc == 0, "rank %d: %s" % (r, out[-2000:])
+            logs.append(open(os.path.join(tmp, "rank%d.log" % r)).read().splitlines())
+    culprit, peer = logs[1], logs[0]
+    if point == "fetch":
+        assert culprit[0] == peer[0] == "allgather: ok" and culprit[1] == peer[1] == "gather_summaries: ok"
+        for k in (2, 3):
+            assert "injected failure at 'fetch' on rank 1" in culprit[k] and "(-2)" in culprit[k]
+            assert "(-5)" in peer[k] and "rank 1 failed" in peer[k]
+        return
+    assert "injected failure at '%s' on rank 1" % point in culprit[0] and "(-2)" in culprit[0]
+    assert "allgather" in peer[0] and "ok" not in peer[0]
+    if point == "group":
+        # the culprit left in the middle of the grouped transfers: both communicators are gone, the next call says so
+        assert "aborted" in culprit[0]
+        assert "(-5)" in culprit[1] and "aborted" in culprit[1]
+        assert "(-5)" in peer[1] and "aborted" in peer[1]
+    else:
+        assert "(-5)" in peer[0] and "rank 1 failed" in peer[0]
+        assert "injected failure" in culprit[1] and "(-5)" in peer[1]       # the communicator is intact: the protocol again
+    assert len(culprit) == len(peer) == 2
+
+
+# ---- the host program, two ranks (run.sh with TLM_GPUS=2; both on device 0) -------------------------------------------------
+REPORT = ("-", "Paths", "Found", "Consensus", "Final", "ctg", "read", "Anchor pairs")
+
+
+def _dataset_dir(tmp, name):
+    import golden_util as G
+    import helpers as H
+    from telomeri_amd import synth
+    meta = G.load_json(name + ".json")
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    d = os.path.join(tmp, name)
+    os.makedirs(d)
+    os.rename(G.gunzip_to(tmp, name + "_rr.paf.gz"), os.path.join(d, "rr_overlaps.paf"))
+    os.rename(G.gunzip_to(tmp, name + "_cr.paf.gz"), os.path.join(d, "cr_overlaps.paf"))
+    synth.write_fasta(ds, os.path.join(d, "reads.fasta"), os.path.join(d, "contigs.fasta"))
+    return d, [a for a in meta["args"] if a != "--sqrt"]
+
+
+def _run_sh(d, args, env):
+    res = subprocess.run([os.path.join(ROOT, "run.sh"), d] + args, capture_output=True, text=True, timeout=420,
+                         env=dict(os.environ, **env))
+    out = os.path.join(d, "HERA_result.fasta")
+    body = open(out, "rb").read() if os.path.exists(out) else None
+    if body is not None:
+        os.remove(out)
+    return res, body
+
+
+@pytest.mark.parametrize("name", ["tiny", "quirks"])
+@pytest.mark.parametrize("mode", ["lazy", "full"])
+def test_host_program_with_two_ranks(fake_rccl, name, mode):
+    """telomeri_hip as a two-rank job (TLM_WORLD=2: every rank loads and builds, walks its bundle, joins the exchange, runs
+    the host stages; rank 0 writes the scaffold): same report, same scaffold bytes as the one-process run."""
+    with tempfile.TemporaryDirectory() as tmp:
+        d, args = _dataset_dir(tmp, name)
+        one, body_one = _run_sh(d, args, {})
+        assert one.returncode == 0, one.stderr[-2000:]
+        two, body_two = _run_sh(d, args, {"TLM_GPUS": "2", "TLM_DEVICES": "0 0", "TLM_RCCL_LIB": fake_rccl, "TLM_EXCHANGE": mode,
+                                          "FAKE_RCCL_TIMEOUT_S": "90"})
+        rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
+        assert two.returncode == 0, two.stderr[-2000:] + rank1[-2000:]
+        assert "Gathered" in two.stdout and "from 2 ranks" in two.stdout and "from 2 ranks" in rank1
+        keep = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(REPORT)]
+        assert keep(two.stdout) == keep(one.stdout)
+        assert keep(rank1) == keep(one.stdout)          # every rank runs the same host stages on the same paths_
+        assert body_two == body_one and body_one
+
+
+def test_host_program_ranks_end_together(fake_rccl):
+    """A rank that fails takes the job down: run.sh returns its status and leaves no rank behind waiting in a collective."""
+    import time
+    with tempfile.TemporaryDirectory() as tmp:
+        d, args = _dataset_dir(tmp, "tiny")
+        t0 = time.time()
+        res, body = _run_sh(d, args, {"TLM_GPUS": "2", "TLM_DEVICES": "0 0", "TLM_RCCL_LIB": fake_rccl, "TLM_EXCHANGE_FAULT": "1:prep",
+                                      "FAKE_RCCL_TIMEOUT_S": "90"})
+        assert res.returncode != 0 and body is None
+        assert time.time() - t0 < 120
+        rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
+        assert "injected failure" in rank1
+        assert "rank 1 failed" in res.stderr or "a rank ended with status" in res.stderr
