@@ -96,6 +96,9 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-layout-accounting", action="store_true",
+                    help="skip the untimed accounting launch behind roofline.frac_layout (under a profiler: its kernels would "
+                         "be counted with the product's)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (reported as cores)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -107,10 +110,13 @@ def main() -> None:
             time.sleep(30)      # the launcher must end this rank when the failing one has gone
         sys.exit(7 if status else 0)
 
+    from telomeri_amd import cpu_share
+    host_threads = cpu_share.limit_thread_pools()       # before numpy / torch start their pools (DESIGN.md "The CPU quota")
     import numpy as np
     import torch
     import torch.distributed as dist
     from telomeri_amd import capi, pathgather, synth
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_threads)))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -173,9 +179,11 @@ def main() -> None:
     g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
     cold_build_ms = float(g.info().build_ms)
     del g
+    throttle0 = cpu_share.throttle_counters()
     t0 = time.time()
     g = ctx.build_graph(fp, [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
     t_build = time.time() - t0
+    throttle1 = cpu_share.throttle_counters()
     gi = g.info()
     n_records = int(gi.n_records)
     del ds
@@ -281,8 +289,31 @@ def main() -> None:
         return
 
     value = evals_all / elapsed
-    # roofline of the dominant kernel (walk_mc_kernel): 8 algorithmic bytes per eval (DESIGN.md §6)
+    # roofline of the dominant kernel (walk_mc_kernel): 8 algorithmic bytes per eval (SURVEY.md §8d, DESIGN.md §6)
     ach = 8.0 * mc_evals / (mc_ms * 1e-3) / 1e9 if mc_ms > 0 else 0.0
+    # ... and against the bytes the walk layout REALLY has to move: compact rows are 6 bytes per entry, lists are read in
+    # whole lane widths, every step also reads a row record and a {q_start, t_start} pair.  Counted exactly by ONE untimed
+    # launch of the accounting build of the same kernels over the same units (tlm_ctx_set_walk_accounting).
+    layout = {}
+    try:
+        if args.no_layout_accounting:
+            raise RuntimeError("switched off")
+        ctx.set_walk_accounting(True)
+        a, b = g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range)
+        lb_mc, ev_mc = int(a.counters.layout_bytes), int(a.counters.evals) + int(b.counters.evals)
+        a_classes = list(a.counters.step_class)
+        del a, b
+        layout["mc"] = (lb_mc, ev_mc)
+        layout["mc_classes"] = [int(x) for x in a_classes]
+        if not args.no_det and d1 > d0:
+            a, b = g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
+            layout["det"] = (int(a.counters.layout_bytes), int(a.counters.evals) + int(b.counters.evals))
+            layout["det_classes"] = [int(x) for x in a.counters.step_class]
+            del a, b
+    except Exception as e:
+        log("layout accounting failed: %r" % (e,))
+    finally:
+        ctx.set_walk_accounting(False)
     # HBM traffic of the dominant kernel cannot be counted from inside this process (PMC counters need rocprofv3 around
     # it): it is taken from the tracked profile of THIS workload (profiles/run_profile.sh -> profiles/summarize.py) and
     # reported only when that profile's launch processed the same number of evals as the launches timed here
@@ -311,11 +342,8 @@ def main() -> None:
                    "anchors_total": n_anchors, "anchors_walked": min(apg * world, n_anchors), "anchors_per_gpu": apg, "rebuild_attempts": args.rb_att, "backtrack_attempts": args.bt_att,
                    "len_threshold": args.len_thr, "seed_policy": "per-walk mt19937",
                    "partition": "anchor bundles per rank, CSR replicated, one all-gather of Paths (inside the timed step)"},
-        "roofline": {"bound": "hbm", "kernel": "walk_mc_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                     "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                     "achieved_is": "algorithmic bytes (8 B per eval) per second, not HBM traffic",
-                     "launches": int(mc_launches), "avg_launch_ms": mc_ms / max(mc_launches, 1),
-                     "algorithmic_bytes_per_eval": 8, "evals_per_launch": evals_per_launch},
+        "roofline": roofline_block(ach, traffic, traffic_source, mc_ms, mc_launches, evals_per_launch, layout.get("mc"),
+                                   layout.get("mc_classes")),
         "kernels": {"walk_mc_ms_per_step": mc_ms / max(args.steps, 1),
                     # the deterministic launch is queued behind the Monte-Carlo one: from launch to end (queued) and from
                     # its first workgroup in to its last one out (busy, device clock)
@@ -323,10 +351,17 @@ def main() -> None:
                     "walk_det_ms_per_step": det_busy_ms / max(args.steps, 1),
                     "walk_mc_evals_per_s": mc_evals / (mc_ms * 1e-3) if mc_ms else None,
                     "walk_det_evals_per_s": det_evals / (det_busy_ms * 1e-3) if det_busy_ms else None,
+                    "walk_det_roofline": det_roofline(det_evals, det_busy_ms, layout.get("det"), layout.get("det_classes")),
                     "graph_build_cold_ms": cold_build_ms, "graph_build_device_ms": gi.build_ms, "filter_score_ms": gi.filter_ms,
                     "graph_build_wall_ms": gi.build_wall_ms, "graph_build_alloc_ms": gi.build_alloc_ms,
                     "graph_build_host_syncs": gi.host_syncs,
                     "graph_build_phases_ms": {k: round(v, 3) for k, v in gi.phases().items()},
+                    # the host's time between the same marks (waits for the device excluded) and those waits: a phase that
+                    # is long on the device timeline and long HERE was held up on the host, not by its kernels
+                    "graph_build_host_phases_ms": {k: round(v, 3) for k, v in gi.host_phases().items()},
+                    "graph_build_sync_wait_ms": gi.sync_wait_ms,
+                    "graph_build_cpu_throttled": {k: throttle1.get(k, 0) - throttle0.get(k, 0) for k in throttle1},
+                    "host_threads": host_threads,
                     "filter_score_records_per_s": n_records / (gi.filter_ms * 1e-3) if gi.filter_ms else None,
                     "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
         "paths_per_step": paths_total,
@@ -394,6 +429,58 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+STEP_CLASS_NAMES = ("compact_k4", "compact_k6", "compact_k8", "compact_k12", "row8_k4", "row8_k6", "row8_k8", "row8_k12",
+                    "long_list", "serial")
+
+
+def class_shares(classes):
+    tot = float(sum(classes)) if classes else 0.0
+    return {n: round(c / tot, 5) for n, c in zip(STEP_CLASS_NAMES, classes) if c} if tot else None
+
+
+def roofline_block(ach, traffic, traffic_source, mc_ms, mc_launches, evals_per_launch, layout, classes=None):
+    """`frac` stays what SURVEY.md §8(d) defines: 8 algorithmic bytes per eval against 8 TB/s.  Since the compact rows
+    (6 bytes per entry) that figure is no longer a lower bound on the bytes moved, so `frac` CAN exceed 1 on graphs whose
+    steps run mostly on compact rows; `frac_layout` prices the same launch against the bytes its loads really ask the
+    layout for (counted by the accounting build) and is the one that is bounded by 1."""
+    avg_ms = mc_ms / max(mc_launches, 1)
+    r = {"bound": "hbm", "kernel": "walk_mc_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+         "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+         "achieved_is": "algorithmic bytes (8 B per eval) per second, not HBM traffic",
+         "launches": int(mc_launches), "avg_launch_ms": avg_ms,
+         "algorithmic_bytes_per_eval": 8, "evals_per_launch": evals_per_launch}
+    if traffic and avg_ms > 0:
+        r["traffic_TBps"] = traffic / (avg_ms * 1e-3) / 1e12
+    if layout and layout[1] > 0 and avg_ms > 0:
+        lb, ev = layout
+        r["layout_bytes_per_eval"] = lb / ev
+        r["layout_bytes_per_launch"] = lb * (evals_per_launch / ev)
+        r["achieved_layout"] = r["layout_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        r["frac_layout"] = r["achieved_layout"] / 8000.0
+        r["layout_is"] = ("bytes the steps' loads ask the walk layout for, counted by an untimed launch of the accounting "
+                          "build over the same units: list entries as read (6 B compact / 8 B rows, whole lane widths), "
+                          "8 B row record, 8 B {q_start, t_start}")
+    if classes:
+        r["step_classes"] = class_shares(classes)       # share of the steps by the form of their selection (accounting launch)
+    if r["frac"] > 1.0:
+        r["frac_note"] = ("frac > 1: the yardstick (8 B per eval) is SURVEY.md's figure, most steps of this graph read 6-byte "
+                          "compact rows; frac_layout is the bounded figure")
+    return r
+
+
+def det_roofline(det_evals, det_busy_ms, layout, classes=None):
+    if not det_busy_ms:
+        return None
+    r = {"kernel": "walk_det_kernel", "achieved": 8.0 * det_evals / (det_busy_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s"}
+    r["frac"] = r["achieved"] / 8000.0
+    if layout and layout[1] > 0:
+        r["layout_bytes_per_eval"] = layout[0] / layout[1]
+        r["frac_layout"] = r["layout_bytes_per_eval"] * det_evals / (det_busy_ms * 1e-3) / 8e12
+    if classes:
+        r["step_classes"] = class_shares(classes)
+    return r
 
 
 def cpu_baseline(args, g, wp, h, mc_range, capi):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TLM_ABI_VERSION 2
+#define TLM_ABI_VERSION 3
 
 enum {
     TLM_OK = 0,
@@ -79,7 +79,15 @@ typedef struct {
     double kernel_busy_ms;         /* first workgroup in -> last workgroup out, device clock: equals kernel_ms for a launch
                                       that starts at once; tlm_walk_builders queues its deterministic launch behind the
                                       Monte-Carlo launch, where kernel_ms includes the wait for free compute units */
+    uint64_t layout_bytes;         /* (ABI 3) 0 unless tlm_ctx_set_walk_accounting is on: the bytes the steps' loads asked
+                                      the walk layout for -- list entries as read (6-byte compact or 8-byte rows, padded
+                                      to the lane width), row record, {q_start, t_start}; booked like kernel_ms */
+    /* (ABI 3, accounting launches) steps by the form of their selection: 0-3 compact row read with 4 / 6 / 8 / 12 entries
+     * per lane (lists up to 256 / 384 / 512 / 768), 4-7 the same on an 8-byte row (7: deterministic kernel only), 8 chunked
+     * long list, 9 serial (order-unsafe row) */
+    uint64_t step_class[10];
 } tlm_counters;
+#define TLM_STEP_CLASSES 10
 
 typedef struct {
     uint8_t status;
@@ -124,6 +132,11 @@ int tlm_ctx_set_walk_tuning(tlm_ctx *ctx, int waves_per_cu, uint32_t path_capaci
  * sized from the number of units).  A launch that outgrows its arena is re-run for the units that did not fit with a
  * larger one (results unchanged); tests use a small limit to exercise that. */
 int tlm_ctx_set_arena_limit(tlm_ctx *ctx, uint64_t bytes);
+/* Measurement: with `on` != 0 the walk calls launch a second build of the same kernels that also adds up the bytes its
+ * steps ask the walk layout for (tlm_counters.layout_bytes).  Same walks, same results; a little slower, so never on for a
+ * timed launch: bench.py runs one accounting launch beside its timed steps to price the roofline against the bytes the
+ * layout really has to move. */
+int tlm_ctx_set_walk_accounting(tlm_ctx *ctx, int on);
 
 /* Device memory held by the library on the context's device.  Every buffer (graph, temporaries, walk workspaces, path
  * sets) comes from a cache owned by the library: blocks are hipMalloc'd once and re-used by later calls; the device's
@@ -190,6 +203,11 @@ typedef struct {
     double build_wall_ms;          /* host wall-clock of the build call */
     double build_alloc_ms;         /* of which: host time in hipMalloc (0 once the library's cache is warm) */
     uint32_t host_syncs;           /* host waits for the device during the build */
+    /* (ABI 3) the HOST's time between the same marks, its waits for the device excluded: what the host spent queueing a
+     * phase.  A phase with a few ms of kernels and tens of ms here was held up on the host (an allocation, a blocking
+     * copy, the process being descheduled), not on the device.  sync_wait_ms = the excluded waits, all phases. */
+    double phase_host_ms[TLM_BUILD_PHASES];
+    double sync_wait_ms;
 } tlm_graph_info;
 int tlm_graph_get_info(const tlm_graph *g, tlm_graph_info *out);
 const char *tlm_build_phase_name(int phase);

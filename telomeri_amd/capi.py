@@ -49,7 +49,7 @@ class WalkParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("units", C.c_uint64), ("steps", C.c_uint64), ("evals", C.c_uint64), ("draws", C.c_uint64),
                 ("accepted", C.c_uint64), ("kernel_ms", C.c_double), ("kernel_launches", C.c_uint32),
-                ("waves", C.c_uint32), ("kernel_busy_ms", C.c_double)]
+                ("waves", C.c_uint32), ("kernel_busy_ms", C.c_double), ("layout_bytes", C.c_uint64), ("step_class", C.c_uint64 * 10)]
 
 
 class _Records(C.Structure):
@@ -63,11 +63,15 @@ class GraphInfo(C.Structure):
                 ("n_kept", C.c_uint64), ("n_kept_per_file", C.c_uint64 * 4), ("max_degree", C.c_uint32),
                 ("unsafe_nodes", C.c_uint32 * 4), ("bfs_levels", C.c_uint32), ("build_ms", C.c_double), ("filter_ms", C.c_double),
                 ("phase_ms", C.c_double * 12), ("build_wall_ms", C.c_double), ("build_alloc_ms", C.c_double),
-                ("host_syncs", C.c_uint32)]
+                ("host_syncs", C.c_uint32), ("phase_host_ms", C.c_double * 12), ("sync_wait_ms", C.c_double)]
 
     def phases(self) -> dict:
         """{phase name: device-timeline ms} of the build (tlm_build_phase_name)."""
         return {lib().tlm_build_phase_name(i).decode(): float(self.phase_ms[i]) for i in range(12)}
+
+    def host_phases(self) -> dict:
+        """Host time spent queueing each phase (waits for the device excluded)."""
+        return {lib().tlm_build_phase_name(i).decode(): float(self.phase_host_ms[i]) for i in range(12)}
 
 
 class GraphStats(C.Structure):
@@ -123,6 +127,7 @@ def lib() -> C.CDLL:
     L.tlm_ctx_synchronize.argtypes = [V]
     L.tlm_ctx_set_walk_tuning.argtypes = [V, C.c_int, C.c_uint32]
     L.tlm_ctx_set_arena_limit.argtypes = [V, C.c_uint64]
+    L.tlm_ctx_set_walk_accounting.argtypes = [V, C.c_int]
     L.tlm_ctx_memory_info.argtypes = [V, P(MemoryInfo)]
     L.tlm_ctx_trim.argtypes = [V]
     L.tlm_build_phase_name.argtypes = [C.c_int]
@@ -515,6 +520,10 @@ class Context:
 
     def dist_finalize(self) -> None:
         lib().tlm_dist_finalize(self._h)
+
+    def set_walk_accounting(self, on: bool) -> None:
+        """Walk calls launch the builds of the kernels that also count layout bytes (Counters.layout_bytes); never timed."""
+        _check(lib().tlm_ctx_set_walk_accounting(self._h, int(bool(on))), "tlm_ctx_set_walk_accounting")
 
     def set_arena_limit(self, nbytes: int) -> None:
         _check(lib().tlm_ctx_set_arena_limit(self._h, nbytes), "tlm_ctx_set_arena_limit")

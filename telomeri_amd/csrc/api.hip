@@ -131,6 +131,7 @@ extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
         || hipStreamCreateWithPriority(&c->side.stream, hipStreamNonBlocking, prio_lo) != hipSuccess
         || hipEventCreate(&c->side.ev0) != hipSuccess || hipEventCreate(&c->side.ev1) != hipSuccess
         || hipMalloc((void **) &c->side.ws.cursor, WALK_CURSOR_WORDS * 4) != hipSuccess
+        || hipHostMalloc((void **) &c->pinned_small, TLM_PINNED_SMALL_BYTES, hipHostMallocDefault) != hipSuccess
         || hipHostMalloc((void **) &c->resident_host, 64, hipHostMallocMapped) != hipSuccess
         || hipHostGetDevicePointer((void **) &c->resident_dev, c->resident_host, 0) != hipSuccess) {
         tlm_set_error("tlm_ctx_create: stream/event creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -158,6 +159,7 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     c->side.ws.release_host();
     (void) hipFree(c->side.ws.cursor);
     if (c->resident_host) (void) hipHostFree(c->resident_host);
+    if (c->pinned_small) (void) hipHostFree(c->pinned_small);
     if (c->peer_window) (void) hipIpcCloseMemHandle(c->peer_window);
     if (c->upload_window) (void) hipFree(c->upload_window);
     for (hipEvent_t e : c->phase_ev) (void) hipEventDestroy(e);
@@ -181,6 +183,12 @@ extern "C" void *tlm_ctx_stream(tlm_ctx *ctx) { return ctx ? (void *) ctx->strea
 extern "C" int tlm_ctx_synchronize(tlm_ctx *ctx) {
     TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_synchronize: null ctx");
     TLM_HIP(hipStreamSynchronize(ctx->stream));
+    return TLM_OK;
+}
+
+extern "C" int tlm_ctx_set_walk_accounting(tlm_ctx *ctx, int on) {
+    TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_set_walk_accounting: null ctx");
+    ctx->walk_accounting = on != 0;
     return TLM_OK;
 }
 
@@ -624,7 +632,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             launch_waves = std::max<uint32_t>(WPB, launch_waves);
             TLM_HIP(hipMemsetAsync(W.cursor + WALK_QUEUE_BASE, 0, WALK_QUEUE_STRIDE * WALK_XCDS * 4, s));
             TLM_HIP(hipMemsetAsync(W.cursor + 6, 0xFF, 8, s));      // first workgroup in (atomicMin)
-            TLM_HIP(hipMemsetAsync(W.cursor + 8, 0, 8, s));         // last workgroup out (atomicMax)
+            TLM_HIP(hipMemsetAsync(W.cursor + 8, 0, 96, s));        // last workgroup out (atomicMax); accounting [10..31]
             if (wait_for) {
                 // The other lane's launch goes first, and this one must not reach the dispatcher before ALL workgroups of
                 // that launch are resident: two launches dispatched together share the slots, and deterministic waves that
@@ -646,15 +654,15 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 a.resident_flag = c->resident_dev;
             }
             TLM_HIP(hipEventRecord(ev0, s));
-            if (is_mc) tlm_launch_walk_mc(s, launch_waves / WPB, sq, a);
-            else tlm_launch_walk_det(s, launch_waves / WPB, sq, a);
+            if (is_mc) tlm_launch_walk_mc(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
+            else tlm_launch_walk_det(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));
             if (launched) launched->store(1);
             static const bool tidy_after = [] { const char *e = std::getenv("TLM_TIDY"); return e && !std::strcmp(e, "after"); }();
             if (lane == 0 && round == 0 && !tidy_after) tlm_ctx_start_deferred(ctx);      // the device is busy for a while: the host tidies up
-            unsigned long long span[2] = {0, 0};
-            TLM_HIP(hipMemcpyAsync(span, W.cursor + 6, 16, hipMemcpyDeviceToHost, s));
+            unsigned long long span[13] = {0};     // first workgroup in, last out; accounting builds: layout bytes, step classes
+            TLM_HIP(hipMemcpyAsync(span, W.cursor + 6, sizeof(span), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipMemcpyAsync(h_units, u.units, (size_t) n_all * sizeof(UnitOut), hipMemcpyDeviceToHost, s));
             TLM_HIP(hipEventSynchronize(ev1));
             TLM_HIP(hipStreamSynchronize(s));
@@ -663,6 +671,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             TLM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             cnt[0].kernel_ms += ms;          // the launch is shared by the slots: it is booked on the first one
             cnt[0].kernel_launches++;
+            cnt[0].layout_bytes += span[2];
+            for (int k = 0; k < TLM_STEP_CLASSES; k++) cnt[0].step_class[k] += span[3 + k];
             // (only the deterministic kernel stamps its span; a Monte-Carlo launch starts at once: its span is `ms`)
             cnt[0].kernel_busy_ms += (!is_mc && span[1] > span[0]) ? (double) (span[1] - span[0]) * 1e-5 : ms;     // 100 MHz ticks
             // overflow handling: re-run the affected units with a full-size path buffer / a larger arena

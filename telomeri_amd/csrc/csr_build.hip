@@ -60,9 +60,17 @@ struct Phases {
     uint32_t syncs = 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     double malloc_ms0 = tlm_pool_thread_malloc_ms();
+    // the HOST's side of the same timeline: when each mark was made, and how long the host waited in sync() since the
+    // previous mark -- a phase whose host time (waits excluded) is long was held up on the host, whatever its kernels took
+    std::chrono::steady_clock::time_point t_host[64];
+    double wait_ms[64];
+    double wait_since_mark = 0, wait_total = 0;
     Phases(tlm_ctx *c, hipStream_t st) : ctx(c), s(st) { mark(PH_OTHER); }
     void mark(int phase) {          // `phase` ENDS here (the first mark only opens the timeline)
         if (n >= 64) return;
+        t_host[n] = std::chrono::steady_clock::now();
+        wait_ms[n] = wait_since_mark;
+        wait_since_mark = 0;
         while ((int) ctx->phase_ev.size() <= n) {
             hipEvent_t e = nullptr;
             if (hipEventCreate(&e) != hipSuccess) return;
@@ -73,14 +81,20 @@ struct Phases {
     }
     int sync() {
         syncs++;
+        const auto w0 = std::chrono::steady_clock::now();
         TLM_HIP(hipStreamSynchronize(s));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        wait_since_mark += ms;
+        wait_total += ms;
         return TLM_OK;
     }
     void collect(tlm_graph_info &info) {     // after the final sync
         for (int k = 1; k < n; k++) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, ctx->phase_ev[k - 1], ctx->phase_ev[k]) == hipSuccess) info.phase_ms[phase_of[k]] += ms;
+            info.phase_host_ms[phase_of[k]] += std::chrono::duration<double, std::milli>(t_host[k] - t_host[k - 1]).count() - wait_ms[k];
         }
+        info.sync_wait_ms += wait_total;
         info.host_syncs += syncs;
         info.build_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         info.build_alloc_ms += tlm_pool_thread_malloc_ms() - malloc_ms0;
@@ -591,8 +605,8 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         hipLaunchKernelGGL(node_flags_kernel, dim3(grid_for((uint64_t) N * 64)), dim3(256), 0, s, N, g->row_ptr,
                            g->ent_es, g->ent_os, g->node_flags, cnts.as<uint32_t>(), cnts.as<uint32_t>() + 4);
     }
-    uint32_t h_cnts[8];
-    TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, sizeof(h_cnts), hipMemcpyDeviceToHost, s));
+    uint32_t *const h_cnts = (uint32_t *) ctx->pinned_small;
+    TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     std::vector<uint8_t> h_anchor(N);
     if (N) TLM_HIP(hipMemcpyAsync(h_anchor.data(), g->node_anchor, N, hipMemcpyDeviceToHost, s));
     ph.mark(PH_FLAGS);
@@ -635,28 +649,31 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         hipLaunchKernelGGL(bfs_init_kernel, dim3((na + 255) / 256), dim3(256), 0, s, na, g->anchors,
                            key.as<unsigned long long>(), f0.as<uint32_t>());
         uint32_t level = 0;
-        uint32_t h_cnt[BATCH + 1];
-        std::memset(h_cnt, 0, sizeof(h_cnt));
+        static_assert(128 + 2 * (BATCH + 1) * 4 <= TLM_PINNED_SMALL_BYTES, "the BFS counters fit the pinned words");
+        uint32_t *const h_cnt = (uint32_t *) ((char *) ctx->pinned_small + 128);        // up: this batch's initial counters
+        uint32_t *const h_got = h_cnt + (BATCH + 1);                                    // down: what the batch counted
+        constexpr size_t cnt_bytes = (BATCH + 1) * sizeof(uint32_t);
+        std::memset(h_cnt, 0, cnt_bytes);
         h_cnt[0] = na;
         uint32_t *fr[2] = {f0.as<uint32_t>(), f1.as<uint32_t>()};
         // every level of a batch runs the same grid: one wave per frontier node, strided
         const unsigned bfs_grid = grid_for(std::min<uint64_t>((uint64_t) N * 64, 1u << 20));
         for (bool done = false; !done;) {
-            TLM_HIP(hipMemcpyAsync(cnt.p, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));     // {frontier size, 0, ..., 0}
+            TLM_HIP(hipMemcpyAsync(cnt.p, h_cnt, cnt_bytes, hipMemcpyHostToDevice, s));     // {frontier size, 0, ..., 0}
             for (uint32_t j = 0; j < BATCH; j++) {
                 hipLaunchKernelGGL(bfs_expand_kernel, dim3(bfs_grid), dim3(256), 0, s, cnt.as<uint32_t>() + j,
                                    fr[(level + j) & 1u], level + j, g->row_ptr, g->ent_es, key.as<unsigned long long>(),
                                    fr[(level + j + 1) & 1u]);
             }
-            TLM_HIP(hipMemcpyAsync(h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(h_got, cnt.p, cnt_bytes, hipMemcpyDeviceToHost, s));
             if (int rc = ph.sync()) return rc;
             uint32_t j = 1;
-            while (j <= BATCH && h_cnt[j] != 0) j++;        // level + j - 1 = the last level with a frontier
+            while (j <= BATCH && h_got[j] != 0) j++;        // level + j - 1 = the last level with a frontier
             done = j <= BATCH;
             level += done ? j : BATCH;
             TLM_CHECK(level <= N + BATCH, TLM_EINTERNAL, "BFS did not terminate");
-            const uint32_t carry = h_cnt[BATCH];
-            std::memset(h_cnt, 0, sizeof(h_cnt));
+            const uint32_t carry = h_got[BATCH];
+            std::memset(h_cnt, 0, cnt_bytes);
             h_cnt[0] = carry;
         }
         g->info.bfs_levels = level;
@@ -696,9 +713,9 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
             if (int rc = dev_alloc(tmp, tb)) return rc;
             TLM_HIP(rocprim::exclusive_scan(tmp.p, tb, pd.as<uint32_t>(), ws.as<uint32_t>(), WALK_ROW0, (size_t) N,
                                             rocprim::plus<uint32_t>(), s));
-            uint32_t last_start = 0, last_pd = 0;
-            TLM_HIP(hipMemcpyAsync(&last_start, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-            TLM_HIP(hipMemcpyAsync(&last_pd, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            uint32_t *const h_last = (uint32_t *) ((char *) ctx->pinned_small + 64);
+            TLM_HIP(hipMemcpyAsync(h_last, ws.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipMemcpyAsync(h_last + 1, pd.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
             // the DET unit table (reference layout) rides on the same round trip
             if (na) {
                 if (int rc = dev_alloc(det_cnt, na * sizeof(uint64_t))) return rc;
@@ -707,7 +724,7 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
                 TLM_HIP(hipMemcpyAsync(h_det_cnt.data(), det_cnt.p, na * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             }
             if (int rc = ph.sync()) return rc;
-            apad = (uint64_t) last_start + last_pd;
+            apad = (uint64_t) h_last[0] + h_last[1];
         }
         g->n_adj_pad = apad;
         for (uint32_t a = 0; a < na; a++) g->h_det_off[a + 1] = g->h_det_off[a] + h_det_cnt[a];
@@ -851,8 +868,9 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
                                 r_es.as<float>() + b, nk.as<unsigned long long>() + i);
     }
     ph.mark(PH_FILTER);
-    unsigned long long h_nk[MAX_FILES] = {0, 0, 0, 0};
-    TLM_HIP(hipMemcpyAsync(h_nk, nk.p, sizeof(h_nk), hipMemcpyDeviceToHost, s));
+    // (read-backs of the build land in the context's pinned words: [0, 64) bytes counts, [64, 128) sizes, [128, ..) BFS)
+    unsigned long long *const h_nk = (unsigned long long *) ctx->pinned_small;
+    TLM_HIP(hipMemcpyAsync(h_nk, nk.p, MAX_FILES * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     // 2. rank of each kept record (queued before the host waits for the counts)
     {
         auto in = rocprim::make_transform_iterator(keep.as<uint8_t>(), KeepToU32());
@@ -901,8 +919,10 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         // N = number of names that occur in a kept record
         uint32_t *n_dev = (uint32_t *) (nk.as<unsigned long long>() + MAX_FILES);
         hipLaunchKernelGGL(count_seen_kernel, dim3(1), dim3(1), 0, s, n_names, sorted_pos.as<uint32_t>(), n_dev);
-        TLM_HIP(hipMemcpyAsync(&N, n_dev, 4, hipMemcpyDeviceToHost, s));
+        uint32_t *const h_n = (uint32_t *) ((char *) ctx->pinned_small + 64);
+        TLM_HIP(hipMemcpyAsync(h_n, n_dev, 4, hipMemcpyDeviceToHost, s));
         if (int rc = ph.sync()) return rc;
+        N = *h_n;
     }
     g->n_nodes = N;
     if (int rc = dev_alloc_keep(&g->node_len, N)) return rc;

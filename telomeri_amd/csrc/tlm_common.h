@@ -40,12 +40,16 @@ struct tlm_ctx {
     int waves_per_cu = 0;          // 0 = default
     uint32_t path_capacity = 0;    // 0 = default
     uint64_t arena_limit = 0;      // bytes; 0 = default (tlm_ctx_set_arena_limit)
+    bool walk_accounting = false;  // tlm_ctx_set_walk_accounting: launch the builds of the walk kernels that count layout bytes
     std::vector<hipEvent_t> phase_ev;   // graph-build phase marks, created on first use
     void *comm = nullptr;          // ncclComm_t (exchange.hip); rank / world of the one-process-per-GPU job
     int rank = 0, world = 1;
     void *xchg_scratch = nullptr;  // device, TLM_XCHG_SCRATCH_BYTES: status words and block sizes of the exchange calls; owned
                                    // since tlm_dist_init so that telling the peers "I failed" never needs an allocation
     bool comm_broken = false;      // the communicator was aborted after a failure inside a collective sequence
+    // pinned host memory for the few words the graph build reads back between its phases (counts, sizes): a device-to-host
+    // copy into pageable memory goes through the runtime's staging path and may block the queueing thread
+    void *pinned_small = nullptr;
     void *upload_window = nullptr; // device memory shared with an upload helper process (tlm_upload_window_create)
     void *peer_window = nullptr;   // ... and, in the helper, the other process's window (tlm_upload_window_open)
     // host-side tidying that may wait (unpinning and unmapping 15 GB of uploaded text takes 0.65 s and blocks every
@@ -56,6 +60,7 @@ struct tlm_ctx {
     std::vector<std::thread> deferred_running;
 };
 #define TLM_XCHG_SCRATCH_BYTES 16384
+#define TLM_PINNED_SMALL_BYTES 4096
 void tlm_ctx_defer(tlm_ctx *ctx, std::function<void()> fn);
 void tlm_ctx_start_deferred(tlm_ctx *ctx);      // run what has been deferred so far, in background threads
 void tlm_ctx_join_deferred(tlm_ctx *ctx);       // start the rest and wait for all of it

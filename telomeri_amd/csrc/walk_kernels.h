@@ -61,7 +61,9 @@ struct WalkArgs {
     uint32_t cap;
     uint32_t *bitmaps;
     uint32_t bm_words;              // 32-bit words per wave: the N-bit visited map, then WALK_RNG_WORDS of generator state
-    // arena cursor (u64) at cursor[2..3]; one work cursor per XCD at cursor[WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * x]
+    // arena cursor (u64) at cursor[2..3]; launch span at [6..9]; ACCOUNT builds: layout bytes (u64) at [10..11] and ten
+    // u64 step-class counters at [12..31]; one work
+    // cursor per XCD at cursor[WALK_QUEUE_BASE + WALK_QUEUE_STRIDE * x]
     uint32_t *cursor;
     UnitOut *units;
     uint2 *arena;                   // accepted paths: {reference node, edge slot}
@@ -84,7 +86,8 @@ constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
 
 // resident workgroups per CU of the kernel (occupancy query): the persistent grid is sized from it
 int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric);
-void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a);
-void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a);
+// account: the build of the kernel that also sums the layout bytes its steps ask for into cursor[10..11] (tlm_counters.layout_bytes)
+void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account);
+void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account);
 
 #endif

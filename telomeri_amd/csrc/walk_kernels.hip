@@ -926,9 +926,31 @@ __device__ __forceinline__ void ring_sync(PathRing &pr, const WaveScratch &ws, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool SQRT>
+// ACCOUNT builds of the walk kernels (never the timed ones; bench.py runs one launch of them beside the timed steps) add up
+// the bytes a step's loads ASK the layout for: the list as it is read -- ceil(deg / K) * K entries of 6 bytes (compact row)
+// or 8, K = the entries a lane owns for this list length; a chunked long list: all of it once plus one chunk of 512 again
+// -- plus the 8-byte row record and the 8-byte {q_start, t_start} of the chosen edge.  Summed per launch in cursor[10..11].
+__device__ __forceinline__ uint32_t step_layout_bytes(uint32_t deg, bool compact) {
+    if (deg > 768u || (!compact && deg > 512u)) return ((deg + 7u) & ~7u) * 8u + 512u * 8u + 16u;
+    const uint32_t k = deg <= 256u ? 4u : deg <= 384u ? 6u : deg <= 512u ? 8u : 12u;
+    return ((deg + k - 1u) / k) * k * (compact ? 6u : 8u) + 16u;
+}
+
+// ... and which form of the selection every step took (ACCOUNT builds; cursor[12..31] = 10 u64 counters):
+// 0-3 compact row with 4 / 6 / 8 / 12 entries per lane, 4-6 8-byte row with 4 / 6 / 8, 7 8-byte row with 12 (deterministic
+// kernel only), 8 chunked long list, 9 serial (order-unsafe row)
+constexpr int STEP_CLASSES = 10;
+__device__ __forceinline__ int step_class(uint32_t deg, bool compact, bool safe, bool is_det) {
+    if (!safe) return 9;
+    if (deg > 768u || (!compact && !is_det && deg > 512u)) return 8;
+    const int k = deg <= 256u ? 0 : deg <= 384u ? 1 : deg <= 512u ? 2 : 3;
+    return (compact ? 0 : 4) + k;
+}
+
+template <bool SQRT, bool ACCOUNT>
 __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after,
-                        uint32_t *ring, int lane, uint32_t ui, uint32_t start, uint32_t seed, int64_t len0) {
+                        uint32_t *ring, int lane, uint32_t ui, uint32_t start, uint32_t seed, int64_t len0,
+                        uint32_t *acct) {
     // `start` and every node id below are walk-order indices
     Rng rng{mt, ws.rng, 0};
     mt_seed((lds_u32 *) mt, (glb_u32 *) ws.rng, lane, seed);
@@ -947,6 +969,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     int backtracks = 0;
     uint32_t steps = 0, draws = 0;
     uint64_t evals = 0;
+    uint64_t lbytes = 0;     // ACCOUNT only
     bool acceptable = false;
     uint8_t status = ST_ABANDONED;
     if (lane == 0) {
@@ -997,6 +1020,10 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                                           : select_long<SQRT>(a, vs, rng, after, lane, row, deg, start, anchor_nbr, draws);
         evals += s.evals;
         steps++;
+        if (ACCOUNT) {
+            lbytes += step_layout_bytes(deg, compact);
+            if (lane == 0) atomicAdd(acct + step_class(deg, compact, safe, false), 1u);
+        }
         clk.mark(CLK_SELECT, false);
 #ifdef TLM_TIMING
         clk.steps++;
@@ -1095,6 +1122,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     // acc holds the increments of edges 0..m-2 (the last pushed edge is still pending): exactly Path::length()
     const int64_t len_final = len0 + acc;
     if (acceptable && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :146-155
+    if (ACCOUNT && lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(cold_args()->cursor + 10), (unsigned long long) lbytes);
     finish_unit(ws, lane, ui, status, m, nlog, len_final, steps, evals, draws);
 }
 
@@ -1447,9 +1475,9 @@ __device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
     else vs.bm[n >> 5] &= ~(1u << (n & 31));
 }
 
-template <bool SQRT>
+template <bool SQRT, bool ACCOUNT>
 __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, uint32_t *ring, int lane, uint32_t ui,
-                         uint32_t start, uint32_t start_ref, uint32_t first_slot) {
+                         uint32_t start, uint32_t start_ref, uint32_t first_slot, uint32_t *acct) {
     Visited vs;
     vs.win = win;
     vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
@@ -1464,6 +1492,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     PathRing pr{ring, 1u, 0u};          // edge 0 and nodes 0, 1 are written directly below
     uint32_t steps = 0;
     uint64_t evals = 0;
+    uint64_t lbytes = 0;     // ACCOUNT only
     uint8_t status = ST_ABANDONED;
     wave_sync();
     if (lane == 0) {
@@ -1510,6 +1539,11 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 evals += deg;
                 steps++;
                 const bool compact = ((rfl(rec.y) >> 29) & 1u) != 0;
+                if (ACCOUNT) {
+                    // (no {q_start, t_start} inside the loop; lists of 513..768 entries are read once here even as 8-byte rows)
+                    lbytes += (!compact && deg > 512u && deg <= 768u ? ((deg + 11u) / 12u) * 96u + 16u : step_layout_bytes(deg, compact)) - 8u;
+                    if (lane == 0) atomicAdd(acct + step_class(deg, compact, true, true), 1u);
+                }
                 pk = compact && deg <= 768u
                          ? (deg <= 256u   ? det_select_regs<4, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
                             : deg <= 384u ? det_select_regs<6, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
@@ -1573,6 +1607,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
     const int64_t len_final = len0 + (int64_t) __shfl(part, 0);
     if (all_ok && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :372-384
+    if (ACCOUNT && lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.cursor + 10), (unsigned long long) lbytes);
     finish_unit(ws, lane, ui, status, m, nlog, len_final, steps, evals, 0);
 }
 
@@ -1651,15 +1686,20 @@ __device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, ui
     return b;
 }
 
-template <bool SQRT>
+template <bool SQRT, bool ACCOUNT = false>
 __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
     __shared__ double after_s[WALK_WAVES_PER_BLOCK][AFTER_SLOTS];
     __shared__ uint32_t ring_s[WALK_WAVES_PER_BLOCK][2 * PATH_RING];
+    __shared__ uint32_t acct_s[ACCOUNT ? WALK_WAVES_PER_BLOCK : 1][STEP_CLASSES];      // ACCOUNT builds only
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
+    if (ACCOUNT) {
+        if (lane < STEP_CLASSES) acct_s[wib][lane] = 0u;
+        wave_sync();
+    }
     if (threadIdx.x == 0) {      // "all workgroups are resident" for a host that wants to queue another launch behind this one
         ColdArgs *ca = cold_args();
         uint32_t *flag = ca->resident_flag;
@@ -1694,8 +1734,13 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
         h.backtrack_attempts = a.backtrack_attempts;
         h.len_threshold = a.len_threshold;
         const int64_t len0 = (int64_t) rfl(ca->node_len[start_ref]);
-        mc_walk<SQRT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], ring_s[wib], lane, cu, start,
-                      walk_seed_dev(metric, start_ref, r), len0);
+        mc_walk<SQRT, ACCOUNT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], ring_s[wib], lane, cu, start,
+                      walk_seed_dev(metric, start_ref, r), len0, ACCOUNT ? acct_s[wib] : nullptr);
+    }
+    if (ACCOUNT) {
+        wave_sync();
+        if (lane < STEP_CLASSES)
+            atomicAdd(reinterpret_cast<unsigned long long *>(cold_args()->cursor + 12) + lane, (unsigned long long) acct_s[wib][lane]);
     }
 }
 
@@ -1703,13 +1748,18 @@ __global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
 #ifndef TLM_DET_WAVES
 #define TLM_DET_WAVES 6
 #endif
-template <bool SQRT>
+template <bool SQRT, bool ACCOUNT = false>
 __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t ring_s[WALK_WAVES_PER_BLOCK][2 * PATH_RING];
+    __shared__ uint32_t acct_s[ACCOUNT ? WALK_WAVES_PER_BLOCK : 1][STEP_CLASSES];      // ACCOUNT builds only
     const int lane = threadIdx.x & 63;
     const int wib = (int) rfl(threadIdx.x >> 6);      // wave-uniform: keeps the per-wave pointers in SGPRs
     const WaveScratch ws = wave_scratch(a, blockIdx.x * WALK_WAVES_PER_BLOCK + wib);
+    if (ACCOUNT) {
+        if (lane < STEP_CLASSES) acct_s[wib][lane] = 0u;
+        wave_sync();
+    }
     stamp_span(a.cursor, false);
     uint32_t cu;
     QueueState q = queue_init();
@@ -1723,8 +1773,13 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(Wal
             if (a.det_off[mid] <= unit) lo = mid;
             else hi = mid;
         }
-        det_walk<SQRT>(b, ws, win_s[wib], ring_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
-                       (uint32_t) (unit - a.det_off[lo]));
+        det_walk<SQRT, ACCOUNT>(b, ws, win_s[wib], ring_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
+                       (uint32_t) (unit - a.det_off[lo]), ACCOUNT ? acct_s[wib] : nullptr);
+    }
+    if (ACCOUNT) {
+        wave_sync();
+        if (lane < STEP_CLASSES)
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.cursor + 12) + lane, (unsigned long long) acct_s[wib][lane]);
     }
     __syncthreads();
     stamp_span(a.cursor, true);
@@ -1743,7 +1798,12 @@ int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric) {
     return n;
 }
 
-void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a) {
+void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+    if (account) {      // same walks, plus the layout-byte count (never the timed launch)
+        if (sqrt_metric) hipLaunchKernelGGL((walk_mc_kernel<true, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((walk_mc_kernel<false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+        return;
+    }
 #ifdef TLM_TIMING
     {
         unsigned long long z[8] = {0};
@@ -1768,7 +1828,12 @@ void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const 
 #endif
 }
 
-void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a) {
+void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+    if (account) {
+        if (sqrt_metric) hipLaunchKernelGGL((walk_det_kernel<true, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((walk_det_kernel<false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+        return;
+    }
     if (sqrt_metric) hipLaunchKernelGGL(walk_det_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(walk_det_kernel<false>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
 }

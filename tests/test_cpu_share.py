@@ -50,3 +50,13 @@ def test_cpu_share_follows_affinity_and_quota(tmp_path):
     one = sorted(os.sched_getaffinity(0))[:1]
     got1 = int(subprocess.run(["taskset", "-c", str(one[0]), str(exe)], check=True, capture_output=True, text=True).stdout)
     assert got1 == 1
+
+
+def test_python_cpu_share_follows_the_same_rule(monkeypatch):
+    from telomeri_amd import cpu_share
+    for var in ("LOCAL_WORLD_SIZE", "TLM_WORLD"):
+        monkeypatch.delenv(var, raising=False)
+    assert cpu_share.cpu_share() == expected_share()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert cpu_share.cpu_share() == max(1, expected_share() // 2)
+    assert isinstance(cpu_share.throttle_counters(), dict)

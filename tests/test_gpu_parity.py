@@ -742,3 +742,28 @@ def test_no_cpu_fallback_symbols():
     assert "oracle" not in out
     nm = subprocess.run(["nm", "-D", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "tlo_" not in nm
+
+
+def test_walk_accounting_counts_layout_bytes_and_changes_nothing(ctx):
+    """tlm_ctx_set_walk_accounting: the accounting builds of the walk kernels return the same Path sets and per-unit records
+    and report the bytes their steps asked the layout for: per step a list of ceil(deg / K) * K entries of 6 or 8 bytes, a
+    row record and (Monte-Carlo) a {q_start, t_start} pair."""
+    c2 = capi.Context(0)
+    dg = H.device_graph(c2, synth.make_config("dense"), capi.FilterParams.default())
+    wp = capi.WalkParams.default(rb_att=20)
+    plain = list(dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp)) + list(dg.walk_det2(capi.METRIC_ES, capi.METRIC_OS))
+    assert all(p.counters.layout_bytes == 0 for p in plain)
+    c2.set_walk_accounting(True)
+    counted = list(dg.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp)) + list(dg.walk_det2(capi.METRIC_ES, capi.METRIC_OS))
+    c2.set_walk_accounting(False)
+    for a, b in zip(plain, counted):
+        H.assert_paths_equal(a.to_host(), b.to_host())
+        H.assert_stats_equal(a.unit_stats(), b.unit_stats())
+    for k, extra in ((0, 16), (2, 8)):            # the launch's bytes are booked on the first set of a two-metric call
+        evals = counted[k].counters.evals + counted[k + 1].counters.evals
+        steps = counted[k].counters.steps + counted[k + 1].counters.steps
+        lb = counted[k].counters.layout_bytes
+        assert counted[k + 1].counters.layout_bytes == 0
+        # MC evals stop at a forcing anchor edge, the list is read whole: evals <= entries read <= evals' lists padded by < 12
+        assert lb >= 6 * evals + extra * steps
+        assert lb <= 8 * (evals + 12 * steps) + extra * steps + 8 * 600 * steps
