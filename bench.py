@@ -403,7 +403,7 @@ def main() -> None:
         out["cpu_baseline"] = cpu_baseline(args, g, wp, g.download(cold=False), mc_range, capi)
     if world == 1 and not args.no_scaffold:
         # the metric's second half: PAF + FASTA TEXT in -> scaffold FASTA out through the C++ host program, on the same
-        # config, reference argv and defaults (profiles/probes/scaffold_bench.py; outside the timed region above)
+        # config, reference argv and defaults (telomeri_amd/scaffold_bench.py; outside the timed region above)
         # nothing of this process stays on the device while the program runs
         del g
         import gc
@@ -414,10 +414,7 @@ def main() -> None:
         out["device_memory_kept_during_scaffold_leg"] = {"library_live_bytes": int(mi.live_bytes), "library_cached_bytes": int(mi.cached_bytes),
                                                          "torch_reserved_bytes": int(torch.cuda.memory_reserved())}
         try:
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("scaffold_bench", os.path.join(ROOT, "profiles", "probes", "scaffold_bench.py"))
-            sb = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(sb)
+            from telomeri_amd import scaffold_bench as sb
             cfg = args.scaffold_config or args.config
             sc = sb.run(cfg, device=str(dev))
             out["scaffold_wall_s"] = sc.get("scaffold_wall_s")

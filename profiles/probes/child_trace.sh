@@ -3,7 +3,7 @@
 O=$GRAFT_REPO_ROOT/gpurun_out/r02_bimodal; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for i in $(seq 1 $1); do
   rm -rf $O/prof_$i
-  TLM_SCAFFOLD_ROCPROF=$O/prof_$i timeout -k 10 300 python3 $GRAFT_REPO_ROOT/profiles/probes/scaffold_bench.py athaliana > $O/s_$i.json 2> $O/s_$i.err
+  TLM_SCAFFOLD_ROCPROF=$O/prof_$i timeout -k 10 300 python3 $GRAFT_REPO_ROOT/telomeri_amd/scaffold_bench.py athaliana > $O/s_$i.json 2> $O/s_$i.err
   python3 - <<PY
 import json, glob, csv
 d=json.load(open("$O/s_$i.json")); print("run $i", d["scaffold_wall_s"], d.get("walk_kernel_ms"), flush=True)

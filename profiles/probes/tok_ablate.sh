@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_tokabl; mkdir -p $O
 D=$(python3 - <<PY
 import sys, json
 sys.path.insert(0, "$R/profiles/probes"); sys.path.insert(0, "$R")
-import scaffold_bench as sb
+from telomeri_amd import scaffold_bench as sb
 out = sb.run("athaliana", keep=True, extra_args=["--no-scaffold", "--rb-att", "1"])
 print(out["dir"])
 PY

@@ -474,7 +474,7 @@ int ensure_arena(Workspace &w, hipStream_t stream, uint64_t need, uint64_t keep)
 // stream, or when the call gives up earlier; `wait_for` (optional) is waited for before that first kernel is launched.
 int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const int *metrics, const tlm_walk_params *p,
               uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr, int lane = 0,
-              std::atomic<int> *launched = nullptr, std::atomic<int> *wait_for = nullptr) {
+              std::atomic<int> *launched = nullptr, std::atomic<int> *wait_for = nullptr, bool wait_resident = true) {
     struct Signal {         // whoever waits for this call's launch is let go when the call ends, whatever happened
         std::atomic<int> *f;
         std::atomic<int> *gate;
@@ -641,7 +641,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 // that, this launch's workgroups start where Monte-Carlo workgroups retire: in the tail.
                 while (!wait_for->load()) std::this_thread::yield();
                 wait_for = nullptr;
-                if (c->resident_host) {
+                if (c->resident_host && wait_resident) {
                     const auto t0 = std::chrono::steady_clock::now();
                     while (*(volatile uint32_t *) c->resident_host == 0 && !c->gate_released.load()
                            && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5))
@@ -649,7 +649,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 }
             }
             a.resident_flag = nullptr;
-            if (launched && round == 0 && c->resident_host) {      // someone waits for this launch to be resident
+            if (launched && round == 0 && c->resident_host && is_mc) {      // someone waits for this launch to be resident
                 *(volatile uint32_t *) c->resident_host = 0;
                 a.resident_flag = c->resident_dev;
             }
@@ -817,14 +817,21 @@ extern "C" int tlm_walk_builders(tlm_ctx *ctx, const tlm_graph *g, int metric_a,
     tlm_counters cd[2], cm[2];
     std::memset(cd, 0, sizeof(cd));
     std::memset(cm, 0, sizeof(cm));
-    std::atomic<int> mc_launched{0};
+    std::atomic<int> mc_launched{0}, det_launched{0};
     int rc_det = TLM_OK;
     char det_err[512] = "";
+    // Which launch goes first.  "tail" (default): Monte-Carlo first, the deterministic launch once every Monte-Carlo
+    // workgroup is resident -- its workgroups start in the Monte-Carlo launch's tail.  "det_first": the deterministic launch
+    // first -- most of its units are short and its waves leave within milliseconds, the few long walks (no length cap:
+    // they bound the launch) then run BESIDE the Monte-Carlo launch instead of after it.
+    static const bool det_first = [] { const char *e = std::getenv("TLM_BUILDERS_ORDER"); return e && !std::strcmp(e, "det_first"); }();
     std::thread side([&] {
-        rc_det = run_walks(ctx, g, false, 2, m, nullptr, det_begin, det_end, out4 + 2, cd, 1, nullptr, &mc_launched);
+        rc_det = det_first ? run_walks(ctx, g, false, 2, m, nullptr, det_begin, det_end, out4 + 2, cd, 1, &det_launched, nullptr)
+                           : run_walks(ctx, g, false, 2, m, nullptr, det_begin, det_end, out4 + 2, cd, 1, nullptr, &mc_launched);
         if (rc_det != TLM_OK) std::snprintf(det_err, sizeof(det_err), "%s", tlm_last_error());
     });
-    const int rc_mc = run_walks(ctx, g, true, 2, m, p, mc_begin, mc_end, out4, cm, 0, &mc_launched);
+    const int rc_mc = det_first ? run_walks(ctx, g, true, 2, m, p, mc_begin, mc_end, out4, cm, 0, nullptr, &det_launched, false)
+                                : run_walks(ctx, g, true, 2, m, p, mc_begin, mc_end, out4, cm, 0, &mc_launched);
     side.join();
     if (rc_mc != TLM_OK || rc_det != TLM_OK) {
         if (rc_mc == TLM_OK) tlm_set_error("%s", det_err);

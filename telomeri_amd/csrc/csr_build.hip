@@ -24,6 +24,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 namespace {
@@ -607,17 +609,33 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
     }
     uint32_t *const h_cnts = (uint32_t *) ctx->pinned_small;
     TLM_HIP(hipMemcpyAsync(h_cnts, cnts.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    std::vector<uint8_t> h_anchor(N);
-    if (N) TLM_HIP(hipMemcpyAsync(h_anchor.data(), g->node_anchor, N, hipMemcpyDeviceToHost, s));
+    // the anchors, ascending: a stable select over 0..N-1 by the anchor flags, on the device (the host used to fetch all N
+    // flags into pageable memory -- a blocking copy in the middle of the build -- and pick them out itself)
+    DevBuf sel, n_sel;
+    if (int rc = dev_alloc(sel, ((size_t) N + 1) * 4)) return rc;
+    if (int rc = dev_alloc(n_sel, 8)) return rc;
+    TLM_HIP(hipMemsetAsync(n_sel.p, 0, 8, s));
+    if (N) {
+        size_t tb = 0;
+        TLM_HIP(rocprim::select(nullptr, tb, rocprim::counting_iterator<uint32_t>(0), g->node_anchor, sel.as<uint32_t>(),
+                                n_sel.as<uint32_t>(), (size_t) N, s));
+        DevBuf tmp;
+        if (int rc = dev_alloc(tmp, tb)) return rc;
+        TLM_HIP(rocprim::select(tmp.p, tb, rocprim::counting_iterator<uint32_t>(0), g->node_anchor, sel.as<uint32_t>(),
+                                n_sel.as<uint32_t>(), (size_t) N, s));
+    }
+    TLM_HIP(hipMemcpyAsync(h_cnts + 8, n_sel.p, 4, hipMemcpyDeviceToHost, s));
     ph.mark(PH_FLAGS);
     if (int rc = ph.sync()) return rc;
     for (int m = 0; m < 4; m++) g->info.unsafe_nodes[m] = h_cnts[m];
     g->info.max_degree = h_cnts[4];
     TLM_CHECK(h_cnts[4] < (1u << 24), TLM_ELIMIT, "a node of degree %u exceeds the 2^24 layout limit", h_cnts[4]);
-    g->h_anchors.clear();
-    for (uint32_t i = 0; i < N; i++)
-        if (h_anchor[i]) g->h_anchors.push_back(i);
-    const uint32_t na = (uint32_t) g->h_anchors.size();
+    const uint32_t na = h_cnts[8];
+    g->h_anchors.assign(na, 0);
+    if (na) {       // (a few hundred words; the walk calls need them on the host for their unit arithmetic)
+        TLM_HIP(hipMemcpyAsync(g->h_anchors.data(), sel.p, (size_t) na * 4, hipMemcpyDeviceToHost, s));
+        if (int rc = ph.sync()) return rc;
+    }
     g->info.n_anchors = na;
     g->info.n_nodes = N;
     g->info.n_adj = g->n_adj;
@@ -625,7 +643,7 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
     if (int rc = tlm_pool_alloc((void **) &g->w_anchors, (na ? na : 1) * sizeof(uint32_t), s)) return rc;
     if (int rc = tlm_pool_alloc((void **) &g->det_off, ((size_t) na + 1) * sizeof(uint64_t), s)) return rc;
     g->h_det_off.assign((size_t) na + 1, 0);
-    if (na) TLM_HIP(hipMemcpyAsync(g->anchors, g->h_anchors.data(), na * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (na) TLM_HIP(hipMemcpyAsync(g->anchors, sel.p, na * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 
     // ---- walk order: (nearest anchor, BFS level, reference index); identity if TLM_NO_LOCALIZE is set
     if (int rc = tlm_pool_alloc((void **) &g->w_old_of_new, ((size_t) N + 1) * 4, s)) return rc;

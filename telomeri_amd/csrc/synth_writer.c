@@ -1,4 +1,4 @@
-/* profiles/probes/synth_writer.c -- BENCH INFRASTRUCTURE (not part of the product, never loaded by it).
+/* telomeri_amd/csrc/synth_writer.c -- BENCH INFRASTRUCTURE (not part of the product, never loaded by it).
  *
  * Renders a synthetic dataset (telomeri_amd.synth: integer columns) as the text files the host program reads: 16-column
  * PAF (the 12 columns the reference parses + 4 it discards, OverlapGraph.cpp:109-127) and two-line FASTA records

@@ -1686,8 +1686,12 @@ __device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, ui
     return b;
 }
 
+// waves per SIMD the Monte-Carlo kernel is compiled for (8 = the architecture's maximum: 64 vector / 78 scalar registers)
+#ifndef TLM_MC_WAVES
+#define TLM_MC_WAVES 8
+#endif
 template <bool SQRT, bool ACCOUNT = false>
-__global__ __launch_bounds__(WALK_BLOCK, 8) void walk_mc_kernel(WalkArgs a) {
+__global__ __launch_bounds__(WALK_BLOCK, TLM_MC_WAVES) void walk_mc_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
     __shared__ double after_s[WALK_WAVES_PER_BLOCK][AFTER_SLOTS];

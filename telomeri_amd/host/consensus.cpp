@@ -224,76 +224,113 @@ std::pair<ulong, ulong> PathManager::getMinMaxPathLength(std::vector<const Path 
 }
 
 // ---- the per-pair stage of main() (src/Main.cpp:254-342) ----------------------------------------------
-long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>> &paths_between_anchors,
-                                  std::map<AnchorPair, std::vector<PathGroup>> &groups_for_anchors,
-                                  std::map<AnchorPair, const Path *> &consensus_for_anchors, const Parameters &params) {
-    for (auto &pbai : paths_between_anchors) {
-        const OverlapGraph::Node &a1 = *pbai.first.first, &a2 = *pbai.first.second;
-        std::cout << "====> Constructing groups for paths between anchor '" << a1.name << "' and anchor '" << a2.name
-                  << "'..." << std::endl;
-        groups_for_anchors[{&a1, &a2}] = constructGroups(pbai.second, params);      // sorts pbai.second in place
-        std::cout << "<==== Finished constructing groups for paths between anchor '" << a1.name << "' and anchor '"
-                  << a2.name << "'!\n" << std::endl;
-    }
-    long consensus_num = 0;
-    const auto t_groups = std::chrono::steady_clock::now();
-    double discard_ms = 0, cons_ms = 0, valid_ms = 0;
-    auto lap = [](std::chrono::steady_clock::time_point &t) {
+// Written from its behaviour, in two parts.
+//   (1) per group: drop the infrequent lengths, pick the group's consensus, count the paths of its length; a group
+//       without consensus only leaves its log line.
+//   (2) among the groups of one anchor pair that have a consensus: none -> no consensus for the pair; one -> it; otherwise
+//       rank them by consensus length, longest first (std::sort: the order among equal lengths is whatever libstdc++'s
+//       introsort makes of the input order, and the scaffold depends on it -- so the SAME sort runs here, over indices);
+//       two groups -> the longer one; more -> walk down the ranking holding a champion, which is replaced whenever the next
+//       group has at least twice the champion's number of valid paths.
+namespace {
+
+struct GroupResult {            // what part (2) needs of a group that has a consensus
+    const Path *consensus;
+    long length;
+    int valid_paths;            // (int as in PathGroup: the comparison below is the reference's int arithmetic)
+};
+
+struct StageClock {             // TLM_HOST_TIMING: where the stage's time goes
+    double discard_ms = 0, consensus_ms = 0, valid_ms = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { t = std::chrono::steady_clock::now(); }
+    double lap() {
         const auto n = std::chrono::steady_clock::now();
         const double ms = std::chrono::duration<double, std::milli>(n - t).count();
         t = n;
         return ms;
-    };
-    for (auto &agp : groups_for_anchors) {
-        const OverlapGraph::Node &a1 = *agp.first.first, &a2 = *agp.first.second;
-        std::cout << "====> Finding consensus path in each group between anchor '" << a1.name << "' and anchor '" << a2.name
-                  << "'..." << std::endl;
-        std::vector<PathGroup *> pgswc;
-        for (PathGroup &pg : agp.second) {
-            auto t = std::chrono::steady_clock::now();
-            pg.discardNotFrequent();
-            discard_ms += lap(t);
-            pg.calculateConsensusPath();
-            cons_ms += lap(t);
-            pg.calculateValidPathNumber();
-            valid_ms += lap(t);
-            if (pg.consensus) {
-                std::cout << "Consensus length: " << pg.consensus->length() << "    "
-                          << "Valid path number: " << pg.valid_path_number << std::endl;
-                pgswc.push_back(&pg);
-            } else {
-                std::cout << "No consensus sequence for group!\n" << std::endl;
-            }
+    }
+};
+
+bool settle_group(PathGroup &pg, StageClock &clk, GroupResult &out) {
+    clk.start();
+    pg.discardNotFrequent();
+    clk.discard_ms += clk.lap();
+    pg.calculateConsensusPath();
+    clk.consensus_ms += clk.lap();
+    pg.calculateValidPathNumber();
+    clk.valid_ms += clk.lap();
+    if (!pg.consensus) {
+        std::cout << "No consensus sequence for group!\n" << std::endl;
+        return false;
+    }
+    out = GroupResult{pg.consensus, pg.consensus->length(), pg.valid_path_number};
+    std::cout << "Consensus length: " << out.length << "    " << "Valid path number: " << out.valid_paths << std::endl;
+    return true;
+}
+
+const Path *consensus_among(const std::vector<GroupResult> &with_consensus) {
+    const size_t n = with_consensus.size();
+    if (n == 0) return nullptr;
+    std::vector<size_t> ranking(n);
+    for (size_t i = 0; i < n; i++) ranking[i] = i;
+    if (n >= 2)
+        std::sort(ranking.begin(), ranking.end(),
+                  [&](size_t x, size_t y) { return with_consensus[x].length > with_consensus[y].length; });
+    size_t champion = ranking[0];
+    if (n > 2)
+        for (size_t r = 1; r < n; r++) {
+            const size_t challenger = ranking[r];
+            if (with_consensus[challenger].valid_paths >= 2 * with_consensus[champion].valid_paths) champion = challenger;
+        }
+    return with_consensus[champion].consensus;
+}
+
+void announce(const char *opening, const OverlapGraph::Node &from, const OverlapGraph::Node &to, const char *closing) {
+    std::cout << opening << from.name << "' and anchor '" << to.name << closing << std::endl;
+}
+
+}   // namespace
+
+long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>> &paths_between_anchors,
+                                  std::map<AnchorPair, std::vector<PathGroup>> &groups_for_anchors,
+                                  std::map<AnchorPair, const Path *> &consensus_for_anchors, const Parameters &params) {
+    // every pair's groups first (the reference reports them all before it looks for any consensus)
+    for (auto &entry : paths_between_anchors) {
+        const AnchorPair &pair = entry.first;
+        announce("====> Constructing groups for paths between anchor '", *pair.first, *pair.second, "'...");
+        groups_for_anchors[pair] = constructGroups(entry.second, params);       // sorts the pair's paths in place
+        announce("<==== Finished constructing groups for paths between anchor '", *pair.first, *pair.second, "'!\n");
+    }
+    const auto t_groups = std::chrono::steady_clock::now();
+    StageClock clk;
+    long pairs_with_consensus = 0;
+    std::vector<GroupResult> settled;
+    for (auto &entry : groups_for_anchors) {
+        const AnchorPair &pair = entry.first;
+        announce("====> Finding consensus path in each group between anchor '", *pair.first, *pair.second, "'...");
+        settled.clear();
+        for (PathGroup &pg : entry.second) {
+            GroupResult r;
+            if (settle_group(pg, clk, r)) settled.push_back(r);
         }
         std::cout << "Done finding consensus path in each group.\n";
-        const Path *chosen = nullptr;
-        if (pgswc.size() == 1) {
-            chosen = pgswc[0]->consensus;
-        } else if (pgswc.size() >= 2) {
-            std::sort(pgswc.begin(), pgswc.end(), [](const PathGroup *p1, const PathGroup *p2) {
-                return p1->consensus->length() > p2->consensus->length();
-            });
-            const PathGroup *longer = pgswc[0];
-            if (pgswc.size() > 2) {                     // Main.cpp:319-330: consecutive comparisons
-                for (size_t i = 1; i < pgswc.size(); i++) {
-                    const PathGroup *shorter = pgswc[i];
-                    if (2 * longer->valid_path_number <= shorter->valid_path_number) longer = shorter;
-                }
-            }
-            chosen = longer->consensus;
+        const Path *final_consensus = consensus_among(settled);
+        consensus_for_anchors[pair] = final_consensus;
+        if (final_consensus) {
+            pairs_with_consensus++;
+            std::cout << "Final consensus (consensus among groups) length: " << final_consensus->length() << '\n';
+        } else {
+            std::cout << "Final consensus not found!\n";
         }
-        consensus_for_anchors[{&a1, &a2}] = chosen;
-        if (chosen && ++consensus_num) std::cout << "Final consensus (consensus among groups) length: " << chosen->length() << '\n';
-        else std::cout << "Final consensus not found!\n";
-        std::cout << "====> Done finding consensus between anchor '" << a1.name << "' and anchor '" << a2.name << "'!"
-                  << std::endl;
+        announce("====> Done finding consensus between anchor '", *pair.first, *pair.second, "'!");
     }
     if (std::getenv("TLM_HOST_TIMING"))
         std::cerr << "[host timing] selectConsensus: after the groups "
                   << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_groups).count()
-                  << " ms, of it discardNotFrequent " << discard_ms << ", calculateConsensusPath " << cons_ms
-                  << ", calculateValidPathNumber " << valid_ms << std::endl;
-    return consensus_num;
+                  << " ms, of it discardNotFrequent " << clk.discard_ms << ", calculateConsensusPath " << clk.consensus_ms
+                  << ", calculateValidPathNumber " << clk.valid_ms << std::endl;
+    return pairs_with_consensus;
 }
 
 // ---- PathManager::constructConsensusPath (src/PathManager.cpp:664-767) --------------------------------

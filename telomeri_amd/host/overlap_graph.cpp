@@ -191,6 +191,7 @@ void OverlapGraph::start_upload_helper(const char *exe, bool context_at_once) {
     ::close(up[1]);
     if (rc != 0) { ::close(down[1]); ::close(up[0]); return; }
     g_helper.pid = pid;
+    if (std::getenv("TLM_HOST_TIMING")) std::fprintf(stderr, "[host timing] upload helper process %ld\n", (long) pid);
     g_helper.to = ::fdopen(down[1], "w");
     g_helper.from = ::fdopen(up[0], "r");
     ::signal(SIGPIPE, SIG_IGN);         // a helper that died is a failed upload, not the end of this process

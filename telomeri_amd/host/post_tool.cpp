@@ -17,6 +17,84 @@ int run_post_stages(PathManager &pm, std::map<PathManager::AnchorPair, std::vect
                     const char *reads_file, const char *contigs_file, const char *output_file,
                     std::function<Scaffolder *()> loaded, bool leave_mapped);
 
+// ---- the same input as raw arrays (`--binary <dir>`): what a full-size comparison can afford (the text dump of the A. thaliana
+// shape would be 20 GB of digits).  Little-endian files in <dir>:
+//   meta.txt "N A P T" | names.txt (N lines) | node_len.u32 node_anchor.u8 [N] | row_ptr.u64 [N+1]
+//   nbr q_start q_end t_start t_end .u32, os si es .f32, strand.u8 [A]                (CSR, per-node order = record order)
+//   path_off.u64 [P+1] path_length.i64 [P] path_nodes.u32 path_slots.u32 [T]          (paths_ AFTER filterUnique)
+template <typename T>
+static bool read_array(const std::string &dir, const char *name, size_t n, std::vector<T> &out) {
+    out.resize(n);
+    FILE *f = std::fopen((dir + "/" + name).c_str(), "rb");
+    if (!f) { std::cerr << "Cannot open file: " << dir << "/" << name << std::endl; return false; }
+    const size_t got = n ? std::fread(out.data(), sizeof(T), n, f) : 0;
+    const bool at_end = std::fgetc(f) == EOF;
+    std::fclose(f);
+    if (got != n || !at_end) { std::cerr << dir << "/" << name << ": expected " << n << " entries" << std::endl; return false; }
+    return true;
+}
+
+static bool load_binary(const std::string &dir, OverlapGraph &g, std::vector<Path> &paths) {
+    size_t N = 0, A = 0, P = 0, T = 0;
+    {
+        std::ifstream m(dir + "/meta.txt");
+        if (!(m >> N >> A >> P >> T)) { std::cerr << "Cannot read " << dir << "/meta.txt" << std::endl; return false; }
+    }
+    std::vector<uint32_t> node_len, nbr, qs, qe, ts, te, pn, psl;
+    std::vector<uint8_t> node_anchor, strand;
+    std::vector<uint64_t> row_ptr, off;
+    std::vector<float> os, si, es;
+    std::vector<int64_t> plen;
+    if (!read_array(dir, "node_len.u32", N, node_len) || !read_array(dir, "node_anchor.u8", N, node_anchor)
+        || !read_array(dir, "row_ptr.u64", N + 1, row_ptr)) return false;
+    g.nodes_.resize(N);
+    {
+        std::ifstream names(dir + "/names.txt");
+        for (size_t i = 0; i < N; i++) {
+            OverlapGraph::Node &nd = g.nodes_[i];
+            if (!std::getline(names, nd.name)) { std::cerr << dir << "/names.txt: " << N << " names expected" << std::endl; return false; }
+            nd.index = (uint) i;
+            nd.anchor = node_anchor[i] != 0;
+            nd.length = node_len[i];
+            if (row_ptr[i + 1] < row_ptr[i] || row_ptr[i + 1] > A) { std::cerr << "row_ptr is not a prefix" << std::endl; return false; }
+            nd.edges.resize(row_ptr[i + 1] - row_ptr[i]);
+        }
+    }
+    if (!read_array(dir, "nbr.u32", A, nbr) || !read_array(dir, "q_start.u32", A, qs) || !read_array(dir, "q_end.u32", A, qe)
+        || !read_array(dir, "t_start.u32", A, ts) || !read_array(dir, "t_end.u32", A, te) || !read_array(dir, "os.f32", A, os)
+        || !read_array(dir, "si.f32", A, si) || !read_array(dir, "es.f32", A, es) || !read_array(dir, "strand.u8", A, strand)) return false;
+    for (size_t i = 0; i < N; i++)
+        for (uint64_t k = row_ptr[i], j = 0; k < row_ptr[i + 1]; k++, j++) {
+            if (nbr[k] >= N) { std::cerr << "neighbour out of range" << std::endl; return false; }
+            g.nodes_[i].edges[j] = OverlapGraph::Edge{nbr[k], (uint) i, qs[k], qe[k], ts[k], te[k], os[k], si[k], es[k], strand[k] != 0};
+        }
+    { std::vector<uint32_t>().swap(nbr); std::vector<uint32_t>().swap(qs); std::vector<uint32_t>().swap(qe); std::vector<uint32_t>().swap(ts);
+      std::vector<uint32_t>().swap(te); std::vector<float>().swap(os); std::vector<float>().swap(si); std::vector<float>().swap(es); }
+    if (!read_array(dir, "path_off.u64", P + 1, off) || !read_array(dir, "path_length.i64", P, plen)
+        || !read_array(dir, "path_nodes.u32", T, pn) || !read_array(dir, "path_slots.u32", T, psl)) return false;
+    paths.resize(P);
+    for (size_t i = 0; i < P; i++) {
+        if (off[i + 1] < off[i] || off[i + 1] > T) { std::cerr << "path_off is not a prefix" << std::endl; return false; }
+        Path &p = paths[i];
+        const size_t n = off[i + 1] - off[i];
+        p.nodes_.reserve(n);
+        p.edges_.reserve(n ? n - 1 : 0);
+        for (size_t k = 0; k < n; k++) {
+            const uint32_t v = pn[off[i] + k];
+            if (v >= N) { std::cerr << "path node out of range" << std::endl; return false; }
+            p.nodes_.push_back(&g.nodes_[v]);
+            if (k + 1 < n) {
+                const uint32_t sl = psl[off[i] + k];
+                if (sl >= g.nodes_[v].edges.size()) { std::cerr << "path slot out of range" << std::endl; return false; }
+                p.edges_.push_back(&g.nodes_[v].edges[sl]);
+            }
+        }
+        p.updateLength();
+        if (p.length() != plen[i]) { std::cerr << "binary dump: path length mismatch at path " << i << std::endl; return false; }
+    }
+    return true;
+}
+
 static float bits_to_float(unsigned u) {
     float f;
     std::memcpy(&f, &u, 4);
@@ -27,12 +105,14 @@ int main(int argc, char **argv) {
     PathManager pm;
     PathManager::Parameters gp = pm.params_;
     const char *groups_out = nullptr;
+    const char *binary_dir = nullptr;
     std::vector<char *> pos;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--len-thr" && i + 1 < argc) pm.params_.len_threshold = std::atol(argv[++i]);
         else if (a == "--w-size" && i + 1 < argc) pm.params_.window_size = std::strtoul(argv[++i], nullptr, 10);
         else if (a == "--r-thr" && i + 1 < argc) pm.params_.ratio_threshold = std::strtof(argv[++i], nullptr);
+        else if (a == "--binary" && i + 1 < argc) binary_dir = argv[++i];
         else if (a == "--groups" && i + 4 < argc) {        // <out file> <len_thr> <w_size> <r_thr>: group report only
             groups_out = argv[++i];
             gp.len_threshold = std::atol(argv[++i]);
@@ -63,14 +143,16 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (binary_dir) pos.insert(pos.begin(), const_cast<char *>(binary_dir));       // takes the place of <dump>
     if (pos.size() != 4) {
-        std::cerr << "usage: telomeri_post [--len-thr N --w-size N --r-thr F] <dump> <reads.fa> <contigs.fa> <out.fa>" << std::endl;
+        std::cerr << "usage: telomeri_post [--len-thr N --w-size N --r-thr F] (<dump> | --binary <dir>) <reads.fa> <contigs.fa> <out.fa>" << std::endl;
         return 2;
     }
-    std::ifstream in(pos[0]);
-    if (!in) { std::cerr << "Cannot open file: " << pos[0] << std::endl; return 1; }
     OverlapGraph g;
     std::vector<Path> paths;
+    if (binary_dir && !load_binary(binary_dir, g, paths)) return 1;
+    std::ifstream in(binary_dir ? "/dev/null" : pos[0]);
+    if (!in) { std::cerr << "Cannot open file: " << pos[0] << std::endl; return 1; }
     std::string line;
     bool in_unique = false;
     while (std::getline(in, line)) {

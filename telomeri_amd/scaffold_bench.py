@@ -3,10 +3,10 @@
 C++ host program `telomeri_hip` (reference argv, reference defaults: 2000 trials per anchor, 60 backtracks) on a synthetic
 dataset of the given shape (reference surface: run.sh:27-47, Main.cpp:212-388).
 
-  python profiles/probes/scaffold_bench.py [config]          (default athaliana; run on the GPU box)
+  python -m telomeri_amd.scaffold_bench [config]          (default athaliana; run on the GPU box)
 
 bench.py imports run() for its `scaffold_wall_s` block.  The input text (for A. thaliana: 150 M PAF lines = 15 GB, reads
-FASTA 10 GB) is rendered by profiles/probes/synth_writer.c on all cores into /dev/shm (or $TLM_SCRATCH) and deleted
+FASTA 10 GB) is rendered by telomeri_amd/csrc/synth_writer.c on all cores into /dev/shm (or $TLM_SCRATCH) and deleted
 afterwards; writing it is NOT part of the measured wall-clock, reading it is."""
 import ctypes as C
 import json
@@ -21,16 +21,17 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(HERE)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WRITER_SRC = os.path.join(HERE, "synth_writer.c")
-WRITER_LIB = os.path.join(HERE, "libsynth_writer.so")
+WRITER_SRC = os.path.join(HERE, "csrc", "synth_writer.c")
+WRITER_LIB = os.path.join(HERE, "lib", "libsynth_writer.so")
 
 
 def build_writer() -> str:
     if not os.path.exists(WRITER_LIB) or os.path.getmtime(WRITER_LIB) < os.path.getmtime(WRITER_SRC):
+        os.makedirs(os.path.dirname(WRITER_LIB), exist_ok=True)
         subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", WRITER_LIB, WRITER_SRC], check=True)
     return WRITER_LIB
 
@@ -130,6 +131,19 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
         res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, TLM_HOST_TIMING="1"))
         t_done = time.time()
         out["scaffold_wall_s"] = round(t_done - t0, 3)
+        # the program does not wait for its upload helper (a second process that holds a device context): when THAT has
+        # gone is when the device is really free again
+        m = re.search(r"\[host timing\] upload helper process (\d+)", res.stderr)
+        if m:
+            hp = int(m.group(1))
+            while os.path.exists("/proc/%d" % hp) and time.time() - t_done < 30:
+                try:
+                    if open("/proc/%d/stat" % hp).read().split(")")[-1].split()[0] == "Z":
+                        break
+                except OSError:
+                    break
+                time.sleep(0.002)
+            out["helper_process_gone_s"] = round(time.time() - t0, 3)
         marks = {m.group(1): float(m.group(2)) for m in re.finditer(r"\[host timing\] ([a-z ]+) at ([0-9.]+)", res.stderr)}
         if "main entered" in marks:
             out["marks_s"] = {k: round(v - t_spawn, 3) for k, v in sorted(marks.items(), key=lambda kv: kv[1])}

@@ -99,3 +99,53 @@ def quirks_dataset(seed: int = 5) -> synth.Dataset:
     perm = torch.randperm(len(cr), generator=g)
     cr = cr.take(perm)
     return dataclasses.replace(ds, rr=rr, cr=cr)
+
+
+def write_binary_dump(dirname: str, names, csr, paths) -> None:
+    """The input of `telomeri_post --binary <dir>` (host/post_tool.cpp): the graph as raw CSR arrays and a packed Path set
+    (paths_ AFTER filterUnique), for comparisons at sizes where the text dump would be tens of GB."""
+    import os
+    os.makedirs(dirname, exist_ok=True)
+    p = lambda n: os.path.join(dirname, n)
+    with open(p("names.txt"), "w") as fh:
+        fh.write("\n".join(names) + ("\n" if len(names) else ""))
+    np.ascontiguousarray(csr.node_len, np.uint32).tofile(p("node_len.u32"))
+    np.ascontiguousarray(csr.node_anchor, np.uint8).tofile(p("node_anchor.u8"))
+    np.ascontiguousarray(csr.row_ptr, np.uint64).tofile(p("row_ptr.u64"))
+    for name, dt, ext in (("nbr", np.uint32, "u32"), ("q_start", np.uint32, "u32"), ("q_end", np.uint32, "u32"),
+                          ("t_start", np.uint32, "u32"), ("t_end", np.uint32, "u32"), ("os", np.float32, "f32"),
+                          ("si", np.float32, "f32"), ("es", np.float32, "f32"), ("strand", np.uint8, "u8")):
+        np.ascontiguousarray(getattr(csr, name), dt).tofile(p("%s.%s" % (name, ext)))
+    np.ascontiguousarray(paths.off, np.uint64).tofile(p("path_off.u64"))
+    np.ascontiguousarray(paths.length, np.int64).tofile(p("path_length.i64"))
+    np.ascontiguousarray(paths.nodes, np.uint32).tofile(p("path_nodes.u32"))
+    np.ascontiguousarray(paths.slots, np.uint32).tofile(p("path_slots.u32"))
+    with open(p("meta.txt"), "w") as fh:
+        fh.write("%d %d %d %d\n" % (csr.n_nodes, csr.n_adj, len(paths.length), paths.nodes.shape[0]))
+
+
+def drop_adjacent_duplicates(ps):
+    """PathManager::filterUnique (reference PathManager.cpp:432-438) on a packed set WITHOUT the per-path Python loop of
+    oracle.pyoracle.filter_unique: only neighbours with equal node counts are compared.  -> (set, number dropped)"""
+    from oracle import pyoracle as po
+    off = ps.off.astype(np.int64)
+    cnt = np.diff(off)
+    n = cnt.shape[0]
+    keep = np.ones(n, bool)
+    same_cnt = np.nonzero(cnt[1:] == cnt[:-1])[0] + 1
+    # std::unique compares each element with the last one KEPT: walk the candidates in order
+    prev = np.arange(n) - 1
+    for i in same_cnt:
+        j = int(prev[i])
+        while j >= 0 and not keep[j]:
+            j -= 1
+        if j >= 0 and cnt[j] == cnt[i] and np.array_equal(ps.nodes[off[i]:off[i + 1]], ps.nodes[off[j]:off[j + 1]]):
+            keep[i] = False
+    dropped = int(n - keep.sum())
+    if dropped == 0:
+        return ps, 0
+    idx = np.nonzero(keep)[0]
+    sel = np.repeat(keep, cnt)
+    new_off = np.zeros(idx.shape[0] + 1, np.uint64)
+    new_off[1:] = np.cumsum(cnt[idx])
+    return po.PathSet(ps.unit[idx], ps.length[idx], new_off, ps.nodes[sel], ps.slots[sel]), dropped

@@ -131,19 +131,20 @@ def test_ranks_fail_together(fake_rccl, point):
     its own error, the other with TLM_EPEER (-5) -- nobody hangs; after a failure inside the grouped transfers the
     communicator is aborted and later calls fail at once."""
     with tempfile.TemporaryDirectory() as tmp:
-        outs = run_ranks(fake_rccl, "toy", 2, tmp, {"TLM_EXCHANGE_FAULT": "1:" + point}, timeout=300)
+        # (rank 0 is the culprit: in the toy set the last anchor, rank 1's only one, has no accepted path -- nothing to send)
+        outs = run_ranks(fake_rccl, "toy", 2, tmp, {"TLM_EXCHANGE_FAULT": "0:" + point}, timeout=300)
         logs = []
         for r, (rc, out) in enumerate(outs):
             assert rc == 0, "rank %d: %s" % (r, out[-2000:])
             logs.append(open(os.path.join(tmp, "rank%d.log" % r)).read().splitlines())
-    culprit, peer = logs[1], logs[0]
+    culprit, peer = logs[0], logs[1]
     if point == "fetch":
         assert culprit[0] == peer[0] == "allgather: ok" and culprit[1] == peer[1] == "gather_summaries: ok"
         for k in (2, 3):
-            assert "injected failure at 'fetch' on rank 1" in culprit[k] and "(-2)" in culprit[k]
-            assert "(-5)" in peer[k] and "rank 1 failed" in peer[k]
+            assert "injected failure at 'fetch' on rank 0" in culprit[k] and "(-2)" in culprit[k]
+            assert "(-5)" in peer[k] and "rank 0 failed" in peer[k]
         return
-    assert "injected failure at '%s' on rank 1" % point in culprit[0] and "(-2)" in culprit[0]
+    assert "injected failure at '%s' on rank 0" % point in culprit[0] and "(-2)" in culprit[0]
     assert "allgather" in peer[0] and "ok" not in peer[0]
     if point == "group":
         # the culprit left in the middle of the grouped transfers: both communicators are gone, the next call says so
@@ -151,7 +152,7 @@ def test_ranks_fail_together(fake_rccl, point):
         assert "(-5)" in culprit[1] and "aborted" in culprit[1]
         assert "(-5)" in peer[1] and "aborted" in peer[1]
     else:
-        assert "(-5)" in peer[0] and "rank 1 failed" in peer[0]
+        assert "(-5)" in peer[0] and "rank 0 failed" in peer[0]
         assert "injected failure" in culprit[1] and "(-5)" in peer[1]       # the communicator is intact: the protocol again
     assert len(culprit) == len(peer) == 2
 
@@ -198,7 +199,12 @@ def test_host_program_with_two_ranks(fake_rccl, name, mode):
         rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
         assert two.returncode == 0, two.stderr[-2000:] + rank1[-2000:]
         assert "Gathered" in two.stdout and "from 2 ranks" in two.stdout and "from 2 ranks" in rank1
-        keep = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(REPORT)]
+        # "Found N paths." is what a builder call found among THIS rank's units: the ranks' counts add up to the one-process
+        # figure, builder by builder; everything after the exchange is the same report on every rank
+        found = lambda txt: [int(ln.split()[1]) for ln in txt.splitlines() if ln.startswith("Found ") and ln.endswith(" paths.")]
+        keep = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(REPORT) and not ln.startswith("Found ")]
+        assert len(found(one.stdout)) == 4
+        assert [a + b for a, b in zip(found(two.stdout), found(rank1))] == found(one.stdout)
         assert keep(two.stdout) == keep(one.stdout)
         assert keep(rank1) == keep(one.stdout)          # every rank runs the same host stages on the same paths_
         assert body_two == body_one and body_one
@@ -216,4 +222,4 @@ def test_host_program_ranks_end_together(fake_rccl):
         assert time.time() - t0 < 120
         rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
         assert "injected failure" in rank1
-        assert "rank 1 failed" in res.stderr or "a rank ended with status" in res.stderr
+        assert "rank 0 failed" in res.stderr or "a rank ended with status" in res.stderr

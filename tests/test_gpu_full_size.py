@@ -299,3 +299,100 @@ def test_pack_roundtrip_on_device(ctx):
         for f in ("unit", "length", "off", "nodes", "slots"):
             assert torch.equal(getattr(x, f), getattr(y, f)), f
     assert pathgather.allgather_paths(sets)[0].n_paths == sets[0].n_paths      # world size 1: identity
+
+
+def test_full_config_scaffold_parity(ctx):
+    """The WHOLE A. thaliana-shaped config, once, end to end (reference surface Main.cpp:212-388):
+      * every unit of all four builders (800 000 Monte-Carlo + ~97 000 deterministic walks, 6.6e11 evals) is walked by the
+        oracle on the same graph (all host threads of the box's CPU share, about two minutes) and must agree with the device unit for
+        unit in status, nodes, steps, evals, draws, length, and path for path (nodes and edge slots);
+      * the product program `telomeri_hip` reads the same config as TEXT (26 GB: PAF + FASTA) and writes a scaffold; the
+        expected scaffold is what the host stages (`telomeri_post --binary`, validated against the unmodified reference at small
+        sizes in test_host_post_stages.py) make of the ORACLE's paths: same bytes."""
+    import hashlib
+    import os
+    import shutil
+    import subprocess
+    import time
+    from telomeri_amd import cpu_share, scaffold_bench as sb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary, post = [os.path.join(root, "telomeri_amd", "bin", b) for b in ("telomeri_hip", "telomeri_post")]
+    threads = max(1, min(16, cpu_share.cpu_share()))
+    t_start = time.time()
+    ds = synth.make_config("athaliana", device="cuda")
+    g = ctx.build_graph(capi.FilterParams.default(), [ds.rr, ds.cr], [False, True], ds.n_reads + ds.n_contigs, ds.name_is_ctg())
+    wp = capi.WalkParams.default()                  # 2000 trials, 60 backtracks, 4.7 Mb: the reference's defaults
+    tmp = sb.scratch_dir(40 << 30)
+    try:
+        # ---- the text the product reads (written while the dataset is on the device), then the product itself
+        rr, cr = os.path.join(tmp, "rr_overlaps.paf"), os.path.join(tmp, "cr_overlaps.paf")
+        reads, contigs = os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "contigs.fasta")
+        sb.write_paf(ds, ds.rr, rr, threads=threads)
+        sb.write_paf(ds, ds.cr, cr, threads=threads)
+        sb.write_fasta(ds, reads, contigs)
+        n_reads = ds.n_reads
+        names_of = lambda i: "read%07d" % (i + 1) if i < n_reads else "ctg%d" % (i - n_reads + 1)       # synth.Dataset.name_of
+        assert names_of(0) == ds.name_of(0) and names_of(n_reads) == ds.name_of(n_reads)
+        del ds
+        torch.cuda.empty_cache()
+        # ---- device: all four builders over all units
+        sets = list(g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp))
+        csr = g.download(cold=True)
+        og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
+        owp = po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
+        osets = []
+        evals = units = 0
+        t_oracle = time.time()
+        for k, (kind, metric) in enumerate((("mc", po.METRIC_ES), ("mc", po.METRIC_OS), ("det", po.METRIC_ES), ("det", po.METRIC_OS))):
+            ops, octr, ostats = (og.walk_mc(metric, owp, po.SEED_PER_WALK, threads=threads) if kind == "mc"
+                                 else og.walk_det(metric, threads=threads))
+            H.assert_stats_equal(sets[k].unit_stats(), ostats)
+            assert sets[k].counters.evals == octr.evals
+            h = sets[k].to_host()
+            H.assert_paths_equal(h, ops)
+            evals += int(octr.evals)
+            units += int(ostats.shape[0])
+            osets.append(ops)
+            del h
+        t_oracle = time.time() - t_oracle
+        del sets
+        # ---- expected scaffold: the host stages over the oracle's paths_
+        allp = po.concat_paths(osets)
+        del osets
+        uniq, dropped = H.drop_adjacent_duplicates(allp)
+        names = [names_of(int(i)) for i in csr.node_name_id]
+        H.write_binary_dump(os.path.join(tmp, "bin"), names, csr, uniq)
+        n_paths = len(uniq.length)
+        del uniq, allp, csr, og
+        del g
+        ctx.trim()
+        want_fa, got_fa = os.path.join(tmp, "want.fasta"), os.path.join(tmp, "got.fasta")
+        t0 = time.time()
+        exp = subprocess.run([post, "--binary", os.path.join(tmp, "bin"), reads, contigs, want_fa], capture_output=True, text=True, timeout=900)
+        t_post = time.time() - t0
+        assert exp.returncode == 0, exp.stderr[-2000:]
+        shutil.rmtree(os.path.join(tmp, "bin"))
+        t0 = time.time()
+        res = subprocess.run([binary, rr, cr, reads, contigs, got_fa], capture_output=True, text=True, timeout=600)
+        t_hip = time.time() - t0
+        assert res.returncode == 0, res.stderr[-2000:]
+        pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Consensus length", "Final consensus"))]
+        assert pick(res.stdout) == pick(exp.stdout)
+        assert "- total_num: %d" % n_paths in res.stdout
+        a, b = open(got_fa, "rb").read(), open(want_fa, "rb").read()
+        assert len(a) == len(b) and a == b
+        md5 = hashlib.md5(a).hexdigest()
+        print("\nfull-config scaffold parity: %d units' worth of %.3g evals by the oracle on %d threads in %.0f s; %d paths after filterUnique "
+              "(%d adjacent duplicates); scaffold %d bytes md5 %s; telomeri_post %.0f s, telomeri_hip %.1f s; whole test %.0f s" % (
+                  units, evals, threads, t_oracle, n_paths, dropped, len(a), md5, t_post, t_hip, time.time() - t_start))
+        rec = os.path.join(root, "gpurun_out", "full_config_scaffold_parity.json")
+        try:
+            os.makedirs(os.path.dirname(rec), exist_ok=True)
+            import json
+            json.dump({"config": "athaliana", "units": units, "evals": evals, "oracle_threads": threads, "oracle_s": t_oracle, "paths": n_paths,
+                       "adjacent_duplicates": dropped, "scaffold_bytes": len(a), "scaffold_md5": md5, "telomeri_post_s": t_post,
+                       "telomeri_hip_s": t_hip, "test_s": time.time() - t_start}, open(rec, "w"))
+        except OSError:
+            pass
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

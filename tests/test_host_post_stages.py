@@ -9,6 +9,7 @@ import os
 import subprocess
 import tempfile
 
+import numpy as np
 import pytest
 
 import golden_util as G
@@ -167,3 +168,45 @@ def test_scaffolder_load_roles_by_line_number(post, name, fastq, text):
             body = res.stdout[len(out[0]) + 1:]
             want = "".join("%d\t[%s]%s\n" % (i, nm, "\t[%s]" % seqs[i] if i < len(seqs) else "") for i, nm in enumerate(names))
             assert body == want
+
+
+@pytest.mark.parametrize("name", ["tiny", "quirks"])
+def test_binary_dump_gives_the_text_dump_result(post, name):
+    """`telomeri_post --binary <dir>` (raw CSR arrays + packed Path set: the input of the full-size comparison in
+    tests/test_gpu_full_size.py) is the text dump in another encoding: same report, same scaffold bytes as the reference wrote."""
+    import types
+    meta = G.load_json(name + ".json")
+    ds = _dataset(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        ref = po.parse_ref_dump(G.gunzip_to(tmp, name + ".dump.gz"))
+        adj = ref.adj                                   # rows: owner slot nbr q_start q_end t_start t_end os si es strand
+        deg = ref.node_deg
+        row_ptr = np.zeros(len(ref.node_name) + 1, np.uint64)
+        row_ptr[1:] = np.cumsum(deg)
+        order = np.lexsort((adj[:, 1], adj[:, 0]))
+        a = adj[order]
+        csr = types.SimpleNamespace(n_nodes=len(ref.node_name), n_adj=a.shape[0], node_len=ref.node_len, node_anchor=ref.node_anchor,
+                                    row_ptr=row_ptr, nbr=a[:, 2], q_start=a[:, 3], q_end=a[:, 4], t_start=a[:, 5], t_end=a[:, 6],
+                                    os=a[:, 7].astype(np.uint32).view(np.float32), si=a[:, 8].astype(np.uint32).view(np.float32),
+                                    es=a[:, 9].astype(np.uint32).view(np.float32), strand=a[:, 10])
+        counts = np.array([len(n) for _, n, _ in ref.unique], np.int64)
+        off = np.zeros(len(counts) + 1, np.uint64)
+        off[1:] = np.cumsum(counts)
+        nodes = np.concatenate([n for _, n, _ in ref.unique]).astype(np.uint32)
+        slots = np.concatenate([np.r_[s, np.uint32(0xFFFFFFFF)] for _, _, s in ref.unique]).astype(np.uint32)
+        paths = types.SimpleNamespace(off=off, length=np.array([l for l, _, _ in ref.unique], np.int64), nodes=nodes, slots=slots)
+        H.write_binary_dump(os.path.join(tmp, "bin"), ref.node_name, csr, paths)
+        reads, contigs, out = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "out.fa")
+        synth.write_fasta(ds, reads, contigs)
+        res = subprocess.run([post, "--binary", os.path.join(tmp, "bin"), reads, contigs, out], capture_output=True, text=True, timeout=120)
+        want = meta["scaffold"]
+        assert res.returncode == want["exit"], res.stderr
+        body = open(out, "rb").read()
+        assert len(body) == want["bytes"] and hashlib.md5(body).hexdigest() == want["md5"]
+        got_lines = [ln for ln in res.stdout.splitlines() if ln.startswith(("Consensus length", "Final consensus"))]
+        assert got_lines == want["consensus_lines"]
+        # a truncated array is refused, not read short
+        with open(os.path.join(tmp, "bin", "path_nodes.u32"), "r+b") as fh:
+            fh.truncate(max(0, nodes.nbytes - 4))
+        bad = subprocess.run([post, "--binary", os.path.join(tmp, "bin"), reads, contigs, out], capture_output=True, text=True, timeout=120)
+        assert bad.returncode == 1 and "expected" in bad.stderr

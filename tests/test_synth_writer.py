@@ -1,6 +1,5 @@
-"""Bench infrastructure: the all-cores text writer (profiles/probes/synth_writer.c) prints exactly what the Python
+"""Bench infrastructure: the all-cores text writer (telomeri_amd/csrc/synth_writer.c) prints exactly what the Python
 writers of telomeri_amd.synth print -- the scaffold wall-clock leg of bench.py feeds the host program with its output."""
-import importlib.util
 import os
 import tempfile
 
@@ -11,10 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _probe():
-    spec = importlib.util.spec_from_file_location("scaffold_bench", os.path.join(ROOT, "profiles", "probes", "scaffold_bench.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    return m
+    from telomeri_amd import scaffold_bench
+    return scaffold_bench
 
 
 def test_fast_writers_match_python_writers():
