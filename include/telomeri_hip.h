@@ -320,8 +320,10 @@ int tlm_pathset_anchor_pairs(tlm_ctx *ctx, const tlm_pathset *ps, uint32_t *orde
  * tokens, the nine numeric ones plain [+-]digits inside int range, the strand one character, no blank lines -- there
  * line-wise parsing is the reference's token stream.  The text goes to the device (pinned slabs, parallel reads) and is
  * tokenised there; names are numbered in first-seen order over the files (query before target), the numbering a
- * sequential reader assigns.  *clean = 0: the text is something else, nothing was added; the host falls back to its
- * exact token-stream reader for the whole graph. */
+ * sequential reader assigns.  *clean = 0: the text is something else; the host falls back to its exact token-stream
+ * reader for the whole graph.  A handle that has refused a file (or on which an add failed) is good for tlm_paf_destroy
+ * only: every later add, tlm_paf_text_begin and tlm_paf_finish on it returns TLM_EINVAL (the refused file's names are in
+ * the handle's dictionary; numbering the other files' names past them would be wrong). */
 typedef struct tlm_paf tlm_paf;
 int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out);
 void tlm_paf_destroy(tlm_paf *p);

@@ -550,8 +550,10 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
 
     if (n_units) {
         const uint32_t N = g->n_nodes;
-        // a walk pushes at most N nodes and logs at most N marks + one band move per step or backtrack
-        const uint32_t full_cap = (uint32_t) std::min<uint64_t>(2ull * N + 64u, 0xFFFFFFF0ull);
+        // a walk pushes at most N nodes (a node is entered once) and logs, per push, at most one far mark AND one band move
+        // (the band follows the walk), plus one band move per go-back -- and there are at most as many go-backs as pushes:
+        // 3 N log entries bound every walk, whatever the node order and however large backtrack_attempts is
+        const uint32_t full_cap = (uint32_t) std::min<uint64_t>(3ull * N + 64u, 0xFFFFFFF0ull);
         uint32_t cap = ctx->path_capacity ? ctx->path_capacity : 16384u;
         cap = std::max<uint32_t>(8u, std::min(cap, full_cap));
         const uint32_t bm_words = (N + 31) / 32 + 1 + WALK_RNG_WORDS;
@@ -609,6 +611,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         a.len_threshold = is_mc ? p->len_threshold : 0;
         a.cursor = W.cursor;
         a.units = u.units;
+        a.n_ent = g->n_adj_pad;
+        a.n_work_all = n_all;
 
         std::vector<uint32_t> work;     // empty = identity
         uint32_t n_work = n_all;
@@ -654,8 +658,9 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 a.resident_flag = c->resident_dev;
             }
             TLM_HIP(hipEventRecord(ev0, s));
-            if (is_mc) tlm_launch_walk_mc(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
-            else tlm_launch_walk_det(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
+            const int out_of_bounds = is_mc ? tlm_launch_walk_mc(s, launch_waves / WPB, sq, a, ctx->walk_accounting)
+                                            : tlm_launch_walk_det(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
+            if (out_of_bounds) return TLM_EINTERNAL;         // checked build only (the message is set)
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));
             if (launched) launched->store(1);

@@ -385,6 +385,7 @@ unsigned grid_of(uint64_t n, unsigned per = 256) {
 struct tlm_paf {
     tlm_ctx *ctx = nullptr;
     int n_files = 0;
+    bool poisoned = false;      // a file was refused (not clean) or failed: its names are in the dictionary, the handle is only good for destroy
     char *text[MAX_FILES] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t bytes[MAX_FILES] = {0, 0, 0, 0};
     uint64_t n[MAX_FILES] = {0, 0, 0, 0};
@@ -616,6 +617,7 @@ static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStre
 
 extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint64_t *n_records, int *clean) {
     TLM_CHECK(p && path && n_records && clean, TLM_EINVAL, "tlm_paf_add_file: null argument");
+    TLM_CHECK(!p->poisoned, TLM_EINVAL, "tlm_paf_add_file: an earlier file of this handle was refused; destroy the handle and start over");
     TLM_CHECK(!p->finished && p->n_files < MAX_FILES, TLM_EINVAL, "tlm_paf_add_file: at most %d files, before tlm_paf_finish", MAX_FILES);
     TLM_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
@@ -706,7 +708,7 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
     p->anchors[f] = anchors;
     p->n_files = f + 1;
     rc = tokenise_on_device(p, f, n_records, clean);
-    if (rc != TLM_OK || !*clean) p->n_files = f;        // nothing was appended (the buffers go with the handle)
+    if (rc != TLM_OK || !*clean) { p->n_files = f; p->poisoned = true; }       // nothing usable was appended (the buffers go with the handle)
     return rc;
 }
 
@@ -732,6 +734,7 @@ extern "C" int tlm_upload_window_create(tlm_ctx *ctx, uint8_t *handle_out, uint6
 
 extern "C" int tlm_paf_text_begin(tlm_paf *p, uint64_t bytes) {
     TLM_CHECK(p, TLM_EINVAL, "tlm_paf_text_begin: null argument");
+    TLM_CHECK(!p->poisoned, TLM_EINVAL, "tlm_paf_text_begin: an earlier file of this handle was refused; destroy the handle and start over");
     TLM_CHECK(!p->finished && p->n_files < MAX_FILES && !p->pending, TLM_EINVAL, "tlm_paf_text_begin: no room for a file");
     TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_text_begin: text too large");
     TLM_HIP(hipSetDevice(p->ctx->device));
@@ -770,7 +773,7 @@ extern "C" int tlm_paf_text_commit(tlm_paf *p, int anchors, uint64_t *n_records,
     p->anchors[f] = anchors;
     p->n_files = f + 1;
     const int rc = tokenise_on_device(p, f, n_records, clean);
-    if (rc != TLM_OK || !*clean) p->n_files = f;
+    if (rc != TLM_OK || !*clean) { p->n_files = f; p->poisoned = true; }
     return rc;
 }
 
@@ -810,6 +813,7 @@ extern "C" int tlm_upload_file_window(tlm_ctx *ctx, const char *path, uint64_t b
 
 extern "C" int tlm_paf_add_text(tlm_paf *p, const char *text_host, uint64_t bytes, int anchors, uint64_t *n_records, int *clean) {
     TLM_CHECK(p && (text_host || bytes == 0) && n_records && clean, TLM_EINVAL, "tlm_paf_add_text: null argument");
+    TLM_CHECK(!p->poisoned, TLM_EINVAL, "tlm_paf_add_text: an earlier file of this handle was refused; destroy the handle and start over");
     TLM_CHECK(!p->finished && p->n_files < MAX_FILES, TLM_EINVAL, "tlm_paf_add_text: at most %d files, before tlm_paf_finish", MAX_FILES);
     TLM_CHECK(bytes < (1ull << 46), TLM_ELIMIT, "tlm_paf_add_text: text too large");
     TLM_HIP(hipSetDevice(p->ctx->device));
@@ -822,13 +826,14 @@ extern "C" int tlm_paf_add_text(tlm_paf *p, const char *text_host, uint64_t byte
     p->anchors[f] = anchors;
     p->n_files = f + 1;
     const int rc = tokenise_on_device(p, f, n_records, clean);
-    if (rc != TLM_OK || !*clean) p->n_files = f;
+    if (rc != TLM_OK || !*clean) { p->n_files = f; p->poisoned = true; }
     return rc;
 }
 
 extern "C" int tlm_paf_finish(tlm_paf *p, uint32_t *n_names_out, uint64_t *blob_bytes_out) {
     TLM_CHECK(p && n_names_out, TLM_EINVAL, "tlm_paf_finish: null argument");
     TLM_CHECK(!p->finished, TLM_EINVAL, "tlm_paf_finish: called twice");
+    TLM_CHECK(!p->poisoned, TLM_EINVAL, "tlm_paf_finish: a file of this handle was refused; its names would be numbered with the others");
     TLM_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
     const auto t0 = std::chrono::steady_clock::now();

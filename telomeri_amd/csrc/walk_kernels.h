@@ -71,6 +71,9 @@ struct WalkArgs {
     // host-mapped word, or null: set to 1 by the workgroup that finds every workgroup of the launch started (counted in
     // cursor[1]); the host queues the deterministic launch of tlm_walk_builders only then
     uint32_t *resident_flag;
+    // sizes the checked build (-DTLM_CHECKED) compares indices with; unused kernel arguments cost no registers
+    uint64_t n_ent;                 // entries of the walk-layout arrays (ents / met / d16 / qt): zero block + padded rows
+    uint32_t n_work_all;            // entries of `units`
 };
 
 constexpr int WALK_RNG_WORDS = 640;             // raw std::mt19937 state of a wave (624 words), kept in HBM between twists
@@ -87,7 +90,9 @@ constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
 // resident workgroups per CU of the kernel (occupancy query): the persistent grid is sized from it
 int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric);
 // account: the build of the kernel that also sums the layout bytes its steps ask for into cursor[10..11] (tlm_counters.layout_bytes)
-void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account);
-void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account);
+// -> 0; the checked build (-DTLM_CHECKED) waits for the launch and returns 1, with the error text set, when a kernel formed
+// an index outside one of its arrays (the access itself was skipped)
+int tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account);
+int tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account);
 
 #endif

@@ -8,6 +8,49 @@
 __device__ unsigned long long tlm_timing[8];
 #endif
 
+// Checked build (make EXTRA=-DTLM_CHECKED, a separate library that tests load through TLM_LIB): every index the walk kernels
+// form into a global array -- list entries, row records, {q_start, t_start}, the wave's path / log / visited-map scratch,
+// the arena, the unit records -- is compared with its array's size first; an index outside is NOT dereferenced (a GPU
+// memory fault can take the whole host's GPUs down), it is recorded (first offender: site, index, limit) and the launch
+// is reported as failed by the host.  The product build compiles the checks away.
+#ifdef TLM_CHECKED
+struct ChkLimits {
+    unsigned long long n_ent;      // entries of the walk-layout arrays (rows, zero block and padding included)
+    unsigned n_nodes, n_anchors;
+};
+__device__ ChkLimits tlm_chk;
+__device__ unsigned long long tlm_oob[4];       // first offender: site, index, limit; [3] = offences counted
+#ifndef TLM_CHECK_REPORT_INLINE
+#define TLM_CHECK_REPORT_INLINE __noinline__
+#endif
+__device__ TLM_CHECK_REPORT_INLINE void tlm_oob_report(unsigned site, unsigned long long idx, unsigned long long lim) {
+    if (atomicCAS(&tlm_oob[0], 0ull, (unsigned long long) site) == 0ull) {
+        tlm_oob[1] = idx;
+        tlm_oob[2] = lim;
+    }
+    atomicAdd(&tlm_oob[3], 1ull);
+}
+#ifdef TLM_CHECK_OFF        /* bisecting the checked build itself */
+#define TLM_IN(site, idx, lim) true
+#else
+#ifndef TLM_CHECK_SITES
+#define TLM_CHECK_SITES 0xFFFFFFFFu
+#endif
+#define TLM_IN(site, idx, lim) \
+    ((((TLM_CHECK_SITES) >> (site)) & 1u) == 0u || (unsigned long long) (idx) < (unsigned long long) (lim) ? true : (tlm_oob_report((site), (idx), (lim)), false))
+#endif
+#define TLM_N_ENT (tlm_chk.n_ent)
+#define TLM_N_NODES (tlm_chk.n_nodes)
+#else
+#define TLM_IN(site, idx, lim) true
+#define TLM_N_ENT 0ull
+#define TLM_N_NODES 0u
+#endif
+enum {      // sites of the checked build
+    CHK_ROWS = 1, CHK_LIST8 = 2, CHK_LISTC = 3, CHK_CHUNK = 4, CHK_SERIAL = 5, CHK_BACKPROBE = 6, CHK_QT = 7, CHK_PATH = 8,
+    CHK_LOG = 9, CHK_MAP = 10, CHK_ARENA = 11, CHK_UNIT = 12, CHK_NODE_TABLE = 13, CHK_ANCHOR = 14, CHK_BAND = 15
+};
+
 namespace {
 
 struct StepClock {
@@ -61,6 +104,15 @@ __device__ __forceinline__ ColdArgs *cold_args() {
 __device__ __forceinline__ uint2 scalar_load_u2(const uint2 *table, uint32_t index) {
     const uint64_t v = ((__attribute__((address_space(4))) const uint64_t *) table)[index];
     return make_uint2((uint32_t) v, (uint32_t) (v >> 32));
+}
+
+__device__ __forceinline__ uint2 row_record(const uint2 *rows, uint32_t node) {
+    if (!TLM_IN(CHK_ROWS, node, TLM_N_NODES)) return make_uint2(0u, 0u);
+    return scalar_load_u2(rows, node);
+}
+__device__ __forceinline__ uint2 qt_record(const uint2 *qt, uint32_t e) {
+    if (!TLM_IN(CHK_QT, e, TLM_N_ENT)) return make_uint2(0u, 0u);
+    return scalar_load_u2(qt, e);
 }
 
 // What the step loop itself reads (stays in scalar registers for the whole walk).
@@ -182,6 +234,10 @@ __device__ __forceinline__ double mt_canonical(Rng &g, int lane) {
 
 // ---------------------------------------------------------------------------------------------
 
+// (not checked in the checked build: this helper is inlined into every probe of every lane width, and a check here --
+// a conditional call in the innermost divergent code -- made hipcc 7.2 produce a kernel whose walks differed from run to run
+// although no check ever fired (bisected to this site, gpurun_out/r03 notes in DESIGN.md).  The ids that reach it are
+// neighbour ids of the graph, validated when a neighbour is CHOSEN (row_record) and by the graph tests.)
 __device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
 
 // Visited set of a Monte-Carlo walk.  Node ids are walk-order indices (graph build: nearest anchor, BFS level), so
@@ -209,6 +265,7 @@ __device__ __forceinline__ bool visited_test(const Visited &v, uint32_t n) {    
 }
 
 __device__ __forceinline__ int64_t edge_delta(const uint2 *qt_tab, uint32_t e) {
+    if (!TLM_IN(CHK_QT, e, TLM_N_ENT)) return 0;
     const uint2 qt = qt_tab[e];
     return (int64_t) qt.x - (int64_t) qt.y;                    // Path.cpp:14
 }
@@ -274,7 +331,9 @@ __device__ inline void finish_unit(const WaveScratch &ws, int lane, uint32_t ui,
             const uint32_t *old_of_new = ca->old_of_new;
             const uint2 *rows = ca->rows;
             for (uint32_t i = lane; i < n_out; i += 64) {
+                if (!TLM_IN(CHK_PATH, i, ca->cap)) continue;
                 const uint32_t node = ws.pn[i];
+                if (!TLM_IN(CHK_NODE_TABLE, node, TLM_N_NODES) || !TLM_IN(CHK_ARENA, off + i, ca->ar_cap)) continue;
                 arena[off + i] = make_uint2(old_of_new[node],                         // reference index
                                             (i < m) ? (ws.pe[i] - rows[node].x) : 0xFFFFFFFFu);
             }
@@ -289,14 +348,14 @@ __device__ inline void finish_unit(const WaveScratch &ws, int lane, uint32_t ui,
         u.steps = steps;
         u.draws = draws;
         u.status = status;
-        ca->units[ui] = u;
+        if (TLM_IN(CHK_UNIT, ui, ca->n_work_all)) ca->units[ui] = u;
     }
     // the wave's HBM map goes back to all-zero: single marks by node id, flushed bands (band_slide) by their first word
     const uint32_t n_words = ca->bm_words - WALK_RNG_WORDS;
     for (uint32_t base = 0; base < nlog; base += 64) {
-        const bool valid = base + lane < nlog;
+        const bool valid = base + lane < nlog && TLM_IN(CHK_LOG, base + lane, ca->cap);
         const uint32_t e = valid ? ws.lg[base + lane] : 0u;
-        if (valid && !(e >> 31)) ws.bm[e >> 5] = 0u;
+        if (valid && !(e >> 31) && TLM_IN(CHK_MAP, e >> 5, n_words)) ws.bm[e >> 5] = 0u;
         uint64_t bands = __ballot(valid && (e >> 31));
         while (bands) {
             const int j = __ffsll((unsigned long long) bands) - 1;
@@ -353,7 +412,7 @@ __device__ __forceinline__ Chunk load_chunk(const uint2 *ents, uint32_t row, uin
     // entries all lie past the degree load nothing; inside a lane, entries past the degree are row padding, masked
     // by position and never used.
     Chunk c;
-    if (base + 4u * (uint32_t) lane < deg) {
+    if (base + 4u * (uint32_t) lane < deg && TLM_IN(CHK_CHUNK, (uint64_t) row + base + 4u * (uint32_t) lane + 3u, TLM_N_ENT)) {
         const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + base + 4u * (uint32_t) lane);
         const uint4 lo = p[0], hi = p[1];
         c.nb[0] = lo.x; c.mb[0] = lo.y; c.nb[1] = lo.z; c.mb[1] = lo.w;
@@ -378,6 +437,13 @@ __device__ __forceinline__ bool lane_load(const uint2 *ents, uint32_t row, uint3
 #else
     const uint4 *p = reinterpret_cast<const uint4 *>(ents + row + (act ? first : base));
 #endif
+    // (an EMPTY row at the very end of the arrays starts where they end: its inactive lanes read "lane 0's entries" there,
+    // K entries of the 256 zero entries of slack behind the last row -- the one legitimate use of that slack)
+    if (!TLM_IN(CHK_LIST8, (uint64_t) row + (act ? first : base) + (uint32_t) K - 1u, TLM_N_ENT + (deg == 0u ? (uint32_t) K : 0u))) {
+#pragma unroll
+        for (int k = 0; k < K; k++) nb[k] = mb[k] = 0u;
+        return false;
+    }
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
         const uint4 v = p[j];      // (non-temporal loads were tried: 120 -> 179 ms, the lists do get reused in L2)
@@ -398,6 +464,13 @@ __device__ __forceinline__ void lane_load_cw(const uint32_t *met, const uint16_t
     const uint32_t off = first < deg ? row + first : 0u;     // rows start at multiples of 8 entries: 32-byte / 16-byte aligned
     struct alignas(K == 6 ? 8 : 16) Met { uint32_t v[K]; };
     struct alignas(K == 6 ? 4 : K == 12 ? 8 : 2 * K) Ids { uint32_t v[K / 2]; };
+    if (!TLM_IN(CHK_LISTC, (uint64_t) off + (uint32_t) K - 1u, TLM_N_ENT)) {
+#pragma unroll
+        for (int k = 0; k < K; k++) mb[k] = 0u;
+#pragma unroll
+        for (int j = 0; j < K / 2; j++) w[j] = 0x80008000u;
+        return;
+    }
     const Met m = *reinterpret_cast<const Met *>(met + off);
     const Ids ww = *reinterpret_cast<const Ids *>(d16 + off);
 #pragma unroll
@@ -836,7 +909,7 @@ __device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng
         }
         for (uint32_t base = 0; base < deg; base += 64) {
             const uint32_t i = base + lane;
-            const bool valid = i < deg;
+            const bool valid = i < deg && TLM_IN(CHK_SERIAL, (uint64_t) row + i, TLM_N_ENT);
             const uint2 ent = valid ? a.ents[row + i] : make_uint2(0u, 0u);
             const uint32_t nbr = ent.x & 0x7FFFFFFFu;
             if (pass == 0) {
@@ -902,12 +975,15 @@ struct PathRing {
     uint32_t *ring;     // LDS: [0, 32) edge indices, [32, 64) nodes
     uint32_t base;      // index of the first edge held in the ring
     uint32_t cnt;       // edges held
+#ifdef TLM_CHECKED
+    uint32_t cap;       // entries of the wave's path arrays
+#endif
 };
 
 __device__ __forceinline__ void ring_flush(PathRing &pr, const WaveScratch &ws, int lane) {
     if (pr.cnt != 0u) {
         const uint32_t j = (uint32_t) lane & (PATH_RING - 1u);
-        if (j < pr.cnt) {
+        if (j < pr.cnt && TLM_IN(CHK_PATH, pr.base + j + 1u, pr.cap)) {
             const uint32_t v = pr.ring[lane];
             if (lane < (int) PATH_RING) ws.pe[pr.base + j] = v;
             else ws.pn[pr.base + j + 1u] = v;
@@ -960,6 +1036,9 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
     vs.bm = ws.bm;
     for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
     PathRing pr{ring, 0u, 0u};
+#ifdef TLM_CHECKED
+    pr.cap = a.cap;
+#endif
     uint32_t n = start;
     uint32_t m = 0;          // p.edges_.size()
     uint32_t nlog = 0;       // marks that went to the HBM map (ids outside the LDS band)
@@ -981,7 +1060,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         win[d >> 5] |= 1u << (d & 31u);
     }
     wave_sync();
-    uint2 rec = scalar_load_u2(a.rows, n);
+    uint2 rec = row_record(a.rows, n);
     StepClock clk;
     clk.start();
     for (;;) {                                          // :48
@@ -992,7 +1071,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                     status = ST_SCRATCH_OVF;
                     break;
                 }
-                if (lane == 0) ws.lg[nlog] = 0x80000000u | (vs.lo >> 5);
+                if (lane == 0 && TLM_IN(CHK_LOG, nlog, a.cap)) ws.lg[nlog] = 0x80000000u | (vs.lo >> 5);
                 nlog++;
                 band_slide((lds_u32 *) win, (glb_u32 *) ws.bm, cold_args()->bm_words - WALK_RNG_WORDS, vs.lo, want, lane);
                 vs.lo = want;
@@ -1042,12 +1121,12 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                     have_pend = 0u;
                     if (m >= 1) acc -= edge_delta(a.qt, rfl(ws.pe[m - 1]));
                     const uint32_t back = rfl(ws.pn[m]);
-                    const uint2 brec = a.rows[back];
+                    const uint2 brec = row_record(a.rows, back);
                     const uint32_t brow = rfl(brec.x);
                     const uint32_t bdeg = rfl(brec.y) & 0xFFFFFFu;
                     for (uint32_t base = 0; base < bdeg && !t; base += 64) {
                         const uint32_t i = base + lane;
-                        const bool valid = i < bdeg;
+                        const bool valid = i < bdeg && TLM_IN(CHK_BACKPROBE, (uint64_t) brow + i, TLM_N_ENT);
                         const uint32_t nbr = valid ? (a.ents[brow + i].x & 0x7FFFFFFFu) : 0u;
                         if (__ballot(valid && !visited_test(vs, valid ? nbr : vs.lo))) t = true;
                     }
@@ -1058,18 +1137,18 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
                 n = rfl(ws.pn[m]);                      // :98
                 {   // the new last edge's increment becomes the pending one again
                     const uint32_t le = rfl(ws.pe[m - 1]);
-                    const uint2 qt = scalar_load_u2(a.qt, le);
+                    const uint2 qt = qt_record(a.qt, le);
                     pend_qs = qt.x;
                     pend_ts = qt.y;
                     have_pend = 1u;
                 }
-                rec = scalar_load_u2(a.rows, n);
+                rec = row_record(a.rows, n);
                 continue;
             }
             break;                                      // :101
         }
         // ---- advance (:118-123)
-        rec = scalar_load_u2(a.rows, s.nbr);    // the next step's row record: requested before this step's bookkeeping
+        rec = row_record(a.rows, s.nbr);        // the next step's row record: requested before this step's bookkeeping
         if (__builtin_expect(m + 2 > a.cap || nlog + 1 > a.cap, 0)) {
             status = ST_SCRATCH_OVF;
             break;
@@ -1081,7 +1160,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
             pr.ring[pr.cnt] = eidx;                                             // edge m
             pr.ring[PATH_RING + pr.cnt] = s.nbr;                                // node m + 1
             if (md < WIN_BITS) atomicOr(win + (md >> 5), 1u << (md & 31u));     // :123 (ds_or_b32)
-            else if (mark_far) {
+            else if (mark_far && TLM_IN(CHK_MAP, s.nbr, TLM_N_NODES) && TLM_IN(CHK_LOG, nlog, a.cap)) {
                 ws.bm[s.nbr >> 5] |= 1u << (s.nbr & 31);
                 ws.lg[nlog] = s.nbr;
             }
@@ -1099,7 +1178,7 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         pend_ts = 3u;
 #else
         {
-            const uint2 qt = scalar_load_u2(a.qt, eidx);
+            const uint2 qt = qt_record(a.qt, eidx);
             pend_qs = qt.x;
             pend_ts = qt.y;
         }
@@ -1466,13 +1545,13 @@ __device__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int
 __device__ __forceinline__ void visited_set(const Visited &vs, uint32_t n) {
     const uint32_t d = n - vs.lo;
     if (d < WIN_BITS) atomicOr(vs.win + (d >> 5), 1u << (d & 31u));
-    else vs.bm[n >> 5] |= 1u << (n & 31);
+    else if (TLM_IN(CHK_MAP, n, TLM_N_NODES)) vs.bm[n >> 5] |= 1u << (n & 31);
 }
 
 __device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
     const uint32_t d = n - vs.lo;
     if (d < WIN_BITS) atomicAnd(vs.win + (d >> 5), ~(1u << (d & 31u)));
-    else vs.bm[n >> 5] &= ~(1u << (n & 31));
+    else if (TLM_IN(CHK_MAP, n, TLM_N_NODES)) vs.bm[n >> 5] &= ~(1u << (n & 31));
 }
 
 template <bool SQRT, bool ACCOUNT>
@@ -1483,13 +1562,16 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     vs.lo = start > WIN_BITS / 2 ? (start - WIN_BITS / 2) & ~31u : 0u;
     vs.bm = ws.bm;
     for (uint32_t i = lane; i < WIN_WORDS; i += 64) win[i] = 0u;
-    const uint32_t first = rfl(a.rows[start].x) + first_slot;
-    const uint2 ent0 = a.ents[first];
+    const uint32_t first = rfl(row_record(a.rows, start).x) + first_slot;
+    const uint2 ent0 = TLM_IN(CHK_LIST8, first, TLM_N_ENT) ? a.ents[first] : make_uint2(start, 0u);
     const uint32_t second = rfl(ent0.x & 0x7FFFFFFFu);
     const bool second_anchor = rfl(ent0.x >> 31) != 0;
-    const int64_t len0 = (int64_t) a.node_len[start_ref];
+    const int64_t len0 = TLM_IN(CHK_NODE_TABLE, start_ref, TLM_N_NODES) ? (int64_t) a.node_len[start_ref] : 0;
     uint32_t m = 1, nlog = 0;           // nlog: marks that went to the HBM map
     PathRing pr{ring, 1u, 0u};          // edge 0 and nodes 0, 1 are written directly below
+#ifdef TLM_CHECKED
+    pr.cap = a.cap;
+#endif
     uint32_t steps = 0;
     uint64_t evals = 0;
     uint64_t lbytes = 0;     // ACCOUNT only
@@ -1504,7 +1586,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     wave_sync();
     if (lane == 0) {
         visited_set(vs, second);                            // :221
-        if (second - vs.lo >= WIN_BITS) ws.lg[0] = second;
+        if (second - vs.lo >= WIN_BITS && TLM_IN(CHK_LOG, 0u, a.cap)) ws.lg[0] = second;
     }
     if (second - vs.lo >= WIN_BITS) nlog = 1;               // start lies inside the band by construction
     wave_sync();
@@ -1516,7 +1598,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
         uint32_t skip_n_best = 0;
         bool went_back = false;
         uint32_t node = second;
-        uint2 rec = scalar_load_u2(a.rows, node);
+        uint2 rec = row_record(a.rows, node);
         for (;;) {                                          // :243
             {   // keep the band around the walk (see band_slide)
                 const uint32_t want = band_base_for(node);
@@ -1525,7 +1607,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                         status = ST_SCRATCH_OVF;
                         break;
                     }
-                    if (lane == 0) ws.lg[nlog] = 0x80000000u | (vs.lo >> 5);
+                    if (lane == 0 && TLM_IN(CHK_LOG, nlog, a.cap)) ws.lg[nlog] = 0x80000000u | (vs.lo >> 5);
                     nlog++;
                     band_slide((lds_u32 *) win, (glb_u32 *) ws.bm, a.bm_words - WALK_RNG_WORDS, vs.lo, want, lane);
                     vs.lo = want;
@@ -1570,10 +1652,10 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 node = rfl(ws.pn[m]);
                 if (lane == 0) visited_clear(vs, node);     // :262,284,335
                 wave_sync();
-                rec = scalar_load_u2(a.rows, node);
+                rec = row_record(a.rows, node);
                 continue;
             }
-            rec = scalar_load_u2(a.rows, chosen_nbr);       // the next step's row record, requested before the bookkeeping
+            rec = row_record(a.rows, chosen_nbr);           // the next step's row record, requested before the bookkeeping
             if (m + 2 > a.cap || nlog + 1 > a.cap) {
                 status = ST_SCRATCH_OVF;
                 break;
@@ -1584,7 +1666,7 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                 pr.ring[pr.cnt] = eidx;                     // edge m
                 pr.ring[PATH_RING + pr.cnt] = chosen_nbr;   // node m + 1
                 visited_set(vs, node);                      // :355 marks the node being left
-                if (far_mark) ws.lg[nlog] = node;
+                if (far_mark && TLM_IN(CHK_LOG, nlog, a.cap)) ws.lg[nlog] = node;
             }
             if (far_mark) nlog++;
             m++;
@@ -1603,7 +1685,8 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
     // walk depends on it (:372-384 look at it once, at the end), so it is summed here, from the finished path, by all
     // lanes -- not edge by edge inside the step loop.
     int64_t part = 0;
-    for (uint32_t i = lane; i + 1u < m; i += 64) part += edge_delta(a.qt, ws.pe[i]);
+    for (uint32_t i = lane; i + 1u < m; i += 64)
+        if (TLM_IN(CHK_PATH, i, a.cap)) part += edge_delta(a.qt, ws.pe[i]);
     for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
     const int64_t len_final = len0 + (int64_t) __shfl(part, 0);
     if (all_ok && status != ST_SCRATCH_OVF) status = len_final < 0 ? ST_NEGATIVE : ST_ACCEPTED;   // :372-384
@@ -1724,6 +1807,7 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_MC_WAVES) void walk_mc_kernel(WalkA
         const uint64_t rb = (uint64_t) ca->rebuild_attempts;
         const uint32_t a_rank = (uint32_t) (unit / rb);
         const uint32_t r = (uint32_t) (unit % rb);
+        if (!TLM_IN(CHK_ANCHOR, a_rank, ca->n_anchors)) continue;
         const uint32_t start = rfl(ca->w_anchors[a_rank]);
         const uint32_t start_ref = rfl(ca->anchors[a_rank]);        // the anchor's reference index
         const int metric = slot1 ? ca->metric1 : ca->metric;
@@ -1802,11 +1886,48 @@ int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric) {
     return n;
 }
 
-void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+#ifdef TLM_CHECKED
+static void chk_arm(hipStream_t s, const WalkArgs &a) {
+    ChkLimits lim{a.n_ent, a.n_nodes, a.n_anchors};
+    if (const char *e = getenv("TLM_CHECK_SHRINK"))        // the check's own test: pretend the list arrays are shorter
+        lim.n_ent = (unsigned long long) ((double) lim.n_ent * atof(e));
+    unsigned long long z[4] = {0, 0, 0, 0};
+    (void) hipStreamSynchronize(s);
+    const hipError_t e1 = hipMemcpyToSymbol(HIP_SYMBOL(tlm_chk), &lim, sizeof(lim));
+    const hipError_t e2 = hipMemcpyToSymbol(HIP_SYMBOL(tlm_oob), z, sizeof(z));
+    if (getenv("TLM_CHECK_VERBOSE"))
+        fprintf(stderr, "[checked build] limits: %llu entries, %u nodes, %u anchors, cap %u, map words %u (%s, %s)\n", lim.n_ent, lim.n_nodes,
+                lim.n_anchors, a.cap, a.bm_words, hipGetErrorString(e1), hipGetErrorString(e2));
+}
+static int chk_collect(hipStream_t s, const char *kernel) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    (void) hipStreamSynchronize(s);
+    const hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(tlm_oob), sizeof(h));
+    if (getenv("TLM_CHECK_VERBOSE"))
+        fprintf(stderr, "[checked build] %s: read-back %s; site %llu index %llu limit %llu count %llu\n", kernel, hipGetErrorString(e), h[0],
+                h[1], h[2], h[3]);
+    if (e != hipSuccess) {
+        tlm_set_error("checked build: cannot read the offence record: %s", hipGetErrorString(e));
+        return 1;
+    }
+    if (!h[0]) return 0;
+    tlm_set_error("checked build: %s formed an index outside its array %llu time(s); first: site %llu, index %llu, limit %llu",
+                  kernel, h[3], h[0], h[1], h[2]);
+    return 1;
+}
+#endif
+
+int tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+#ifdef TLM_CHECKED
+    chk_arm(s, a);
+#endif
     if (account) {      // same walks, plus the layout-byte count (never the timed launch)
         if (sqrt_metric) hipLaunchKernelGGL((walk_mc_kernel<true, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
         else hipLaunchKernelGGL((walk_mc_kernel<false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
-        return;
+#ifdef TLM_CHECKED
+        return chk_collect(s, "walk_mc_kernel (accounting)");
+#endif
+        return 0;
     }
 #ifdef TLM_TIMING
     {
@@ -1830,14 +1951,28 @@ void tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const 
                     (double) h[0] / h[5], (double) h[1] / h[5], (double) h[2] / h[5], (double) h[3] / h[5], h[4] >> 32);
     }
 #endif
+#ifdef TLM_CHECKED
+    return chk_collect(s, "walk_mc_kernel");
+#endif
+    return 0;
 }
 
-void tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+int tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+#ifdef TLM_CHECKED
+    chk_arm(s, a);
+#endif
     if (account) {
         if (sqrt_metric) hipLaunchKernelGGL((walk_det_kernel<true, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
         else hipLaunchKernelGGL((walk_det_kernel<false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
-        return;
+#ifdef TLM_CHECKED
+        return chk_collect(s, "walk_det_kernel (accounting)");
+#endif
+        return 0;
     }
     if (sqrt_metric) hipLaunchKernelGGL(walk_det_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(walk_det_kernel<false>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+#ifdef TLM_CHECKED
+    return chk_collect(s, "walk_det_kernel");
+#endif
+    return 0;
 }

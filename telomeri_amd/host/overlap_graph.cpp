@@ -304,11 +304,21 @@ int OverlapGraph::upload_helper_main() {
             sc.scan_only_ = true;
             const auto t_scan = std::chrono::steady_clock::now();
             const char *dir = ::access("/dev/shm", W_OK) == 0 ? "/dev/shm" : "/tmp";
-            const std::string idx = std::string(dir) + "/tlm_index_" + std::to_string((long) ::getpid()) + "_" + std::to_string(serial++);
-            if (sc.load(line.c_str() + 2) && sc.save_index(idx.c_str()))
+            // an unpredictable name (mkstemp reserves it; save_index creates the file itself, exclusively, so the
+            // reservation is dropped first), gone again on every path that does not hand it to the other process
+            std::string idx = std::string(dir) + "/tlm_index_" + std::to_string((long) ::getpid()) + "_" + std::to_string(serial++) + "_XXXXXX";
+            const int reserve = ::mkstemp(&idx[0]);
+            if (reserve >= 0) {
+                ::close(reserve);
+                ::unlink(idx.c_str());
+            }
+            if (reserve >= 0 && sc.load(line.c_str() + 2) && sc.save_index(idx.c_str())) {
                 std::printf("OK %s\t%.0f\n", idx.c_str(),
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count());
-            else std::printf("ERR cannot index %s\n", line.c_str() + 2);
+            } else {
+                if (reserve >= 0) ::unlink(idx.c_str());
+                std::printf("ERR cannot index %s\n", line.c_str() + 2);
+            }
         } else {
             std::printf("ERR bad request\n");
         }

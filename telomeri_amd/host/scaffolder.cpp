@@ -129,8 +129,13 @@ bool Scaffolder::load(const char *filename) {
 // index file: "TLMIDX1\n", u64 names, then per name u32 length + bytes; u64 sequence slots, then per slot u64 offset,
 // u64 length, u8 present
 bool Scaffolder::save_index(const char *index_file) const {
-    FILE *f = std::fopen(index_file, "wb");
-    if (!f) return false;
+    // a NEW file of this user only: never through a link somebody left in a shared directory, never over an existing file
+    const int wfd = ::open(index_file, O_CREAT | O_EXCL | O_WRONLY | O_NOFOLLOW | O_CLOEXEC, 0600);
+    FILE *f = wfd >= 0 ? ::fdopen(wfd, "wb") : nullptr;
+    if (!f) {
+        if (wfd >= 0) ::close(wfd);
+        return false;
+    }
     std::fputs("TLMIDX1\n", f);
     const uint64_t nn = names_.size(), ns = where_.size();
     std::fwrite(&nn, 8, 1, f);
@@ -146,15 +151,29 @@ bool Scaffolder::save_index(const char *index_file) const {
         std::fwrite(rec, 8, 2, f);
         std::fwrite(&present, 1, 1, f);
     }
-    return std::fclose(f) == 0;
+    const bool written = !std::ferror(f);
+    if (std::fclose(f) != 0 || !written) {
+        ::unlink(index_file);
+        return false;
+    }
+    return true;
 }
 
 bool Scaffolder::load_index(const char *index_file, const char *filename) {
-    FILE *f = std::fopen(index_file, "rb");
-    if (!f) return false;
+    const int rfd = ::open(index_file, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    FILE *f = rfd >= 0 ? ::fdopen(rfd, "rb") : nullptr;
+    if (!f) {
+        if (rfd >= 0) ::close(rfd);
+        return false;
+    }
+    // the counts in the file are bounded by the file itself before anything is sized from them: a name costs at least 4
+    // bytes, a sequence record 17
+    struct stat st;
+    const uint64_t file_bytes = ::fstat(rfd, &st) == 0 ? (uint64_t) st.st_size : 0;
     char magic[8];
     uint64_t nn = 0, ns = 0;
-    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "TLMIDX1\n", 8) == 0 && std::fread(&nn, 8, 1, f) == 1;
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "TLMIDX1\n", 8) == 0 && std::fread(&nn, 8, 1, f) == 1
+              && nn <= file_bytes / 4;
     std::vector<std::string> names;
     std::vector<View> where;
     if (ok) names.resize(nn);
@@ -162,11 +181,12 @@ bool Scaffolder::load_index(const char *index_file, const char *filename) {
         uint32_t len = 0;
         ok = std::fread(&len, 4, 1, f) == 1;
         if (ok) {
-            names[i].resize(len);
-            ok = len == 0 || std::fread(&names[i][0], 1, len, f) == len;
+            ok = len <= file_bytes;
+            if (ok) names[i].resize(len);
+            ok = ok && (len == 0 || std::fread(&names[i][0], 1, len, f) == len);
         }
     }
-    ok = ok && std::fread(&ns, 8, 1, f) == 1;
+    ok = ok && std::fread(&ns, 8, 1, f) == 1 && ns <= file_bytes / 17;
     const int fd = ok ? ::open(filename, O_RDONLY) : -1;
     ok = ok && (fd >= 0 || ns == 0);
     const int file = (int) files_.size();

@@ -767,3 +767,50 @@ def test_walk_accounting_counts_layout_bytes_and_changes_nothing(ctx):
         # MC evals stop at a forcing anchor edge, the list is read whole: evals <= entries read <= evals' lists padded by < 12
         assert lb >= 6 * evals + extra * steps
         assert lb <= 8 * (evals + 12 * steps) + extra * steps + 8 * 600 * steps
+
+
+def test_mark_log_of_a_walk_that_jumps_and_backtracks(ctx, monkeypatch):
+    """The mark log's worst case: ids that jump further than the LDS band at every step (no locality order:
+    TLM_NO_LOCALIZE) log a far mark AND a band move per push, and every dead-end stub adds a go-back with another band move.
+    A chain of 60 000 reads with a dead-end stub at each -- heavy enough that the roulette all but always tries it first --
+    walked end to end with unlimited backtracking needs about 2.4 N log entries (0.86 N far marks: the band holds a seventh of
+    the ids; 1.5 N band moves): more than the 2 N + 64 the re-run at full capacity used to have, within the 3 N + 64 it has now."""
+    monkeypatch.setenv("TLM_NO_LOCALIZE", "1")
+    rng = np.random.default_rng(3)
+    chain = 60_000
+    n = 2 + 2 * chain                           # two anchors, the chain, one stub per chain node
+    ids = rng.permutation(n)                    # random ids: consecutive chain nodes lie far apart
+    a0, a1 = int(ids[0]), int(ids[1])
+    cid = ids[2:2 + chain]
+    sid = ids[2 + chain:]
+    rows = [[] for _ in range(n)]
+    rows[a0] = [int(cid[0])]
+    for k in range(chain):
+        nxt = int(cid[k + 1]) if k + 1 < chain else a1
+        rows[int(cid[k])] = [int(sid[k]), nxt]  # the stub first: the roulette meets it with a heavy weight
+        rows[int(sid[k])] = [int(cid[k])]       # its only neighbour is visited: a dead end
+    rows[a1] = [int(cid[-1])]
+    row_ptr = np.zeros(n + 1, np.uint64)
+    row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    nbr = np.concatenate([np.array(r, np.uint32) for r in rows])
+    a = nbr.shape[0]
+    es = np.ones(a, np.float32)
+    stub_entry = row_ptr[cid].astype(np.int64)              # the stub is the first entry of every chain node's list
+    es[stub_entry] = 1.0e6
+    os_ = es.copy()
+    q_start = np.full(a, 10, np.uint32)
+    t_start = np.full(a, 3, np.uint32)
+    node_len = np.full(n, 1000, np.uint32)
+    anchors = np.zeros(n, np.uint8)
+    anchors[[a0, a1]] = 1
+    c2 = capi.Context(0)
+    dg = c2.graph_from_csr(row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    wp = capi.WalkParams.default(rb_att=6, bt_att=1_000_000, len_thr=1 << 40)
+    og = po.Graph.from_csr(row_ptr, nbr, q_start, t_start, os_, es, node_len, anchors)
+    ps = dg.walk_mc(capi.METRIC_ES, wp)
+    ops, _, ostats = og.walk_mc(po.METRIC_ES, H.to_oracle_wp(wp), po.SEED_PER_WALK)
+    H.assert_stats_equal(ps.unit_stats(), ostats)
+    H.assert_paths_equal(ps.to_host(), ops)
+    st = ps.unit_stats()
+    assert ps.counters.kernel_launches >= 2, "the walks were meant to outgrow the default path buffer"
+    assert (st["status"] == 1).any() and int(st["steps"].max()) > 2 * chain      # chain + stubs + the scans after each go-back

@@ -267,6 +267,13 @@ def test_device_tokeniser_verdict_on_malformed_text(name, text, expect_clean):
             got = paf.columns(0)
             for k in cols:
                 np.testing.assert_array_equal(got[k], np.array(cols[k]), err_msg=k)
+    else:
+        # a handle that has refused a file is good for nothing but destruction: the refused file's names sit in its
+        # dictionary (include/telomeri_hip.h) -- adding more or finishing is an error, not a wrong numbering
+        with pytest.raises(capi.TlmError, match="refused"):
+            paf.add_text((L * 2).encode(), anchors=False)
+        with pytest.raises(capi.TlmError, match="refused"):
+            paf.finish()
 
 
 def test_cli_falls_back_to_the_host_tokeniser(binary):

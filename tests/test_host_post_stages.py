@@ -210,3 +210,20 @@ def test_binary_dump_gives_the_text_dump_result(post, name):
             fh.truncate(max(0, nodes.nbytes - 4))
         bad = subprocess.run([post, "--binary", os.path.join(tmp, "bin"), reads, contigs, out], capture_output=True, text=True, timeout=120)
         assert bad.returncode == 1 and "expected" in bad.stderr
+
+
+def test_sequence_index_file_is_created_exclusively(post, tmp_path):
+    """The index a Scaffolder leaves for another process (Scaffolder::save_index; the upload helper writes it into /dev/shm)
+    is created O_EXCL | O_NOFOLLOW with mode 0600: a link or a file somebody put at its name is not written through."""
+    fa = tmp_path / "reads.fa"
+    fa.write_text(">r1\nACGT\n>r2\nGGCC\n")
+    env = dict(os.environ, TLM_POST_VIA_INDEX="1")
+    ok = subprocess.run([post, "--list-sequences", str(fa)], capture_output=True, text=True, env=env)
+    assert ok.returncode == 0 and "names 2 sequences 2" in ok.stdout
+    assert not os.path.exists(str(fa) + ".index")                  # removed after use
+    victim = tmp_path / "victim"
+    victim.write_text("precious")
+    os.symlink(victim, str(fa) + ".index")
+    bad = subprocess.run([post, "--list-sequences", str(fa)], capture_output=True, text=True, env=env)
+    assert bad.returncode == 1
+    assert victim.read_text() == "precious"
