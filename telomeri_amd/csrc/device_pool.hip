@@ -1,19 +1,30 @@
 // telomeri_amd/csrc/device_pool.hip -- the library's own device-memory cache (one per device, process lifetime).
 //
 // Every device buffer of the library (graph arrays, build temporaries, walk workspaces, path sets) comes from here.
-// A build of the A. thaliana-shaped graph allocates ~60 buffers, 30 GB in all; hipMalloc / hipFree of GB-sized buffers
-// cost milliseconds each and synchronise the device, and the HIP stream-ordered pool (hipMallocAsync on the device's
-// DEFAULT pool, round 1) turned out to be both a process-wide side effect (its release threshold had to be changed)
-// and slow to re-use blocks freed on another stream (a second graph build took 10x the first one).  So: blocks are
-// hipMalloc'd once, kept in a size-ordered free list when released, and handed out again to requests of (nearly) the
-// same size.  Ordering between the old and the new user of a block:
+// A build of the A. thaliana-shaped graph allocates ~80 buffers, 30 GB in all; hipMalloc / hipFree of GB-sized buffers
+// cost milliseconds each (seconds, on a device that has just seen another process give back tens of GB) and synchronise
+// the device, and the HIP stream-ordered pool (hipMallocAsync on the device's DEFAULT pool, round 1) turned out to be both
+// a process-wide side effect and slow to re-use blocks freed on another stream.  So: memory is obtained from the driver in
+// SEGMENTS (one hipMalloc each), handed out as BLOCKS, kept when released, and handed out again.
+//
+// Round 3: a block may be PART of a segment.  A request that finds no released block of (nearly) its own size takes the
+// front of the smallest released block that holds it and leaves the rest -- the overlap text of a job (15.6 GB for the
+// A. thaliana shape, 61 GB for chr1) is dead once it has been tokenised, and the graph build that follows it used to ask
+// the driver for its eighty buffers while that block sat in the cache: 53 GB held at "graph loaded" for a 17.5 GB graph,
+// 216 GB for the 69 GB one.  Released neighbours of one segment are merged at once, so a job that has released everything
+// is back to whole segments, and a repeated sequence of requests finds the same memory in the same state.
+//
+// Ordering between the old and the new user of a piece of memory:
 //   * same stream        -> stream order, nothing to do;
-//   * another stream     -> the new stream waits for an event recorded on the old stream at release time;
+//   * another stream     -> the new stream waits for the event recorded on the old stream at release time.  Events are
+//                           shared (reference-counted): a split hands the whole's events to both parts, a merge collects
+//                           the parts' events, and an event returns to the spare list when its last block lets go of it;
 //   * released "synced"  -> the caller has synchronised the device (graph / path-set destruction), nothing to wait for.
 // Nothing here touches the device's default memory pool or any other process-wide HIP setting.  tlm_pool_trim returns
-// every cached block to the driver (tlm_ctx_trim in the ABI).
+// every wholly released segment to the driver (tlm_ctx_trim in the ABI).
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 
@@ -23,22 +34,65 @@ namespace {
 
 const hipStream_t DEAD_STREAM = (hipStream_t) (intptr_t) -1;     // the stream a block was used on no longer exists
 
-struct Block {
-    void *p = nullptr;
+struct Segment {
+    char *base = nullptr;
     size_t bytes = 0;
-    hipStream_t stream = nullptr;      // last user
-    hipEvent_t ev = nullptr;           // recorded on `stream` at release (created on first need)
-    bool ev_pending = false;
+    std::map<size_t, struct Block *> blocks;       // by offset: every byte of the segment belongs to exactly one block
+};
+
+// An event recorded at a release, shared by every block that has to wait for it (a split hands it to both parts, a merge
+// collects the parts' events); it goes back to the pool's spare events when the last block lets go of it.
+struct EventPool {
+    std::mutex mu;
+    std::vector<hipEvent_t> spare;
+    hipEvent_t take() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!spare.empty()) {
+                hipEvent_t e = spare.back();
+                spare.pop_back();
+                return e;
+            }
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        return e;
+    }
+    void give(hipEvent_t e) {
+        std::lock_guard<std::mutex> lk(mu);
+        spare.push_back(e);
+    }
+};
+struct Recorded {
+    hipEvent_t ev;
+    hipStream_t stream;         // the stream it was recorded on
+    EventPool *home;
+    Recorded(hipEvent_t e, hipStream_t s, EventPool *h) : ev(e), stream(s), home(h) {}
+    Recorded(const Recorded &) = delete;            // one owner of the handle: a copy's destructor would give it back early
+    Recorded &operator=(const Recorded &) = delete;
+    ~Recorded() { home->give(ev); }
+};
+typedef std::shared_ptr<Recorded> Pending;
+
+struct Block {
+    Segment *seg = nullptr;
+    size_t off = 0, bytes = 0;
+    bool live = false;
+    hipStream_t stream = nullptr;           // last user
+    std::vector<Pending> pend;              // released blocks: what a user on another stream has to wait for
+    void *ptr() const { return seg->base + off; }
 };
 
 struct Pool {
     std::mutex mu;
     std::unordered_map<void *, Block *> live;
-    std::multimap<size_t, Block *> cached;
+    std::multimap<size_t, Block *> cached;          // released blocks by size
+    EventPool events;
     tlm_memory_info info{};
 };
 
 constexpr int MAX_DEVICES = 64;
+constexpr size_t SPLIT_MIN = 1u << 20;              // requests below 1 MiB never carve up a larger block
 
 Pool &pool_of(int device) {
     static Pool *pools = new Pool[MAX_DEVICES];      // never destroyed: path sets may be released during interpreter exit
@@ -51,10 +105,14 @@ size_t round_size(size_t bytes) {
     return (bytes + ((1u << 21) - 1)) & ~(size_t) ((1u << 21) - 1);      // 2 MiB: the driver's large-page granularity
 }
 
-void release_block_to_driver(Block *b) {
-    if (b->ev) (void) hipEventDestroy(b->ev);
-    (void) hipFree(b->p);
-    delete b;
+void uncache(Pool &P, Block *b) {
+    auto range = P.cached.equal_range(b->bytes);
+    for (auto it = range.first; it != range.second; ++it)
+        if (it->second == b) {
+            P.cached.erase(it);
+            P.info.cached_bytes -= b->bytes;
+            return;
+        }
 }
 
 thread_local double t_malloc_ms = 0;
@@ -70,21 +128,39 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
     Pool &P = pool_of(dev);
     const size_t need = round_size(bytes);
     Block *b = nullptr;
+    std::vector<Pending> waits;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.cached.lower_bound(need);
-        // a block may be up to 1/8 (+ 64 KiB) larger than the request: builds repeat their sizes exactly, so the slack
-        // only matters for inputs that change a little between calls
-        if (it != P.cached.end() && it->first <= need + need / 8 + (64u << 10)) {
+        // The smallest released block that holds the request.  Taken whole when it is not much larger (1/8 + 64 KiB; half
+        // again for requests of 256 MiB and more: a job's big buffers follow each other, each a little smaller than one the
+        // previous stage has just let go); otherwise its front is split off, unless the request is small.
+        const size_t slack = need >= (256u << 20) ? need / 2 : need / 8 + (64u << 10);
+        if (it != P.cached.end() && (it->first <= need + slack || need >= SPLIT_MIN)) {
             b = it->second;
             P.cached.erase(it);
             P.info.cached_bytes -= b->bytes;
             P.info.reuses++;
+            if (b->bytes > need + slack) {          // split: [off, off + need) is taken, the rest stays released
+                Block *rest = new Block();
+                rest->seg = b->seg;
+                rest->off = b->off + need;
+                rest->bytes = b->bytes - need;
+                rest->stream = b->stream;
+                rest->pend = b->pend;               // both parts wait for whoever used the whole
+                b->bytes = need;
+                b->seg->blocks[rest->off] = rest;
+                P.cached.emplace(rest->bytes, rest);
+                P.info.cached_bytes += rest->bytes;
+            }
+            waits.swap(b->pend);
+            b->live = true;         // (taken: no neighbour's release may merge it while the waits are queued outside the lock)
         }
     }
     if (b) {
-        if (b->ev_pending && b->stream != s) TLM_HIP(hipStreamWaitEvent(s, b->ev, 0));
-        b->ev_pending = false;
+        for (const Pending &w : waits)
+            if (w->stream != s && w->stream != DEAD_STREAM) TLM_HIP(hipStreamWaitEvent(s, w->ev, 0));
+        waits.clear();
     } else {
         const auto t0 = std::chrono::steady_clock::now();
         void *p = nullptr;
@@ -100,9 +176,14 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
             tlm_set_error("device allocation of %zu bytes failed: %s", need, hipGetErrorString(e));
             return TLM_EHIP;
         }
+        Segment *seg = new Segment();
+        seg->base = (char *) p;
+        seg->bytes = need;
         b = new Block();
-        b->p = p;
+        b->seg = seg;
+        b->off = 0;
         b->bytes = need;
+        seg->blocks[0] = b;
         std::lock_guard<std::mutex> lk(P.mu);
         P.info.driver_allocs++;
         P.info.driver_alloc_ms += ms;
@@ -110,11 +191,12 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
     b->stream = s;
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        P.live[b->p] = b;
+        b->live = true;
+        P.live[b->ptr()] = b;
         P.info.live_bytes += b->bytes;
         if (P.info.live_bytes > P.info.peak_live_bytes) P.info.peak_live_bytes = P.info.live_bytes;
     }
-    *out = b->p;
+    *out = b->ptr();
     return TLM_OK;
 }
 
@@ -134,17 +216,48 @@ void tlm_pool_free(void *p, bool device_is_synced) {
         P.live.erase(it);
         P.info.live_bytes -= b->bytes;
     }
-    b->ev_pending = false;
+    // (still marked live: no neighbour's release merges it while the event is recorded outside the lock)
+    b->pend.clear();
     if (!device_is_synced) {
         if (b->stream == DEAD_STREAM) {
             (void) hipDeviceSynchronize();       // its stream is gone: whatever used the block on other streams must end
         } else {
-            if (!b->ev && hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess) b->ev = nullptr;
-            if (b->ev && hipEventRecord(b->ev, b->stream) == hipSuccess) b->ev_pending = true;
-            else (void) hipStreamSynchronize(b->stream);
+            hipEvent_t ev = P.events.take();
+            if (ev && hipEventRecord(ev, b->stream) == hipSuccess) {
+                b->pend.push_back(std::make_shared<Recorded>(ev, b->stream, &P.events));
+            } else {
+                if (ev) P.events.give(ev);
+                (void) hipStreamSynchronize(b->stream);
+            }
         }
     }
     std::lock_guard<std::mutex> lk(P.mu);
+    b->live = false;
+    // merge with released neighbours of the same segment: the events of all parts go along
+    Segment *seg = b->seg;
+    auto self = seg->blocks.find(b->off);
+    auto next = std::next(self);
+    if (next != seg->blocks.end() && !next->second->live) {
+        Block *n = next->second;
+        uncache(P, n);
+        b->bytes += n->bytes;
+        b->pend.insert(b->pend.end(), n->pend.begin(), n->pend.end());
+        seg->blocks.erase(next);
+        delete n;
+    }
+    if (self != seg->blocks.begin()) {
+        auto prev = std::prev(self);
+        if (!prev->second->live) {
+            Block *q = prev->second;
+            uncache(P, q);
+            q->bytes += b->bytes;
+            q->pend.insert(q->pend.end(), b->pend.begin(), b->pend.end());
+            if (q->stream != b->stream) q->stream = b->stream;      // (only a label: the events carry the ordering)
+            seg->blocks.erase(self);
+            delete b;
+            b = q;
+        }
+    }
     P.cached.emplace(b->bytes, b);
     P.info.cached_bytes += b->bytes;
 }
@@ -155,27 +268,48 @@ void tlm_pool_forget_stream(int device, hipStream_t s) {
     std::lock_guard<std::mutex> lk(P.mu);
     for (auto &kv : P.live)
         if (kv.second->stream == s) kv.second->stream = DEAD_STREAM;
-    for (auto &kv : P.cached)
-        if (kv.second->stream == s) {
-            kv.second->stream = DEAD_STREAM;
-            kv.second->ev_pending = false;
-        }
+    for (auto &kv : P.cached) {
+        Block *b = kv.second;
+        if (b->stream == s) b->stream = DEAD_STREAM;
+        for (size_t i = 0; i < b->pend.size();)
+            if (b->pend[i]->stream == s) b->pend.erase(b->pend.begin() + (long) i);      // synchronised: its events have happened
+            else i++;
+    }
 }
 
 void tlm_pool_trim(int device) {
     Pool &P = pool_of(device);
-    std::multimap<size_t, Block *> gone;
+    std::vector<Block *> gone;
+    std::vector<hipEvent_t> events;
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        gone.swap(P.cached);
-        P.info.cached_bytes = 0;
+        for (auto it = P.cached.begin(); it != P.cached.end();) {
+            Block *b = it->second;
+            if (b->off == 0 && b->bytes == b->seg->bytes) {      // a wholly released segment
+                P.info.cached_bytes -= b->bytes;
+                gone.push_back(b);
+                it = P.cached.erase(it);
+            } else {
+                ++it;
+            }
+        }
     }
-    if (gone.empty()) return;
+    {
+        std::lock_guard<std::mutex> lk(P.events.mu);
+        events.swap(P.events.spare);
+    }
+    if (gone.empty() && events.empty()) return;
     int cur = 0;
     (void) hipGetDevice(&cur);
     (void) hipSetDevice(device);
     (void) hipDeviceSynchronize();
-    for (auto &kv : gone) release_block_to_driver(kv.second);
+    for (Block *b : gone) {
+        b->pend.clear();        // (the device is idle; their events return to the spare list and go with the next trim)
+        (void) hipFree(b->seg->base);
+        delete b->seg;
+        delete b;
+    }
+    for (hipEvent_t e : events) (void) hipEventDestroy(e);
     (void) hipSetDevice(cur);
 }
 

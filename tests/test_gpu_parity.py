@@ -814,3 +814,38 @@ def test_mark_log_of_a_walk_that_jumps_and_backtracks(ctx, monkeypatch):
     st = ps.unit_stats()
     assert ps.counters.kernel_launches >= 2, "the walks were meant to outgrow the default path buffer"
     assert (st["status"] == 1).any() and int(st["steps"].max()) > 2 * chain      # chain + stubs + the scans after each go-back
+
+
+def test_pool_splits_and_merges(ctx):
+    """The library's device cache hands out PARTS of released blocks (round 3) and merges released neighbours again: graphs
+    of different sizes built and dropped in changing order settle on the memory the first round obtained (no further
+    driver allocation), their walks stay the oracle's, and when everything has been released a trim returns every byte."""
+    c2 = capi.Context(0)
+    fp = capi.FilterParams.default()
+    sets = {name: synth.make_config(name) for name in ("tiny", "toy", "dense")}
+    wp = capi.WalkParams.default(rb_att=12)
+    want = {}
+    allocs = []
+    for rnd, order in enumerate((("toy", "tiny", "dense"), ("dense", "toy", "tiny"), ("tiny", "dense", "toy"), ("toy", "tiny", "dense"))):
+        graphs = {}
+        for name in order:
+            graphs[name] = H.device_graph(c2, sets[name], fp)
+            ps = graphs[name].walk_mc(capi.METRIC_ES, wp)
+            got = (ps.to_host(), ps.unit_stats())
+            if name not in want:
+                og = H.oracle_graph(sets[name], H.to_oracle_fp(fp))
+                ops, _, ostats = og.walk_mc(po.METRIC_ES, H.to_oracle_wp(wp), po.SEED_PER_WALK)
+                want[name] = (ops, ostats)
+            H.assert_paths_equal(got[0], want[name][0])
+            H.assert_stats_equal(got[1], want[name][1])
+            del ps
+            if name == order[0]:
+                del graphs[name]            # one graph goes while the others are still being built
+        graphs.clear()
+        allocs.append(c2.memory_info().driver_allocs)
+    # a new ORDER of sizes may still need a block the earlier orders did not; an order seen before needs none
+    assert allocs[3] == allocs[2] and allocs[3] - allocs[0] <= 4, allocs
+    mi = c2.memory_info()
+    assert mi.live_bytes < (64 << 20)        # nothing but the context's own small buffers
+    c2.trim()
+    assert c2.memory_info().cached_bytes == 0
