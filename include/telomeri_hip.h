@@ -153,6 +153,11 @@ int tlm_ctx_memory_info(tlm_ctx *ctx, tlm_memory_info *out);
 /* Give the walk workspaces of the context and every cached block of its device back to the driver (graphs and path
  * sets stay).  Waits for the device. */
 int tlm_ctx_trim(tlm_ctx *ctx);
+/* The walk workspaces of the context (the arena accepted paths are collected in, the waves' path buffers and visited maps:
+ * 16 GB after the builders of the A. thaliana-shaped job) go back to the library's CACHE -- not to the driver: what the
+ * job allocates next (the concatenated Path set, its filtered copy) is carved out of them.  For a host that has made its
+ * last walk call; a later walk call simply obtains workspaces again.  Waits for the context's streams. */
+int tlm_ctx_release_workspaces(tlm_ctx *ctx);
 
 /* ---- a2 + a3: filter decision and SI/OS/ES per record -------------------------------------- */
 /* keep[n] (1 = passes OverlapGraph::filter), si/os/es[n] written for EVERY record; any output

@@ -525,6 +525,10 @@ class Context:
         """Walk calls launch the builds of the kernels that also count layout bytes (Counters.layout_bytes); never timed."""
         _check(lib().tlm_ctx_set_walk_accounting(self._h, int(bool(on))), "tlm_ctx_set_walk_accounting")
 
+    def release_workspaces(self) -> None:
+        """tlm_ctx_release_workspaces: the walk workspaces go back to the library's cache (after the last walk call)."""
+        _check(lib().tlm_ctx_release_workspaces(self._h), "tlm_ctx_release_workspaces")
+
     def set_arena_limit(self, nbytes: int) -> None:
         _check(lib().tlm_ctx_set_arena_limit(self._h, nbytes), "tlm_ctx_set_arena_limit")
 

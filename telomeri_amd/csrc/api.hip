@@ -217,6 +217,19 @@ extern "C" int tlm_ctx_trim(tlm_ctx *ctx) {
     return TLM_OK;
 }
 
+extern "C" int tlm_ctx_release_workspaces(tlm_ctx *ctx) {
+    TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_release_workspaces: null ctx");
+    CtxImpl *c = static_cast<CtxImpl *>(ctx);
+    TLM_HIP(hipSetDevice(c->device));
+    TLM_HIP(hipStreamSynchronize(c->stream));
+    if (c->side.stream) TLM_HIP(hipStreamSynchronize(c->side.stream));
+    c->ws.release_scratch();
+    c->ws.release_arena();
+    c->side.ws.release_scratch();
+    c->side.ws.release_arena();
+    return TLM_OK;
+}
+
 extern "C" int tlm_ctx_set_walk_tuning(tlm_ctx *ctx, int waves_per_cu, uint32_t path_capacity) {
     TLM_CHECK(ctx, TLM_EINVAL, "tlm_ctx_set_walk_tuning: null ctx");
     TLM_CHECK(waves_per_cu >= 0 && waves_per_cu <= 32, TLM_EINVAL, "waves_per_cu must be 0..32");

@@ -191,6 +191,9 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
                              "queueing to its end, %.0f ms of it running), then %.0f ms for the paths' views\n", call_ms, c[0].kernel_ms,
                      c[2].kernel_ms, c[2].kernel_busy_ms,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() - call_ms);
+    // the builders of main() are over (Main.cpp:237-243 is the only place that walks): what the job allocates from here on --
+    // paths_ as one set, its filtered copy -- comes out of the workspaces' memory instead of on top of it
+    if (tlm_ctx_release_workspaces(ctx) != TLM_OK) die_tlm("release workspaces");
     if (!packed_) materialiseAll();
 }
 
