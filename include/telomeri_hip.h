@@ -34,6 +34,10 @@
 extern "C" {
 #endif
 
+/* 1: filter_score, graph, walks, path sets.  2: path summaries / fetch, Edge records, stats, the exchange (tlm_dist_*,
+ * tlm_pathset_allgather, tlm_pathset_gather_summaries), memory accounting, PAF text on the device.  3 (additions only):
+ * TLM_EPEER and the fail-together contract of the exchange calls, TLM_RCCL_LIB, tlm_ctx_set_walk_accounting with
+ * tlm_counters.layout_bytes / step_class, tlm_ctx_release_workspaces, tlm_graph_info.phase_host_ms / sync_wait_ms. */
 #define TLM_ABI_VERSION 3
 
 enum {

@@ -68,14 +68,17 @@ def function_of(line, starts):
 
 def attribute(asm, starts):
     res = {}
+    sites = {}
     cur = None
     line = 0
     depth = 0
+    chain = []
     for ln in asm.splitlines():
         m = re.match(r"^(_ZN12_GLOBAL__N_1\d+walk_\w+_kernelILb\dELb\dEEEv8WalkArgs):", ln)
         if m:
             cur = demangle(m.group(1))
             res[cur] = collections.Counter()
+            sites[cur] = collections.Counter()
             depth = 0
             continue
         if cur is None:
@@ -86,6 +89,7 @@ def attribute(asm, starts):
         m = re.match(r"\s+\.loc\s+\d+\s+(\d+)", ln)
         if m:
             line = int(m.group(1))
+            chain = [line] + [int(x) for x in re.findall(r"walk_kernels\.hip:(\d+):", ln.split(";", 1)[1] if ";" in ln else "")[1:]]
             continue
         m = re.search(r"Depth=(\d+)", ln)
         if m and "Loop" in ln:
@@ -95,7 +99,12 @@ def attribute(asm, starts):
         m = re.match(r"\s+(scratch_(?:load|store)_\w+)", ln)
         if m:
             res[cur][(function_of(line, starts), line, m.group(1).split("_")[1], depth)] += 1
-    return res
+            # the call site inside the walk function itself: which instantiation (entries per lane) the code belongs to
+            for c in chain:
+                if function_of(c, starts) in ("mc_walk", "det_walk"):
+                    sites[cur][c] += 1
+                    break
+    return res, sites
 
 
 def main():
@@ -107,7 +116,8 @@ def main():
         shipped = metadata(compile_asm([], os.path.join(tmp, "a.s")))
         asm_g = compile_asm(["-gline-tables-only"], os.path.join(tmp, "g.s"))
     meta_g = metadata(asm_g)
-    att = attribute(asm_g, starts)
+    att, sites = attribute(asm_g, starts)
+    src_lines = open(SRC).read().splitlines()
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
     out = {"source": "telomeri_amd/csrc/walk_kernels.hip", "commit": commit + "+", "kernels": {}}
     for k in sorted(shipped):
@@ -118,6 +128,8 @@ def main():
             e["lines"].add(line)
             e["max_loop_depth"] = max(e["max_loop_depth"], depth)
         out["kernels"][k] = {"as_shipped": shipped[k], "with_line_tables": meta_g.get(k),
+                             "scratch_instructions_by_call_site_in_the_walk": {
+                                 "%d: %s" % (ln, src_lines[ln - 1].strip()[:110]): n for ln, n in sorted(sites.get(k, {}).items(), key=lambda kv: -kv[1])},
                              "scratch_instructions_by_function": {
                                  fn: {"loads": e["loads"], "stores": e["stores"], "max_loop_depth": e["max_loop_depth"],
                                       "source_lines": sorted(e["lines"])[:40]} for fn, e in sorted(by_fn.items(), key=lambda kv: -(kv[1]["loads"] + kv[1]["stores"]))}}
