@@ -461,6 +461,10 @@ def roofline_block(ach, traffic, traffic_source, mc_ms, mc_launches, evals_per_l
                           "8 B row record, 8 B {q_start, t_start}")
     if classes:
         r["step_classes"] = class_shares(classes)       # share of the steps by the form of their selection (accounting launch)
+    if r.get("frac_layout", 0.0) > 1.0:
+        r["frac_layout_note"] = ("frac_layout > 1: the steps ask the memory system for more bytes per second than HBM's 8 TB/s because "
+                                 "the XCDs' L2s serve part of them (whole anchors are dealt to one XCD on graphs with long lists); "
+                                 "traffic_TBps, where a PMC profile of this workload exists, is what left the L2s")
     if r["frac"] > 1.0:
         r["frac_note"] = ("frac > 1: the yardstick (8 B per eval) is SURVEY.md's figure, most steps of this graph read 6-byte "
                           "compact rows; frac_layout is the bounded figure")

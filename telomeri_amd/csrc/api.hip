@@ -633,11 +633,16 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         for (int round = 0; round < 64; round++) {
             a.n_work = n_work;
             a.work_list = work.empty() ? nullptr : u.work_list;
-            // chunk of work items that go to one XCD: a quarter of the trials of one anchor (MC), a run of first edges
-            // (DET); re-run lists are short and scattered.  Measured on the A. thaliana config: whole anchors per XCD
-            // lift the L2 hit rate (24 % -> 35 %) but cost 5 % (every wave of a die starts on the same rows at once);
-            // quarter anchors keep the hit rate and cost nothing.
-            a.chunk = !work.empty() ? 8u : is_mc ? (uint32_t) std::max(1, p->rebuild_attempts / 4) : 32u;
+            // chunk of work items that go to one XCD: the trials of one anchor under one metric, or half of them (MC), a
+            // run of first edges (DET); re-run lists are short and scattered.  The waves of a die then walk the same
+            // neighbourhood and its L2 holds the rows they share -- which pays where the launch is bound by bytes: chr1-shaped
+            // graph (mean list 468 entries, 8.0 TB/s of fabric traffic) 1345 -> 1241 ms with whole anchors, yeast-shaped (365)
+            // 94.7 -> 92.1 ms; the A. thaliana-shaped graph (234; bound by instruction issue) is indifferent between a
+            // quarter, a half and a whole anchor (738.4 / 737.6 / 742.6 ms).  Round 2 dealt quarters everywhere.
+            const double mean_list = g->n_nodes ? (double) g->n_adj / (double) g->n_nodes : 0.0;
+            a.chunk = !work.empty() ? 8u
+                      : is_mc       ? (uint32_t) std::max(1, mean_list >= 300.0 ? p->rebuild_attempts : p->rebuild_attempts / 2)
+                                    : 32u;
             if (const char *e = getenv("TLM_WALK_CHUNK")) a.chunk = (uint32_t) std::max(1, atoi(e));   // tuning experiments
             a.scratch = W.scratch;
             a.cap = W.cap;
