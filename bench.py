@@ -202,6 +202,9 @@ def main() -> None:
     _, det_off = g.anchor_table()
     d0, d1 = int(det_off[a0]), int(det_off[a1])
 
+    exch = {}
+    state = {"abi_exchange": use_abi_exchange, "fallback": None}
+
     def one_step():
         # the four builders of Main.cpp:237-243; the two metrics of a builder share one persistent launch
         sets, ctrs = [], []
@@ -224,26 +227,33 @@ def main() -> None:
             else:
                 a, b = g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
                 sets += [a, b]; ctrs += [("det", a.counters), ("det", b.counters)]
-        if use_abi_exchange:            # ONE RCCL exchange through the library's own communicator
-            if exchange_mode == "lazy":     # tlm_pathset_gather_summaries
-                gathered = capi.Gathered(sets)
-                xi = gathered.info
-            else:                           # tlm_pathset_allgather
-                gathered, xi = capi.PathSet.allgather(sets)
-            n_total = gathered.n_paths
-            exch["bytes_sent"] = int(xi.bytes_sent); exch["bytes_received"] = int(xi.bytes_received)
-            exch["ms"] = exch.get("ms", 0.0) + float(xi.device_ms); exch["calls"] = exch.get("calls", 0) + 1
-            exch["slot_bits"] = int(xi.slot_bits)
-            del gathered
-        elif world > 1:                 # rehearsal over torch.distributed (gloo on a 1-GPU box)
+        done = False
+        if state["abi_exchange"]:       # ONE RCCL exchange through the library's own communicator
+            try:
+                if exchange_mode == "lazy":     # tlm_pathset_gather_summaries
+                    gathered = capi.Gathered(sets)
+                    xi = gathered.info
+                else:                           # tlm_pathset_allgather
+                    gathered, xi = capi.PathSet.allgather(sets)
+                n_total = gathered.n_paths
+                exch["bytes_sent"] = int(xi.bytes_sent); exch["bytes_received"] = int(xi.bytes_received)
+                exch["ms"] = exch.get("ms", 0.0) + float(xi.device_ms); exch["calls"] = exch.get("calls", 0) + 1
+                exch["slot_bits"] = int(xi.slot_bits)
+                del gathered
+                done = True
+            except capi.TlmError as e:
+                # the exchange calls fail on EVERY rank or on none: all ranks arrive here together and go on
+                # with the harness's gather for this and the remaining steps; the line says so
+                log("rank %d: the library's exchange failed (%s); the harness's gather takes over" % (rank, e))
+                state["abi_exchange"] = False
+                state["fallback"] = str(e)[:200]
+        if not done and world > 1:      # the harness's own gather over torch.distributed (gloo rehearsals; fallback)
             packed = [pathgather.PackedPaths(*ps.to_device_tensors(dev)) for ps in sets]
             gathered = pathgather.allgather_paths(packed)
             n_total = sum(p.n_paths for p in gathered)
-        else:
+        elif not done:
             n_total = sum(ps.n_paths for ps in sets)
         return ctrs, n_total
-
-    exch = {}
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -369,8 +379,9 @@ def main() -> None:
     if world > 1:
         out["exchange"] = {"transport": ("tlm_pathset_gather_summaries (RCCL all-gather of 45-byte path summaries; node lists "
                                          "stay with their owners until tlm_gathered_fetch asks)" if exchange_mode == "lazy" else
-                                         "tlm_pathset_allgather (RCCL send/recv of every node list)") if use_abi_exchange
-                           else "telomeri_amd.pathgather over torch.distributed/%s" % args.dist_backend,
+                                         "tlm_pathset_allgather (RCCL send/recv of every node list)") if state["abi_exchange"]
+                           else "telomeri_amd.pathgather over torch.distributed/%s%s" % (
+                               args.dist_backend, " (the library's exchange failed: %s)" % state["fallback"] if state["fallback"] else ""),
                            "allgather_bytes_sent_per_rank": exch.get("bytes_sent"),
                            "allgather_bytes_received_per_rank": exch.get("bytes_received"),
                            "slot_bits_on_the_wire": exch.get("slot_bits"),
