@@ -9,7 +9,8 @@
 // is executed synchronously -- the stream is drained first, device buffers are copied through host memory -- which is a
 // legal (if slow) schedule of the stream-ordered operations RCCL would queue.  Group semantics as in RCCL: between
 // ncclGroupStart and the matching ncclGroupEnd operations are only recorded; the outermost ncclGroupEnd runs them all:
-//   publish (my sends, my broadcasts as root, my all-gather shares) -> barrier -> consume (my receives, ...) -> barrier.
+//   publish (my sends, my broadcasts as root, my all-gather shares) -> barrier -> consume (my receives, ...) -> barrier
+//   -> tidy (a send nobody received is found here) -> barrier.
 // Pairing is CHECKED, which real RCCL does not do for you: the k-th ncclSend of rank a to rank b inside a group must meet
 // the k-th ncclRecv of b from a with the same byte count; an unmatched send or receive, or a size mismatch, is an error
 // on both sides instead of a hang.  A rank that fails or times out (FAKE_RCCL_TIMEOUT_S, default 120) raises a flag in
@@ -30,6 +31,14 @@
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+
+// FAKE_RCCL_HOST_ONLY (tests/fake_rccl/Makefile target `host`): the same library with buffers in HOST memory and no HIP
+// call at all, so that the stand-in's own logic -- pairing, size checks, group batching, barriers, failure propagation --
+// is tested on machines without a GPU (tests/test_fake_rccl_host.py).
+#ifdef FAKE_RCCL_HOST_ONLY
+#define hipStreamSynchronize(s) hipSuccess
+#define hipMemcpy(dst, src, n, kind) (std::memcpy((dst), (src), (n)), hipSuccess)
+#endif
 
 namespace {
 
@@ -144,8 +153,10 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
     Comm *c = ops[0].comm;
     for (const Op &o : ops)
         if (o.comm != c) return fail(c, ncclInvalidUsage, "one group spans several communicators%s", "");
-    for (const Op &o : ops)
+    for (const Op &o : ops) {
+        (void) o;
         if (hipStreamSynchronize(o.stream) != hipSuccess) return fail(c, ncclUnhandledCudaError, "hipStreamSynchronize failed%s", "");
+    }
     const uint64_t seq = c->seq++;
     std::vector<char> host;
     std::vector<std::string> mine;              // files this rank created
@@ -204,6 +215,8 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
         if (::unlink(p.c_str()) == 0 && was_send && rc == ncclSuccess)
             rc = fail(c, ncclInvalidUsage, "ncclSend without a matching ncclRecv: %s", p.c_str());
     }
+    // ... which only the SENDER can see: one more barrier, so that the rank that never posted the receive fails as well
+    if (rc == ncclSuccess) rc = barrier(c);
     return rc;
 }
 
