@@ -1,7 +1,7 @@
 #!/bin/bash
 # profiles/probes/tokeniser_pmc.sh -- rocprofv3 PMC passes over the host program's load phase (device tokeniser kernels) on the
 # A. thaliana-shaped text.  One process (no upload helper), destructors at exit (the profiler writes its files there).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_tokpmc; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TOK_OUT:-r02_tokpmc}; mkdir -p $O
 D=$(python3 - <<PY
 import sys, json
 sys.path.insert(0, "$R/profiles/probes"); sys.path.insert(0, "$R")

@@ -5,16 +5,16 @@
 // the host's share of a load is tokenising 15 GB of text (5 s on 16 cores for the A. thaliana-shaped input) and uploading
 // the 5.5 GB of columns it produces.  Here the TEXT goes to HBM instead (pinned slabs filled by parallel preads, H2D
 // copies behind them) and is tokenised where the graph build wants its input:
-//   pass A  line starts per 32 KB tile (a line starts at byte 0 and after every '\n')   -> record index of every tile
-//   pass B  the tile (+ overhang) staged in LDS, padded against bank conflicts; one thread per line, its end known from the
-//           next line's start: 16 tokens, every token accumulated as a strict [+-]digits integer inside int range WHILE
-//           its end is looked for (one pass over the bytes; the lanes of a wave stay at the same token), the strand as one
-//           character; the two names go through a device dictionary (open addressing over the text itself: a slot holds
-//           WHERE a name occurs first, an equal name is recognised by comparing bytes) and come out as slot numbers
+//   pass A  line starts per 16 KB tile (a line starts at byte 0 and after every '\n')   -> record index of every tile
+//   pass B  the tile (+ overhang) staged in LDS and tokenised by all lanes: newlines, whitespace and token starts found
+//           four bytes at a time, one scan for the places of lines and tokens, then the work items (line, field) dealt to the
+//           threads field-major -- a token is fetched as 13 bytes at once, its digits tested and converted four at a time --
+//           every token the strict [+-]digits integer inside int range, the strand one character; the two names go through a
+//           device dictionary (open addressing over the text itself: a slot holds WHERE a name occurs first, an equal name
+//           is recognised by comparing bytes) and come out as slot numbers
 //   finish  occupied slots (listed as they were taken) sorted by first occurrence (file, offset) = first-seen order, the
 //           numbering a sequential reader assigns; slot numbers in the columns become those ids; name bytes gathered into
 //           one blob for the host
-// 15.6 GB / 150.8 M lines of the A. thaliana-shaped input: 56 ms (pass A 3 ms, pass B 42 ms), finish 4 ms.
 // Exactly like the host's parallel tokeniser (telomeri_amd/host/overlap_graph.cpp) this is only valid on CLEAN text --
 // every line 16 tokens, plain integers, one-character strand, no blank lines; then line-wise parsing IS the token
 // stream.  Anything else raises `clean = 0` and the caller falls back to the exact operator>> reader on the host.
@@ -42,10 +42,10 @@
 
 namespace {
 
-constexpr uint32_t TILE = 32u << 10;            // bytes of text per workgroup
+constexpr uint32_t TILE = 16u << 10;            // bytes of text per workgroup
 constexpr uint32_t TILE_THREADS = 256;
-// more line starts than this in one tile: not a PAF file (a line of 16 tokens is 32 bytes at least, a tile holds 1024 of those)
-constexpr uint32_t TILE_MAX_LINES = 1040;
+// more line starts than this in one tile: not a PAF file (a line of 16 tokens is 32 bytes at least, a tile holds 512 of those)
+constexpr uint32_t TILE_MAX_LINES = 528;
 constexpr int MAX_FILES = 4;
 constexpr unsigned long long EMPTY = ~0ull;
 
@@ -66,8 +66,6 @@ struct Tmp {
     void *p = nullptr;
     ~Tmp() { tlm_pool_free(p); }
 };
-
-__device__ inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
 // 0x80 in every byte of the result whose byte of `w` is a newline
 __device__ __forceinline__ uint32_t newline_bytes(uint32_t w) {
@@ -111,34 +109,79 @@ struct Dict {
                                     // is refused): tlm_paf_finish reads these instead of searching the table
 };
 
-// The text of the file being parsed, as a workgroup sees it: its tile (+ overhang) staged in LDS by coalesced loads,
-// everything else in HBM.  Per-thread byte-wise reads of lines ~100 bytes apart touch 64 cache lines per wave
-// instruction; out of LDS they are conflict-free.
-// The LDS image is PADDED: 4 bytes after every 128 -- byte o of the tile lies at o + (o / 128) * 4.  Threads own
-// consecutive 128-byte stretches when the line starts are counted, and lines lie ~100 bytes apart when they are parsed:
-// unpadded, the 64 lanes of such a byte read fell into 2 of the 64 banks (stride 32 words); with a stride of 33 words
-// they fall into 64.
-__device__ __forceinline__ uint32_t lds_at(uint32_t o) { return o + ((o >> 7) << 2); }
+// ---- pass B.  Round 3: the tile is tokenised by ALL lanes, field by field, instead of one thread per line walking its bytes
+// (16 tokens x ~6 dependent byte reads out of LDS, a third of the lanes idle because ~330 lines meet 256 threads):
+//   1. the tile (16 KB) and its overhang (1 KB: the tile's last line ends in there) are staged in LDS;
+//   2. every thread classifies 17 words of it, four bytes at a time (SWAR): newlines, whitespace, token starts (a byte that
+//      is not whitespace after one that is).  One scan over the workgroup turns the counts into places: s_tok[] holds the
+//      start of every token of the staged text in order, s_start[l] the start of line l, s_linetok[l] the number of tokens
+//      in front of it -- token f of line l is s_tok[s_linetok[l] + f], and a line is 16 clean tokens iff the next line's
+//      count is 16 more (checked for every line);
+//   3. the work items (line, integer field) -- 10 per line: nine integers and the strand -- are dealt to the threads field-
+//      major, so that a wavefront parses the same field of 64 consecutive lines and its stores are coalesced: a token is 13
+//      bytes fetched at once (five aligned words), its digits are found by a SWAR test, converted four at a time and combined;
+//   4. the items (line, name) likewise: length and hash a word at a time, then the dictionary.
+// A last line that runs past the overhang (names of thousands of characters) is parsed by one thread out of HBM, byte by
+// byte, with the round-2 code (parse_line below).
+constexpr uint32_t TILE_OVERHANG = 1024;
+constexpr uint32_t STAGED_MAX = TILE + TILE_OVERHANG;
+constexpr uint32_t STRETCH_WORDS = STAGED_MAX / 4 / TILE_THREADS;       // words a thread classifies
+static_assert(STRETCH_WORDS * 4 * TILE_THREADS == STAGED_MAX, "the staged text is dealt out in whole words");
+static_assert(STRETCH_WORDS % 2 == 1, "an odd stride between the threads' words: their LDS reads fall into different banks");
+constexpr uint32_t TILE_MAX_TOKENS = STAGED_MAX / 2 + 8;                  // a token and the blank after it: two bytes at least
+static_assert(STAGED_MAX < 65536 && TILE_MAX_TOKENS < 65536, "offsets and token counts are kept in 16 bits");
 
-struct TileText {
-    const char *lds;        // bytes [begin, begin + size) of the text (padded image, lds_at)
-    const char *global;
-    uint64_t begin;
-    uint32_t size;
-    __device__ __forceinline__ char operator[](uint64_t pos) const {
-        const uint64_t d = pos - begin;
-        return d < size ? lds[lds_at((uint32_t) d)] : global[pos];
-    }
-};
+// 0x80 in every byte of the result whose byte of `w` is whitespace: blank, \t \n \v \f \r (what operator>> skips)
+__device__ __forceinline__ uint32_t ws_bytes(uint32_t w) {
+    const uint32_t lo7 = w & 0x7F7F7F7Fu;
+    const uint32_t ge9 = (lo7 + 0x77777777u) | w, ge14 = (lo7 + 0x72727272u) | w;       // bit 7: byte >= 9, byte >= 14
+    const uint32_t y = w ^ 0x20202020u;
+    const uint32_t blank = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y);                      // bit 7: byte == ' '
+    return ((ge9 & ~ge14) | blank) & 0x80808080u;
+}
+// 0x80 in every byte that is NOT the digit value 0..9 (x = bytes ^ '0')
+__device__ __forceinline__ uint32_t nondigit_bytes(uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u; }
+// index of the lowest flagged byte (z != 0)
+__device__ __forceinline__ uint32_t first_byte(uint32_t z) { return ((uint32_t) __ffs((int) z) >> 3) - 1u; }
+__device__ __forceinline__ bool ws_char(uint32_t c) { return c == ' ' || c - 9u < 5u; }
 
-__device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const TileText &mine_text, uint32_t file, uint64_t off,
-                                       uint32_t len) {
-    unsigned long long h = 1469598103934665603ull;
-    for (uint32_t i = 0; i < len; i++) { h ^= (unsigned char) mine_text[off + i]; h *= 1099511628211ull; }
-    h ^= h >> 29;
+// the four bytes at byte position p of a word array (any alignment)
+__device__ __forceinline__ uint32_t window_word(const uint32_t *w, uint32_t p) {
+    return __builtin_amdgcn_alignbit(w[(p >> 2) + 1], w[p >> 2], (p & 3u) * 8u);
+}
+
+// names are hashed a word at a time (the last one masked to the name's bytes): the same value whatever the alignment, and
+// whichever of the two readers (LDS words, bytes out of HBM) met the name
+__device__ __forceinline__ uint32_t mix_word(uint32_t h, uint32_t w) {
+    w *= 0xCC9E2D51u;
+    w = (w << 15) | (w >> 17);
+    w *= 0x1B873593u;
+    h ^= w;
+    h = (h << 13) | (h >> 19);
+    return h * 5u + 0xE6546B64u;
+}
+__device__ __forceinline__ uint32_t mix_end(uint32_t h, uint32_t len) {
+    h ^= len;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+constexpr uint32_t NAME_SEED = 0x9747B28Cu;
+
+// the low n (0..4 and more) bytes of a word
+__device__ __forceinline__ uint32_t low_bytes(uint32_t w, uint32_t n) { return n >= 4u ? w : w & ((1u << (8u * n)) - 1u); }
+
+// `own(i)` = byte i of the name being interned (LDS or HBM); `off` = where it stands in its file.  `own16`: the name's bytes
+// as four words, zero behind its end, when it has 16 bytes or fewer (`short_name`): the first occurrence a slot shows is then
+// fetched as five aligned words at once and compared a word at a time -- one memory latency per probe instead of one per byte.
+template <class Own>
+__device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const Own &own, bool short_name, uint4 own16, uint32_t file,
+                                       uint64_t off, uint32_t len, uint32_t hash) {
     const unsigned long long mine = pack_occ(file, off, len);
     uint32_t probes = 0;
-    for (uint32_t j = (uint32_t) h & d.mask;; j = (j + 1) & d.mask) {
+    for (uint32_t j = hash & d.mask;; j = (j + 1) & d.mask) {
         if (probes++ > d.mask) {            // every slot taken by another name: more names than the table was made for
             atomicOr(d.n_names + 1, 8u);
             return 0;
@@ -155,7 +198,17 @@ __device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const Til
         if (occ_len(cur) == len) {          // whatever occurrence the slot shows at the moment spells the slot's name
             const char *o = tx.p[occ_file(cur)] + occ_off(cur);
             bool same = true;
-            for (uint32_t i = 0; i < len && same; i++) same = o[i] == mine_text[off + i];
+            if (short_name) {               // (the text buffers are 64 bytes longer than the text: the fifth word exists)
+                const uint32_t *g = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(o) & ~(uintptr_t) 3);
+                const uint32_t sh = ((uint32_t) reinterpret_cast<uintptr_t>(o) & 3u) * 8u;
+                const uint32_t g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
+                same = low_bytes(__builtin_amdgcn_alignbit(g1, g0, sh), len) == own16.x
+                       && low_bytes(__builtin_amdgcn_alignbit(g2, g1, sh), len > 4u ? len - 4u : 0u) == own16.y
+                       && low_bytes(__builtin_amdgcn_alignbit(g3, g2, sh), len > 8u ? len - 8u : 0u) == own16.z
+                       && low_bytes(__builtin_amdgcn_alignbit(g4, g3, sh), len > 12u ? len - 12u : 0u) == own16.w;
+            } else {
+                for (uint32_t i = 0; i < len && same; i++) same = o[i] == own(i);
+            }
             if (same) {
                 if (mine < cur) atomicMin(&d.slot[j], mine);
                 return j;
@@ -169,10 +222,10 @@ struct Columns {
     uint8_t *strand;
 };
 
-// One line of PAF text.  The tokens are consumed as they come, every lane of a wavefront at its line's k-th token at the
-// same time (PAF lines have the same number of tokens, so the lanes stay together): the two names are kept as (start,
-// length); every token is accumulated as a decimal integer WHILE its end is looked for -- the strict integer of the host
-// tokeniser: an optional sign, then 1..10 digits and nothing else, inside the int32 range.
+// ---- the byte-wise reader of ONE line (a line that runs past the staged text; round 2 parsed every line with it).  The
+// tokens are consumed as they come: the two names are kept as (start, length); every other token is accumulated as a
+// decimal integer WHILE its end is looked for -- the strict integer of the host tokeniser: an optional sign, then 1..10
+// digits and nothing else, inside the int32 range.
 struct Line {
     uint64_t q_name = 0, t_name = 0;
     uint32_t q_n = 0, t_n = 0;
@@ -181,22 +234,21 @@ struct Line {
     int nt = 0;
 };
 
-// `rd(p)` = the byte at position p; [p, end) holds no newline; `origin` = file offset of position 0.
-template <class Pos, class Read>
-__device__ __forceinline__ void parse_line(const Read &rd, Pos p, const Pos end, uint64_t origin, Line &L) {
-    auto ws = [](char c) { return c == ' ' || (unsigned char) (c - 9) < 5; };       // (no newline in here)
+// `rd(p)` = the byte at position p; [p, end) holds no newline
+template <class Read>
+__device__ void parse_line(const Read &rd, uint64_t p, const uint64_t end, Line &L) {
     for (;;) {
         char c = 0;
-        while (p < end && ws(c = rd(p))) p++;
+        while (p < end && ws_char((unsigned char) (c = rd(p)))) p++;
         if (p >= end) break;
-        const Pos ts = p;
+        const uint64_t ts = p;
         bool neg = false, bad = false, more = true;
         uint32_t nd = 0;
         unsigned long long acc = 0;
         if (c == '+' || c == '-') {
             neg = c == '-';
             p++;
-            more = p < end && !ws(c = rd(p));
+            more = p < end && !ws_char((unsigned char) (c = rd(p)));
         }
         while (more) {
             const uint32_t d = (uint32_t) (unsigned char) c - (uint32_t) '0';
@@ -204,19 +256,19 @@ __device__ __forceinline__ void parse_line(const Read &rd, Pos p, const Pos end,
             acc = acc * 10u + d;            // (wraps on a long name: `nd` refuses those as integers)
             nd++;
             p++;
-            more = p < end && !ws(c = rd(p));
+            more = p < end && !ws_char((unsigned char) (c = rd(p)));
         }
-        const uint64_t len = (uint64_t) (p - ts);
+        const uint64_t len = p - ts;
         const long long a = neg ? -(long long) acc : (long long) acc;
         const bool int_ok = !bad && nd >= 1 && nd <= 10 && a <= 2147483647ll && a >= -2147483648ll;
         const int32_t v = (int32_t) a;
         switch (L.nt) {
-            case 0: L.q_name = origin + ts; L.q_n = (uint32_t) min(len, (uint64_t) 0x10000); break;
+            case 0: L.q_name = ts; L.q_n = (uint32_t) min(len, (uint64_t) 0x10000); break;
             case 1: L.ok = L.ok && int_ok; L.v0 = v; break;
             case 2: L.ok = L.ok && int_ok; L.v1 = v; break;
             case 3: L.ok = L.ok && int_ok; L.v2 = v; break;
             case 4: L.ok = L.ok && len == 1; L.minus = neg; break;
-            case 5: L.t_name = origin + ts; L.t_n = (uint32_t) min(len, (uint64_t) 0x10000); break;
+            case 5: L.t_name = ts; L.t_n = (uint32_t) min(len, (uint64_t) 0x10000); break;
             case 6: L.ok = L.ok && int_ok; L.v3 = v; break;
             case 7: L.ok = L.ok && int_ok; L.v4 = v; break;
             case 8: L.ok = L.ok && int_ok; L.v5 = v; break;
@@ -229,107 +281,287 @@ __device__ __forceinline__ void parse_line(const Read &rd, Pos p, const Pos end,
     }
 }
 
-// flags: 1 = a line is not 16 clean tokens, 2 = too many line starts in a tile, 4 = a name of 65 535 bytes or more
-// bytes after the tile staged with it: the tile's last line ends in there (a longer one is parsed out of HBM).  With the
-// line starts and the scan buffer the workgroup stays below 40 KB of LDS: four of them on a CU.
-constexpr uint32_t TILE_OVERHANG = 2048;
-static_assert(TILE_OVERHANG % TILE_THREADS == 0, "the search for the last line's end gives every thread the same share");
+// the hash of a name read byte by byte: the words mix_word sees are those of the LDS reader
+template <class Read>
+__device__ uint32_t hash_bytes(const Read &rd, uint64_t at, uint32_t len) {
+    uint32_t h = NAME_SEED;
+    for (uint32_t i = 0; i < len; i += 4) {
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < 4 && i + k < len; k++) w |= (uint32_t) (unsigned char) rd(at + i + k) << (8u * k);
+        h = mix_word(h, w);
+    }
+    return mix_end(h, len);
+}
 
+// the value of `c` (0..4) digit bytes standing in the low bytes of x (first digit lowest), x = text ^ '0'
+__device__ __forceinline__ uint32_t digit_group(uint32_t x, uint32_t c) {
+    const uint32_t v = c ? x << (8u * (4u - c)) : 0u;                  // right-aligned in the word, leading zeros below
+    const uint32_t pairs = (v * 10u + (v >> 8)) & 0x00FF00FFu;         // d0 d1 | d2 d3 -> two values below 100
+    return (pairs * 100u + (pairs >> 16)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t pow10_upto4(uint32_t c) { return c == 0 ? 1u : c == 1 ? 10u : c == 2 ? 100u : c == 3 ? 1000u : 10000u; }
+
+// The token at byte position `pos` of the staged text as the strict integer of the host tokeniser: [+-] then 1..10 digits,
+// then whitespace (or the end of the text: the bytes behind the staged text are newlines), inside the int32 range.
+__device__ __forceinline__ bool int_token(const uint32_t *sw, uint32_t pos, int32_t &value) {
+    const uint32_t wi = pos >> 2, sh = (pos & 3u) * 8u;
+    const uint32_t a0 = sw[wi], a1 = sw[wi + 1], a2 = sw[wi + 2], a3 = sw[wi + 3], a4 = sw[wi + 4];
+    uint32_t w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+    uint32_t w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
+    const uint32_t w3 = __builtin_amdgcn_alignbit(a4, a3, sh);
+    const uint32_t c0 = w0 & 0xFFu;
+    const bool neg = c0 == '-';
+    if (neg || c0 == '+') {                 // the digits start a byte later
+        w0 = __builtin_amdgcn_alignbit(w1, w0, 8u);
+        w1 = __builtin_amdgcn_alignbit(w2, w1, 8u);
+        w2 = __builtin_amdgcn_alignbit(w3, w2, 8u);
+    }
+    const uint32_t x0 = w0 ^ 0x30303030u, x1 = w1 ^ 0x30303030u, x2 = w2 ^ 0x30303030u;
+    const uint32_t n0 = nondigit_bytes(x0), n1 = nondigit_bytes(x1), n2 = nondigit_bytes(x2);
+    // m = number of digits = index of the first byte that is none (12: twelve digits at least -- no integer)
+    const uint32_t m = n0 ? first_byte(n0) : n1 ? 4u + first_byte(n1) : n2 ? 8u + first_byte(n2) : 12u;
+    const uint32_t wt = m < 4u ? w0 : m < 8u ? w1 : w2;
+    const uint32_t term = (wt >> ((m & 3u) * 8u)) & 0xFFu;
+    const bool shaped = m >= 1u && m <= 10u && ws_char(term);
+    const uint32_t c_0 = min(m, 4u), c_1 = min(m - c_0, 4u), c_2 = min(m - c_0 - c_1, 4u);
+    const uint32_t g0 = digit_group(x0, c_0), g1 = digit_group(x1, c_1), g2 = digit_group(x2, c_2);
+    const unsigned long long mag = (unsigned long long) (g0 * pow10_upto4(c_1) + g1) * pow10_upto4(c_2) + g2;
+    value = (int32_t) (neg ? 0u - (uint32_t) mag : (uint32_t) mag);
+    return shaped && mag <= (neg ? 2147483648ull : 2147483647ull);
+}
+
+// flags: 1 = a line is not 16 clean tokens, 2 = too many line starts in a tile, 4 = a name of 65 535 bytes or more
 __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uint32_t file, uint64_t bytes, uint64_t n_tiles,
                                                                    const uint64_t *__restrict__ tile_base, Dict dict,
                                                                    Columns out, uint32_t *__restrict__ flags) {
-    __shared__ __attribute__((aligned(16))) char s_text[TILE + TILE_OVERHANG + (TILE + TILE_OVERHANG) / 128 * 4 + 16];
-    __shared__ uint16_t s_start[TILE_MAX_LINES];
-    __shared__ uint32_t s_scan[TILE_THREADS];
-    __shared__ uint32_t s_end;          // tile offset of the newline that ends the tile's last line (or ~0: not staged)
+    // the staged text; the bytes behind it (to the end of its last 16-byte piece and 32 more) are newlines: a token that
+    // ends with the text ends there, and no reader below needs a bound
+    __shared__ __attribute__((aligned(16))) uint32_t s_words[STAGED_MAX / 4 + 12];
+    __shared__ uint16_t s_tok[TILE_MAX_TOKENS];
+    __shared__ uint16_t s_start[TILE_MAX_LINES + 1], s_linetok[TILE_MAX_LINES + 1];
+    __shared__ uint16_t s_qhead[TILE_MAX_LINES + 1];
+    __shared__ uint32_t s_qslot[TILE_MAX_LINES + 1];
+    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    __shared__ uint32_t s_end;          // (tile offset << 16 | tokens in front of it) of the newline that ends the tile's last line
     const char *text = tx.p[file];
+    const char *s_text = reinterpret_cast<const char *>(s_words);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t b = tile * TILE, e = min(bytes, b + TILE);
-        // the tile and its overhang into LDS, 16 bytes per lane and load (the buffer is 64 bytes longer than the text)
-        const uint32_t staged = (uint32_t) min((uint64_t) (TILE + TILE_OVERHANG), bytes - b);
-        for (uint32_t o = threadIdx.x * 16u; o < staged; o += TILE_THREADS * 16u) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(text + b + o);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(s_text + lds_at(o));      // (a 16-byte piece never crosses a pad)
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        const uint32_t staged = (uint32_t) min((uint64_t) STAGED_MAX, bytes - b);
+        // ---- 1. stage: 16 bytes per lane and load (the buffer is 64 bytes longer than the text)
+        for (uint32_t o = tid * 16u; o < staged; o += TILE_THREADS * 16u) {
+            uint4 v = *reinterpret_cast<const uint4 *>(text + b + o);
+            if (o + 16u > staged) {         // the text ends inside this piece: newlines behind it
+                uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t at = o + 4u * k;
+                    if (at >= staged) w[k] = 0x0A0A0A0Au;
+                    else if (at + 4u > staged) w[k] = (w[k] & (0xFFFFFFFFu >> (8u * (at + 4u - staged)))) | (0x0A0A0A0Au << (8u * (staged - at)));
+                }
+            }
+            *reinterpret_cast<uint4 *>(s_words + (o >> 2)) = v;
+            if (o + 16u >= staged) {        // (the piece that holds the last byte: 32 bytes of newlines behind it)
+                *reinterpret_cast<uint4 *>(s_words + (o >> 2) + 4) = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+                *reinterpret_cast<uint4 *>(s_words + (o >> 2) + 8) = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+            }
         }
         const char before = b ? text[b - 1] : '\n';
-        if (threadIdx.x == 0) s_end = 0xFFFFFFFFu;
+        if (tid == 0) s_end = 0xFFFFFFFFu;
         __syncthreads();
-        const TileText t{s_text, text, b, staged};
-        // line starts of the tile, in order: every thread owns 128 consecutive bytes
-        constexpr uint32_t PER = TILE / TILE_THREADS;
-        const uint32_t m0 = threadIdx.x * PER, m1 = (uint32_t) min((uint64_t) (m0 + PER), e - b);
-        // a line starts after every newline (and at the tile's first byte when the byte before the tile is one; a start
-        // at the tile's end belongs to the next tile).  Newlines are looked for a 32-bit word at a time: 0x80 in every
-        // byte of `z` that holds one.
-        auto newlines_of = [&](uint32_t o) {        // of the word at tile offset o (a multiple of 4), bytes inside [0, e - b - 1)
-            uint32_t z = newline_bytes(*reinterpret_cast<const uint32_t *>(s_text + lds_at(o)));
-            const uint32_t last = (uint32_t) (e - b) - 1u;      // a newline in the tile's last byte starts nothing here
-            if (o + 4u > last) z &= o >= last ? 0u : (0xFFFFFFFFu >> (8u * (o + 4u - last)));
-            return z;
+        // ---- 2. classify.  A line starts after every newline of [0, last) (and at the tile's first byte when the byte before
+        // the tile is one; a start at the tile's end belongs to the next tile); a token starts at a byte that is not
+        // whitespace behind one that is.
+        const uint32_t last = (uint32_t) (e - b) - 1u;
+        const uint32_t w_first = tid * STRETCH_WORDS;
+        auto line_starts_of = [&](uint32_t zn, uint32_t o) {        // newline flags of the word at offset o that start a line here
+            return o + 4u > last ? (o >= last ? 0u : zn & (0xFFFFFFFFu >> (8u * (o + 4u - last)))) : zn;
         };
-        uint32_t n = threadIdx.x == 0 && before == '\n';
-        for (uint32_t o = m0; o < m1; o += 4) n += __popc(newlines_of(o));
-        s_scan[threadIdx.x] = n;
-        // the tile's last line ends at the first newline at or after the tile's last byte: a few bytes per thread from there
-        constexpr uint32_t SHARE = TILE_OVERHANG / TILE_THREADS;
-        for (uint32_t o = (uint32_t) (e - b) - 1u + threadIdx.x * SHARE, k = 0; k < SHARE && o < staged; k++, o++)
-            if (s_text[lds_at(o)] == '\n') {
-                atomicMin(&s_end, o);
-                break;
+        const uint32_t carry_in = tid ? (ws_bytes(s_words[w_first - 1]) >> 24) : (ws_char((unsigned char) before) ? 0x80u : 0u);
+        uint32_t n_tok = 0, n_line = tid == 0 && before == '\n';
+        {
+            uint32_t carry = carry_in;
+            for (uint32_t k = 0; k < STRETCH_WORDS; k++) {
+                const uint32_t o = 4u * (w_first + k);
+                if (o >= staged) break;
+                const uint32_t w = s_words[w_first + k];
+                const uint32_t zw = ws_bytes(w);
+                n_tok += __popc(~zw & ((zw << 8) | carry) & 0x80808080u);
+                n_line += __popc(line_starts_of(newline_bytes(w), o));
+                carry = zw >> 24;
             }
-        __syncthreads();
-        for (uint32_t d = 1; d < TILE_THREADS; d <<= 1) {
-            const uint32_t a = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0u;
-            __syncthreads();
-            s_scan[threadIdx.x] += a;
-            __syncthreads();
         }
-        const uint32_t total = s_scan[TILE_THREADS - 1];
-        uint32_t at = s_scan[threadIdx.x] - n;
-        if (total > TILE_MAX_LINES) {
-            if (threadIdx.x == 0) atomicOr(flags, 2u);
-        } else {
-            if (threadIdx.x == 0 && before == '\n') s_start[at++] = 0;
-            for (uint32_t o = m0; o < m1; o += 4)
-                for (uint32_t z = newlines_of(o); z; z &= z - 1u) s_start[at++] = (uint16_t) (o + (uint32_t) (__ffs((int) z) >> 3));
+        // places: one scan of (lines << 16 | tokens) over the workgroup
+        uint32_t incl = (n_line << 16) | n_tok;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t) __shfl_up((int) incl, (int) d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t all = 0, mine_base = 0;
+        for (uint32_t k = 0; k < TILE_THREADS / 64; k++) {
+            if (k < wave) mine_base += s_wave[k];
+            all += s_wave[k];
+        }
+        const uint32_t total = all >> 16, total_tok = all & 0xFFFFu;
+        const bool countable = total <= TILE_MAX_LINES;
+        if (!countable && tid == 0) atomicOr(flags, 2u);
+        if (countable) {
+            const uint32_t excl = mine_base + incl - ((n_line << 16) | n_tok);
+            uint32_t at_line = excl >> 16, at_tok = excl & 0xFFFFu, carry = carry_in;
+            if (tid == 0 && before == '\n') {
+                s_start[0] = 0;
+                s_linetok[0] = 0;
+                at_line = 1;
+            }
+            for (uint32_t k = 0; k < STRETCH_WORDS; k++) {
+                const uint32_t o = 4u * (w_first + k);
+                if (o >= staged) break;
+                const uint32_t w = s_words[w_first + k];
+                const uint32_t zw = ws_bytes(w), zn = newline_bytes(w);
+                const uint32_t st = ~zw & ((zw << 8) | carry) & 0x80808080u;
+                carry = zw >> 24;
+                const uint32_t starts = line_starts_of(zn, o);
+                for (uint32_t z = zn; z; z &= z - 1u) {
+                    const uint32_t kk = first_byte(z), p = o + kk;
+                    const uint32_t in_front = at_tok + (uint32_t) __popc(st & ((1u << (8u * kk)) - 1u));
+                    if ((starts >> (8u * kk)) & 0x80u) {
+                        s_start[at_line] = (uint16_t) (p + 1u);
+                        s_linetok[at_line] = (uint16_t) in_front;
+                        at_line++;
+                    } else if (p >= last && p < staged) {       // the first of these ends the tile's last line
+                        atomicMin(&s_end, (p << 16) | in_front);
+                    }
+                }
+                for (uint32_t z = st; z; z &= z - 1u) s_tok[at_tok++] = (uint16_t) (o + first_byte(z));
+            }
         }
         __syncthreads();
-        if (total <= TILE_MAX_LINES) {
-            for (uint32_t l = threadIdx.x; l < total; l += TILE_THREADS) {
-                const uint64_t r = tile_base[tile] + l;
-                const uint32_t start = s_start[l];
-                // the line ends before the next line's start; the tile's last line at the newline found above, or with the text
-                uint32_t end = l + 1 < total ? (uint32_t) s_start[l + 1] - 1u : s_end;
-                if (end == 0xFFFFFFFFu && b + staged == bytes) end = staged;
+        if (countable && total) {
+            const uint32_t endpack = s_end;
+            // the tile's last line ends at that newline, or with the text; otherwise it runs past the staged bytes
+            const bool slow_last = endpack == 0xFFFFFFFFu && b + staged != bytes;
+            const uint32_t end_tok = endpack == 0xFFFFFFFFu ? total_tok : endpack & 0xFFFFu;
+            const uint32_t n_fast = total - (slow_last ? 1u : 0u);
+            const uint64_t r0 = tile_base[tile];
+            // ---- every line 16 tokens
+            for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {
+                const uint32_t next = l + 1u < total ? (uint32_t) s_linetok[l + 1] : end_tok;
+                if (next - (uint32_t) s_linetok[l] != 16u) atomicOr(flags, 1u);
+            }
+            // ---- 3. the integer fields and the strand, field-major
+            const uint32_t inv = n_fast > 1u ? 0xFFFFFFFFu / n_fast + 1u : 0u;       // i / n_fast = umulhi(i, inv) for i < 2^16, n_fast > 1
+            for (uint32_t i = tid; i < n_fast * 10u; i += TILE_THREADS) {
+                const uint32_t f = n_fast == 1u ? i : __umulhi(i, inv), l = i - f * n_fast;
+                const uint32_t j = (uint32_t) s_linetok[l] + f + 1u + (f >= 4u ? 1u : 0u);      // tokens 1..4, 6..11
+                if (j >= total_tok) continue;           // (a short line: refused above)
+                const uint32_t pos = s_tok[j];
+                const uint64_t r = r0 + l;
+                if (f == 3u) {                          // the strand: one character
+                    const uint32_t w = window_word(s_words, pos);
+                    if (!ws_char((w >> 8) & 0xFFu)) atomicOr(flags, 1u);
+                    out.strand[r] = (w & 0xFFu) == '-';
+                    continue;
+                }
+                int32_t v;
+                if (!int_token(s_words, pos, v)) atomicOr(flags, 1u);
+                int32_t *col = f == 0u ? out.q_len : f == 1u ? out.q_start : f == 2u ? out.q_end : f == 4u ? out.t_len
+                               : f == 5u ? out.t_start : f == 6u ? out.t_end : f == 7u ? out.matches : nullptr;
+                if (col) col[r] = v;                    // (alignment block length, mapping quality: integers, never used)
+            }
+            // ---- 4. the names.  `name_of`: length and hash of the name at `pos` (a word at a time; it ends at the newlines behind
+            // the staged text at the latest), its first 16 bytes as words, and the dictionary
+            auto name_of = [&](uint32_t pos) {
+                uint32_t h = NAME_SEED, len = 0;
+                uint4 first16 = make_uint4(0u, 0u, 0u, 0u);
+                for (uint32_t k = 0;; k++) {
+                    const uint32_t w = window_word(s_words, pos + 4u * k);
+                    const uint32_t z = ws_bytes(w);
+                    const uint32_t rest = z ? first_byte(z) : 4u;
+                    const uint32_t part = low_bytes(w, rest);
+                    if (k == 0u) first16.x = part;
+                    else if (k == 1u) first16.y = part;
+                    else if (k == 2u) first16.z = part;
+                    else if (k == 3u) first16.w = part;
+                    if (rest) h = mix_word(h, part);
+                    len = 4u * k + rest;
+                    if (z) break;
+                }
+                const char *name = s_text + pos;
+                return dict_intern(dict, tx, [&](uint32_t q) { return name[q]; }, len <= 16u, first16, file, b + pos, len,
+                                   mix_end(h, len));
+            };
+            for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {         // target names
+                const uint32_t j = (uint32_t) s_linetok[l] + 5u;
+                if (j < total_tok) out.t_id[r0 + l] = (int32_t) name_of(s_tok[j]);
+            }
+            // Query names: the lines of one query follow each other (the overlaps of a read are written together), so a line
+            // whose query name is the previous line's takes that line's slot -- a name seen before can be no first occurrence.
+            // s_qhead[l] = l + 1 for a line that looks its name up, 0 for one that repeats; a running maximum (wave 0) then
+            // names every line's head.
+            for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {
+                const uint32_t j = s_linetok[l];
+                if (j >= total_tok) { s_qhead[l] = (uint16_t) (l + 1u); s_qslot[l] = 0; continue; }
+                const uint32_t pos = s_tok[j];
+                bool repeat = l != 0u && (uint32_t) s_linetok[l - 1u] < total_tok;
+                if (repeat) {
+                    const uint32_t prev = s_tok[s_linetok[l - 1u]];
+                    for (uint32_t k = 0; repeat; k++) {
+                        const uint32_t w = window_word(s_words, pos + 4u * k), v = window_word(s_words, prev + 4u * k);
+                        const uint32_t z = ws_bytes(w);
+                        if (z) {            // the name ends in this word: the same bytes in front, and the other ends there too
+                            const uint32_t rest = first_byte(z);
+                            repeat = low_bytes(w, rest) == low_bytes(v, rest) && ws_char((v >> (8u * rest)) & 0xFFu);
+                            break;
+                        }
+                        repeat = w == v;
+                    }
+                }
+                s_qhead[l] = repeat ? (uint16_t) 0 : (uint16_t) (l + 1u);
+                if (!repeat) s_qslot[l] = name_of(pos);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t run = 0;
+                for (uint32_t base = 0; base < n_fast; base += 64u) {
+                    const uint32_t l = base + lane;
+                    uint32_t m = l < n_fast ? (uint32_t) s_qhead[l] : 0u;
+                    for (uint32_t d = 1; d < 64; d <<= 1) {
+                        const uint32_t up = (uint32_t) __shfl_up((int) m, (int) d);
+                        if (lane >= d) m = max(m, up);
+                    }
+                    m = max(m, run);
+                    if (l < n_fast) s_qhead[l] = (uint16_t) m;
+                    run = (uint32_t) __shfl((int) m, 63);
+                }
+            }
+            __syncthreads();
+            for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) out.q_id[r0 + l] = (int32_t) s_qslot[(uint32_t) s_qhead[l] - 1u];
+            // ---- a last line that runs past the staged bytes: one thread, byte by byte out of HBM
+            if (slow_last && tid == 0) {
+                const uint64_t from = b + s_start[total - 1u];
+                uint64_t q = from;
+                while (q < bytes && text[q] != '\n') q++;
+                auto rd = [&](uint64_t o) { return text[o]; };
                 Line L;
-                if (end != 0xFFFFFFFFu) {
-                    parse_line<uint32_t>([&](uint32_t o) { return s_text[lds_at(o)]; }, start, end, b, L);
-                } else {                // (a line that runs past the staged bytes: out of HBM)
-                    uint64_t q = b + start;
-                    while (q < bytes && t[q] != '\n') q++;
-                    parse_line<uint64_t>([&](uint64_t o) { return t[o]; }, b + start, q, 0, L);
-                }
-                const bool ok = L.ok;
-                const int nt = L.nt;
-                const uint64_t q_name = L.q_name, t_name = L.t_name;
-                const uint32_t q_n = L.q_n, t_n = L.t_n;
-                const int32_t v0 = L.v0, v1 = L.v1, v2 = L.v2, v3 = L.v3, v4 = L.v4, v5 = L.v5, v6 = L.v6;
-                const bool minus = L.minus;
-                if (!ok || nt != 16) {
+                parse_line(rd, from, q, L);
+                const uint64_t r = r0 + total - 1u;
+                if (!L.ok || L.nt != 16) {
                     atomicOr(flags, 1u);
-                    continue;
-                }
-                if (q_n >= 0xFFFFu || t_n >= 0xFFFFu) {
+                } else if (L.q_n >= 0xFFFFu || L.t_n >= 0xFFFFu) {
                     atomicOr(flags, 4u);
-                    continue;
+                } else {
+                    const uint64_t qn = L.q_name, tn = L.t_name;
+                    out.q_id[r] = (int32_t) dict_intern(dict, tx, [&](uint32_t k) { return text[qn + k]; }, false, make_uint4(0u, 0u, 0u, 0u), file, qn, L.q_n,
+                                                        hash_bytes(rd, qn, L.q_n));
+                    out.t_id[r] = (int32_t) dict_intern(dict, tx, [&](uint32_t k) { return text[tn + k]; }, false, make_uint4(0u, 0u, 0u, 0u), file, tn, L.t_n,
+                                                        hash_bytes(rd, tn, L.t_n));
+                    out.q_len[r] = L.v0; out.q_start[r] = L.v1; out.q_end[r] = L.v2;
+                    out.t_len[r] = L.v3; out.t_start[r] = L.v4; out.t_end[r] = L.v5;
+                    out.matches[r] = L.v6;
+                    out.strand[r] = L.minus;
                 }
-                out.q_id[r] = (int32_t) dict_intern(dict, tx, t, file, q_name, q_n);
-                out.t_id[r] = (int32_t) dict_intern(dict, tx, t, file, t_name, t_n);
-                out.q_len[r] = v0; out.q_start[r] = v1; out.q_end[r] = v2;
-                out.t_len[r] = v3; out.t_start[r] = v4; out.t_end[r] = v5;
-                out.matches[r] = v6;
-                out.strand[r] = minus;
             }
         }
         __syncthreads();
