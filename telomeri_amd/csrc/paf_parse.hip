@@ -113,10 +113,11 @@ struct Dict {
 // (16 tokens x ~6 dependent byte reads out of LDS, a third of the lanes idle because ~330 lines meet 256 threads):
 //   1. the tile (16 KB) and its overhang (1 KB: the tile's last line ends in there) are staged in LDS;
 //   2. every thread classifies 17 words of it, four bytes at a time (SWAR): newlines, whitespace, token starts (a byte that
-//      is not whitespace after one that is).  One scan over the workgroup turns the counts into places: s_tok[] holds the
-//      start of every token of the staged text in order, s_start[l] the start of line l, s_linetok[l] the number of tokens
-//      in front of it -- token f of line l is s_tok[s_linetok[l] + f], and a line is 16 clean tokens iff the next line's
-//      count is 16 more (checked for every line);
+//      is not whitespace after one that is).  It writes the token starts of its stretch into slots of its own and keeps its
+//      (three at most) line starts in registers; one scan over the workgroup then numbers lines and tokens: s_linetok[l] =
+//      tokens in front of line l -- a line is 16 clean tokens iff the next line's count is 16 more (checked for every
+//      line) -- and s_lineslot[l] = where the line's first token is looked for; token f of the line is f slots further,
+//      over at most two or three threads' slots;
 //   3. the work items (line, integer field) -- 10 per line: nine integers and the strand -- are dealt to the threads field-
 //      major, so that a wavefront parses the same field of 64 consecutive lines and its stores are coalesced: a token is 13
 //      bytes fetched at once (five aligned words), its digits are found by a SWAR test, converted four at a time and combined;
@@ -128,8 +129,8 @@ constexpr uint32_t STAGED_MAX = TILE + TILE_OVERHANG;
 constexpr uint32_t STRETCH_WORDS = STAGED_MAX / 4 / TILE_THREADS;       // words a thread classifies
 static_assert(STRETCH_WORDS * 4 * TILE_THREADS == STAGED_MAX, "the staged text is dealt out in whole words");
 static_assert(STRETCH_WORDS % 2 == 1, "an odd stride between the threads' words: their LDS reads fall into different banks");
-constexpr uint32_t TILE_MAX_TOKENS = STAGED_MAX / 2 + 8;                  // a token and the blank after it: two bytes at least
-static_assert(STAGED_MAX < 65536 && TILE_MAX_TOKENS < 65536, "offsets and token counts are kept in 16 bits");
+constexpr uint32_t TOK_SLOTS = STRETCH_WORDS * 2;                         // a token and the blank after it: two bytes at least
+static_assert(STAGED_MAX < (1u << 14) * 2 && TILE_THREADS * TOK_SLOTS < 65536 && TOK_SLOTS < 64, "offsets and token counts are packed");
 
 // 0x80 in every byte of the result whose byte of `w` is whitespace: blank, \t \n \v \f \r (what operator>> skips)
 __device__ __forceinline__ uint32_t ws_bytes(uint32_t w) {
@@ -174,11 +175,12 @@ constexpr uint32_t NAME_SEED = 0x9747B28Cu;
 __device__ __forceinline__ uint32_t low_bytes(uint32_t w, uint32_t n) { return n >= 4u ? w : w & ((1u << (8u * n)) - 1u); }
 
 // `own(i)` = byte i of the name being interned (LDS or HBM); `off` = where it stands in its file.  `own16`: the name's bytes
-// as four words, zero behind its end, when it has 16 bytes or fewer (`short_name`): the first occurrence a slot shows is then
+// as four words, zero behind its end, when it has 16 bytes or fewer (`short_name`); the first occurrence a slot shows is then
 // fetched as five aligned words at once and compared a word at a time -- one memory latency per probe instead of one per byte.
 template <class Own>
 __device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const Own &own, bool short_name, uint4 own16, uint32_t file,
-                                       uint64_t off, uint32_t len, uint32_t hash) {
+                                       uint64_t off, uint32_t len, uint32_t hash, bool have_first = false,
+                                       unsigned long long first = 0) {
     const unsigned long long mine = pack_occ(file, off, len);
     uint32_t probes = 0;
     for (uint32_t j = hash & d.mask;; j = (j + 1) & d.mask) {
@@ -186,7 +188,7 @@ __device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const Own
             atomicOr(d.n_names + 1, 8u);
             return 0;
         }
-        unsigned long long cur = d.slot[j];
+        unsigned long long cur = have_first && probes == 1u ? first : d.slot[j];      // (`first`: slot hash & mask, read earlier)
         if (cur == EMPTY) {
             cur = atomicCAS(&d.slot[j], EMPTY, mine);
             if (cur == EMPTY) {
@@ -337,12 +339,18 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
     // the staged text; the bytes behind it (to the end of its last 16-byte piece and 32 more) are newlines: a token that
     // ends with the text ends there, and no reader below needs a bound
     __shared__ __attribute__((aligned(16))) uint32_t s_words[STAGED_MAX / 4 + 12];
-    __shared__ uint16_t s_tok[TILE_MAX_TOKENS];
-    __shared__ uint16_t s_start[TILE_MAX_LINES + 1], s_linetok[TILE_MAX_LINES + 1];
+    // token starts: thread t writes those of its stretch to s_tok[t * TOK_SLOTS ..] as it finds them, s_cnt[t] says how many
+    __shared__ uint16_t s_tok[TILE_THREADS * TOK_SLOTS];
+    __shared__ uint8_t s_cnt[TILE_THREADS];
+    // per line: tokens of the staged text in front of it; where its first token is looked for (thread << 8 | slot)
+    __shared__ uint16_t s_linetok[TILE_MAX_LINES + 1], s_lineslot[TILE_MAX_LINES + 1];
     __shared__ uint16_t s_qhead[TILE_MAX_LINES + 1];
     __shared__ uint32_t s_qslot[TILE_MAX_LINES + 1];
     __shared__ uint32_t s_wave[TILE_THREADS / 64];
-    __shared__ uint32_t s_end;          // (tile offset << 16 | tokens in front of it) of the newline that ends the tile's last line
+    __shared__ uint32_t s_end;          // of the newline that ends the tile's last line: tile offset << 14 | thread << 6 | its tokens in front
+    __shared__ uint32_t s_end_tok;      // tokens of the staged text in front of that newline
+    __shared__ uint32_t s_last_start;   // tile offset of the tile's last line
+    __shared__ uint32_t s_bad;          // a stretch with more line starts than clean text can have: nothing of the tile is parsed
     const char *text = tx.p[file];
     const char *s_text = reinterpret_cast<const char *>(s_words);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -367,29 +375,54 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
             }
         }
         const char before = b ? text[b - 1] : '\n';
-        if (tid == 0) s_end = 0xFFFFFFFFu;
+        if (tid == 0) {
+            s_end = 0xFFFFFFFFu;
+            s_bad = 0;
+        }
         __syncthreads();
-        // ---- 2. classify.  A line starts after every newline of [0, last) (and at the tile's first byte when the byte before
-        // the tile is one; a start at the tile's end belongs to the next tile); a token starts at a byte that is not
-        // whitespace behind one that is.
+        // ---- 2. classify, once.  A line starts after every newline of [0, last) (and at the tile's first byte when the byte
+        // before the tile is one; a start at the tile's end belongs to the next tile); a token starts at a byte that is not
+        // whitespace behind one that is -- two per word at most.  A stretch of 68 bytes of clean text holds three line
+        // starts at most (a line of 16 tokens has 32 bytes): kept in registers until the scan has said where they go.
         const uint32_t last = (uint32_t) (e - b) - 1u;
         const uint32_t w_first = tid * STRETCH_WORDS;
-        auto line_starts_of = [&](uint32_t zn, uint32_t o) {        // newline flags of the word at offset o that start a line here
-            return o + 4u > last ? (o >= last ? 0u : zn & (0xFFFFFFFFu >> (8u * (o + 4u - last)))) : zn;
-        };
-        const uint32_t carry_in = tid ? (ws_bytes(s_words[w_first - 1]) >> 24) : (ws_char((unsigned char) before) ? 0x80u : 0u);
-        uint32_t n_tok = 0, n_line = tid == 0 && before == '\n';
+        uint16_t *my_tok = s_tok + tid * TOK_SLOTS;
+        uint32_t n_tok = 0, n_line = 0, ls0 = 0, ls1 = 0, ls2 = 0;         // line starts: (tile offset << 8) | own tokens in front
+        if (tid == 0 && before == '\n') n_line = 1;                         // (ls0 = 0: offset 0, no token in front)
         {
-            uint32_t carry = carry_in;
+            uint32_t carry = tid ? (ws_bytes(s_words[w_first - 1]) >> 24) : (ws_char((unsigned char) before) ? 0x80u : 0u);
             for (uint32_t k = 0; k < STRETCH_WORDS; k++) {
                 const uint32_t o = 4u * (w_first + k);
                 if (o >= staged) break;
                 const uint32_t w = s_words[w_first + k];
                 const uint32_t zw = ws_bytes(w);
-                n_tok += __popc(~zw & ((zw << 8) | carry) & 0x80808080u);
-                n_line += __popc(line_starts_of(newline_bytes(w), o));
+                const uint32_t st = ~zw & ((zw << 8) | carry) & 0x80808080u;
                 carry = zw >> 24;
+                for (uint32_t z = newline_bytes(w); z; z &= z - 1u) {         // (one word in twenty-five has a newline)
+                    const uint32_t kk = first_byte(z), p = o + kk;
+                    const uint32_t in_front = n_tok + (uint32_t) __popc(st & ((1u << (8u * kk)) - 1u));
+                    if (p < last) {
+                        const uint32_t rec = ((p + 1u) << 8) | in_front;
+                        if (n_line == 0) ls0 = rec;
+                        else if (n_line == 1) ls1 = rec;
+                        else if (n_line == 2) ls2 = rec;
+                        n_line++;
+                    } else if (p < staged) {        // the first of these ends the tile's last line
+                        atomicMin(&s_end, (p << 14) | (tid << 6) | in_front);
+                    }
+                }
+                if (st) {
+                    my_tok[n_tok] = (uint16_t) (o + first_byte(st));
+                    const uint32_t st2 = st & (st - 1u);
+                    if (st2) my_tok[n_tok + 1u] = (uint16_t) (o + first_byte(st2));
+                    n_tok += (uint32_t) __popc(st);
+                }
             }
+        }
+        s_cnt[tid] = (uint8_t) n_tok;
+        if (n_line > 3u) {
+            atomicOr(flags, 1u);
+            s_bad = 1;
         }
         // places: one scan of (lines << 16 | tokens) over the workgroup
         uint32_t incl = (n_line << 16) | n_tok;
@@ -405,58 +438,116 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
             all += s_wave[k];
         }
         const uint32_t total = all >> 16, total_tok = all & 0xFFFFu;
-        const bool countable = total <= TILE_MAX_LINES;
-        if (!countable && tid == 0) atomicOr(flags, 2u);
+        const bool countable = total <= TILE_MAX_LINES && !s_bad;
+        if (total > TILE_MAX_LINES && tid == 0) atomicOr(flags, 2u);
         if (countable) {
             const uint32_t excl = mine_base + incl - ((n_line << 16) | n_tok);
-            uint32_t at_line = excl >> 16, at_tok = excl & 0xFFFFu, carry = carry_in;
-            if (tid == 0 && before == '\n') {
-                s_start[0] = 0;
-                s_linetok[0] = 0;
-                at_line = 1;
+            const uint32_t at_line = excl >> 16, at_tok = excl & 0xFFFFu;
+            for (uint32_t q = 0; q < n_line; q++) {
+                const uint32_t rec = q == 0 ? ls0 : q == 1 ? ls1 : ls2;
+                s_linetok[at_line + q] = (uint16_t) (at_tok + (rec & 0xFFu));
+                s_lineslot[at_line + q] = (uint16_t) ((tid << 8) | (rec & 0xFFu));
+                if (at_line + q + 1u == total) s_last_start = rec >> 8;
             }
-            for (uint32_t k = 0; k < STRETCH_WORDS; k++) {
-                const uint32_t o = 4u * (w_first + k);
-                if (o >= staged) break;
-                const uint32_t w = s_words[w_first + k];
-                const uint32_t zw = ws_bytes(w), zn = newline_bytes(w);
-                const uint32_t st = ~zw & ((zw << 8) | carry) & 0x80808080u;
-                carry = zw >> 24;
-                const uint32_t starts = line_starts_of(zn, o);
-                for (uint32_t z = zn; z; z &= z - 1u) {
-                    const uint32_t kk = first_byte(z), p = o + kk;
-                    const uint32_t in_front = at_tok + (uint32_t) __popc(st & ((1u << (8u * kk)) - 1u));
-                    if ((starts >> (8u * kk)) & 0x80u) {
-                        s_start[at_line] = (uint16_t) (p + 1u);
-                        s_linetok[at_line] = (uint16_t) in_front;
-                        at_line++;
-                    } else if (p >= last && p < staged) {       // the first of these ends the tile's last line
-                        atomicMin(&s_end, (p << 16) | in_front);
-                    }
-                }
-                for (uint32_t z = st; z; z &= z - 1u) s_tok[at_tok++] = (uint16_t) (o + first_byte(z));
-            }
+            const uint32_t endpack = s_end;
+            if (endpack != 0xFFFFFFFFu && tid == ((endpack >> 6) & 0xFFu)) s_end_tok = at_tok + (endpack & 63u);
         }
         __syncthreads();
         if (countable && total) {
             const uint32_t endpack = s_end;
             // the tile's last line ends at that newline, or with the text; otherwise it runs past the staged bytes
             const bool slow_last = endpack == 0xFFFFFFFFu && b + staged != bytes;
-            const uint32_t end_tok = endpack == 0xFFFFFFFFu ? total_tok : endpack & 0xFFFFu;
+            const uint32_t end_tok = endpack == 0xFFFFFFFFu ? total_tok : s_end_tok;
             const uint32_t n_fast = total - (slow_last ? 1u : 0u);
             const uint64_t r0 = tile_base[tile];
+            // token f of line l (it exists: the callers have compared its number with total_tok): the f-th behind the place
+            // the line's first token is looked for, over the threads' slots
+            auto token_at = [&](uint32_t l, uint32_t f) {
+                const uint32_t ref = s_lineslot[l];
+                uint32_t t = ref >> 8, idx = (ref & 0xFFu) + f, c;
+                while (idx >= (c = s_cnt[t]) && t < TILE_THREADS - 1u) {
+                    idx -= c;
+                    t++;
+                }
+                return (uint32_t) s_tok[t * TOK_SLOTS + idx];
+            };
             // ---- every line 16 tokens
             for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {
                 const uint32_t next = l + 1u < total ? (uint32_t) s_linetok[l + 1] : end_tok;
                 if (next - (uint32_t) s_linetok[l] != 16u) atomicOr(flags, 1u);
             }
-            // ---- 3. the integer fields and the strand, field-major
+            // ---- 3. the names, first half.  `name_scan`: length and hash of the name at `pos` (a word at a time; it ends at the
+            // newlines behind the staged text at the latest) and its first 16 bytes as words.  The dictionary slot the hash
+            // points at is READ here and looked at behind the integer fields: the two dependent memory latencies of a lookup
+            // (the slot, then the text of the first occurrence it names) are what the names cost, and the first of them now
+            // passes while the integers are parsed.
+            struct Name {
+                uint32_t pos, len, hash;
+                uint4 first16;
+                unsigned long long slot0;
+            };
+            auto name_scan = [&](uint32_t pos) {
+                Name nm;
+                nm.pos = pos;
+                nm.first16 = make_uint4(0u, 0u, 0u, 0u);
+                uint32_t h = NAME_SEED;
+                for (uint32_t k = 0;; k++) {
+                    const uint32_t w = window_word(s_words, pos + 4u * k);
+                    const uint32_t z = ws_bytes(w);
+                    const uint32_t rest = z ? first_byte(z) : 4u;
+                    const uint32_t part = low_bytes(w, rest);
+                    if (k == 0u) nm.first16.x = part;
+                    else if (k == 1u) nm.first16.y = part;
+                    else if (k == 2u) nm.first16.z = part;
+                    else if (k == 3u) nm.first16.w = part;
+                    if (rest) h = mix_word(h, part);
+                    nm.len = 4u * k + rest;
+                    if (z) break;
+                }
+                nm.hash = mix_end(h, nm.len);
+                nm.slot0 = dict.slot[nm.hash & dict.mask];
+                return nm;
+            };
+            auto name_slot = [&](const Name &nm) {
+                const char *name = s_text + nm.pos;
+                return dict_intern(dict, tx, [&](uint32_t q) { return name[q]; }, nm.len <= 16u, nm.first16, file, b + nm.pos, nm.len,
+                                   nm.hash, true, nm.slot0);
+            };
+            // Query names: the lines of one query follow each other (the overlaps of a read are written together), so a line
+            // whose query name is the previous line's takes that line's slot -- a name seen before can be no first occurrence.
+            // s_qhead[l] = l + 1 for a line that looks its name up, 0 for one that repeats; a running maximum (wave 0) then
+            // names every line's head.
+            auto repeats_previous = [&](uint32_t l, uint32_t pos) {
+                if (l == 0u || (uint32_t) s_linetok[l - 1u] >= total_tok) return false;
+                const uint32_t prev = token_at(l - 1u, 0u);
+                for (uint32_t k = 0;; k++) {
+                    const uint32_t w = window_word(s_words, pos + 4u * k), v = window_word(s_words, prev + 4u * k);
+                    const uint32_t z = ws_bytes(w);
+                    if (z) {            // the name ends in this word: the same bytes in front, and the other ends there too
+                        const uint32_t rest = first_byte(z);
+                        return low_bytes(w, rest) == low_bytes(v, rest) && ws_char((v >> (8u * rest)) & 0xFFu);
+                    }
+                    if (w != v) return false;
+                }
+            };
+            // (this thread's line of the first round: l = tid; a tile of more than 256 lines does the rest behind the integers)
+            const bool t_mine = tid < n_fast && (uint32_t) s_linetok[tid] + 5u < total_tok;
+            const bool q_there = tid < n_fast && (uint32_t) s_linetok[tid] < total_tok;
+            Name t_name{}, q_name{};
+            bool q_head = false;
+            if (t_mine) t_name = name_scan(token_at(tid, 5u));
+            if (q_there) {
+                const uint32_t pos = token_at(tid, 0u);
+                q_head = !repeats_previous(tid, pos);
+                if (q_head) q_name = name_scan(pos);
+            }
+            // ---- 4. the integer fields and the strand, field-major
             const uint32_t inv = n_fast > 1u ? 0xFFFFFFFFu / n_fast + 1u : 0u;       // i / n_fast = umulhi(i, inv) for i < 2^16, n_fast > 1
             for (uint32_t i = tid; i < n_fast * 10u; i += TILE_THREADS) {
                 const uint32_t f = n_fast == 1u ? i : __umulhi(i, inv), l = i - f * n_fast;
                 const uint32_t j = (uint32_t) s_linetok[l] + f + 1u + (f >= 4u ? 1u : 0u);      // tokens 1..4, 6..11
                 if (j >= total_tok) continue;           // (a short line: refused above)
-                const uint32_t pos = s_tok[j];
+                const uint32_t pos = token_at(l, f + 1u + (f >= 4u ? 1u : 0u));
                 const uint64_t r = r0 + l;
                 if (f == 3u) {                          // the strand: one character
                     const uint32_t w = window_word(s_words, pos);
@@ -470,56 +561,19 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
                                : f == 5u ? out.t_start : f == 6u ? out.t_end : f == 7u ? out.matches : nullptr;
                 if (col) col[r] = v;                    // (alignment block length, mapping quality: integers, never used)
             }
-            // ---- 4. the names.  `name_of`: length and hash of the name at `pos` (a word at a time; it ends at the newlines behind
-            // the staged text at the latest), its first 16 bytes as words, and the dictionary
-            auto name_of = [&](uint32_t pos) {
-                uint32_t h = NAME_SEED, len = 0;
-                uint4 first16 = make_uint4(0u, 0u, 0u, 0u);
-                for (uint32_t k = 0;; k++) {
-                    const uint32_t w = window_word(s_words, pos + 4u * k);
-                    const uint32_t z = ws_bytes(w);
-                    const uint32_t rest = z ? first_byte(z) : 4u;
-                    const uint32_t part = low_bytes(w, rest);
-                    if (k == 0u) first16.x = part;
-                    else if (k == 1u) first16.y = part;
-                    else if (k == 2u) first16.z = part;
-                    else if (k == 3u) first16.w = part;
-                    if (rest) h = mix_word(h, part);
-                    len = 4u * k + rest;
-                    if (z) break;
-                }
-                const char *name = s_text + pos;
-                return dict_intern(dict, tx, [&](uint32_t q) { return name[q]; }, len <= 16u, first16, file, b + pos, len,
-                                   mix_end(h, len));
-            };
-            for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {         // target names
-                const uint32_t j = (uint32_t) s_linetok[l] + 5u;
-                if (j < total_tok) out.t_id[r0 + l] = (int32_t) name_of(s_tok[j]);
+            // ---- 5. the names, second half
+            if (t_mine) out.t_id[r0 + tid] = (int32_t) name_slot(t_name);
+            if (tid < n_fast) {
+                s_qhead[tid] = q_there && !q_head ? (uint16_t) 0 : (uint16_t) (tid + 1u);
+                s_qslot[tid] = q_head ? name_slot(q_name) : 0u;
             }
-            // Query names: the lines of one query follow each other (the overlaps of a read are written together), so a line
-            // whose query name is the previous line's takes that line's slot -- a name seen before can be no first occurrence.
-            // s_qhead[l] = l + 1 for a line that looks its name up, 0 for one that repeats; a running maximum (wave 0) then
-            // names every line's head.
-            for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {
-                const uint32_t j = s_linetok[l];
-                if (j >= total_tok) { s_qhead[l] = (uint16_t) (l + 1u); s_qslot[l] = 0; continue; }
-                const uint32_t pos = s_tok[j];
-                bool repeat = l != 0u && (uint32_t) s_linetok[l - 1u] < total_tok;
-                if (repeat) {
-                    const uint32_t prev = s_tok[s_linetok[l - 1u]];
-                    for (uint32_t k = 0; repeat; k++) {
-                        const uint32_t w = window_word(s_words, pos + 4u * k), v = window_word(s_words, prev + 4u * k);
-                        const uint32_t z = ws_bytes(w);
-                        if (z) {            // the name ends in this word: the same bytes in front, and the other ends there too
-                            const uint32_t rest = first_byte(z);
-                            repeat = low_bytes(w, rest) == low_bytes(v, rest) && ws_char((v >> (8u * rest)) & 0xFFu);
-                            break;
-                        }
-                        repeat = w == v;
-                    }
-                }
+            for (uint32_t l = tid + TILE_THREADS; l < n_fast; l += TILE_THREADS) {
+                if ((uint32_t) s_linetok[l] + 5u < total_tok) out.t_id[r0 + l] = (int32_t) name_slot(name_scan(token_at(l, 5u)));
+                if ((uint32_t) s_linetok[l] >= total_tok) { s_qhead[l] = (uint16_t) (l + 1u); s_qslot[l] = 0; continue; }
+                const uint32_t pos = token_at(l, 0u);
+                const bool repeat = repeats_previous(l, pos);
                 s_qhead[l] = repeat ? (uint16_t) 0 : (uint16_t) (l + 1u);
-                if (!repeat) s_qslot[l] = name_of(pos);
+                if (!repeat) s_qslot[l] = name_slot(name_scan(pos));
             }
             __syncthreads();
             if (wave == 0) {
@@ -540,7 +594,7 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
             for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) out.q_id[r0 + l] = (int32_t) s_qslot[(uint32_t) s_qhead[l] - 1u];
             // ---- a last line that runs past the staged bytes: one thread, byte by byte out of HBM
             if (slow_last && tid == 0) {
-                const uint64_t from = b + s_start[total - 1u];
+                const uint64_t from = b + s_last_start;
                 uint64_t q = from;
                 while (q < bytes && text[q] != '\n') q++;
                 auto rd = [&](uint64_t o) { return text[o]; };

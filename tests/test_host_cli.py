@@ -325,7 +325,7 @@ def test_cli_through_the_gathered_representation(binary, name, mode):
 
 
 def test_device_tokeniser_long_lines_and_tile_borders():
-    """Lines that straddle the 32 KB tiles of the tokeniser kernel and run past the overhang staged in LDS (names of
+    """Lines that straddle the 16 KB tiles of the tokeniser kernel and run past the overhang staged in LDS (names of
     several thousand characters) are parsed through the same accessor from HBM; names of 65 535 bytes are refused."""
     import test_host_ingest as TI
     from telomeri_amd import capi
@@ -400,7 +400,7 @@ def test_cli_upload_through_the_window_reuses_its_slots(binary):
 def test_device_tokeniser_fuzz(seed):
     """Random 16-column text -- runs of blanks and tabs between tokens, leading blanks, CRLF, signs and leading zeros on
     the numbers, names of 1..40 arbitrary printable characters, a few hundred to a few thousand lines so that several
-    32 KB tiles and a last line without a newline occur -- against the token-stream model; every third seed plants one
+    16 KB tiles and a last line without a newline occur -- against the token-stream model; every third seed plants one
     defect (a 15- or 17-token line, a non-number, an int overflow, a two-character strand, a blank line): refused."""
     import test_host_ingest as TI
     from telomeri_amd import capi
