@@ -352,6 +352,32 @@ def test_device_tokeniser_long_lines_and_tile_borders():
     assert not clean
 
 
+def test_device_tokeniser_lines_around_the_overhang():
+    """Lines of 900..1150 bytes: the last line of a 16 KB tile ends just inside or just outside the 1 KB overhang that is
+    staged with the tile -- both readers of the kernel (all lanes out of LDS; one thread out of HBM) meet the same names,
+    in every phase of the line start against the tile end."""
+    import test_host_ingest as TI
+    from telomeri_amd import capi
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(1500):
+        qn = "read%d" % (i // 7)
+        tn = "t%d_" % rng.integers(0, 30) + "x" * int(rng.integers(830, 1080))
+        lines.append("%s\t9000\t%d\t8000\t%s\t%s\t7000\t5\t6990\t6500\t7990\t60\ttp:A:S\tcm:i:9\ts1:i:8\tdv:f:0.01\n" % (
+            qn, i, "+-"[i % 2], tn))
+    body = "".join(lines)
+    ctx = capi.Context(0)
+    paf = capi.PafTokens(ctx)
+    n, clean = paf.add_text(body.encode(), anchors=False)
+    assert clean and n == len(lines)
+    cols, names = TI.stream_parse(body)
+    got_names, _ = paf.finish()
+    assert got_names == names
+    got = paf.columns(0)
+    for k in cols:
+        np.testing.assert_array_equal(got[k], np.array(cols[k]), err_msg=k)
+
+
 def test_cli_text_upload_through_slabs(binary):
     """The forms of the text upload -- by the helper process through the shared window of device memory (the default), by
     this process out of its own registered mapping, by pread into pinned slabs (files that cannot be mapped) -- feed the
