@@ -394,18 +394,36 @@ def main() -> None:
         if not args.no_det:
             sets += list(g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1))
         torch.cuda.synchronize(dev)
-        t0 = time.time()
-        allp = capi.PathSet.concat(sets)
-        t1 = time.time()
-        uniq = allp.filter_unique()
-        t2 = time.time()
-        pairs = uniq.anchor_pairs()
-        t3 = time.time()
-        nbytes = 8.0 * allp.n_nodes_total          # nodes + slots of every path, read once
-        out["post_passes"] = {"paths_in": allp.n_paths, "paths_unique": uniq.n_paths, "anchor_pairs": len(pairs),
-                              "path_nodes": allp.n_nodes_total, "concat_ms": 1e3 * (t1 - t0),
-                              "filter_unique_ms": 1e3 * (t2 - t1), "anchor_pairs_ms": 1e3 * (t3 - t2),
-                              "filter_unique_GBps": 2 * nbytes / max(t2 - t1, 1e-9) / 1e9}
+        # three times: the first pass obtains its two 5 GB results from the driver (the timed steps never concatenate; that
+        # call takes 1 ms in one run and 250 ms in the next), the others find them in the library's cache -- the passes'
+        # own times are the faster of those two
+        first, best = None, None
+        for rep in range(3):
+            mi0 = ctx.memory_info()
+            t0 = time.time()
+            allp = capi.PathSet.concat(sets)
+            t1 = time.time()
+            uniq = allp.filter_unique()
+            t2 = time.time()
+            pairs = uniq.anchor_pairs()
+            t3 = time.time()
+            mi1 = ctx.memory_info()
+            nbytes = 8.0 * allp.n_nodes_total          # nodes + slots of every path, read once
+            res = {"paths_in": allp.n_paths, "paths_unique": uniq.n_paths, "anchor_pairs": len(pairs),
+                   "path_nodes": allp.n_nodes_total, "concat_ms": 1e3 * (t1 - t0),
+                   "filter_unique_ms": 1e3 * (t2 - t1), "anchor_pairs_ms": 1e3 * (t3 - t2),
+                   "filter_unique_GBps": 2 * nbytes / max(t2 - t1, 1e-9) / 1e9,
+                   "driver_allocations": int(mi1.driver_allocs - mi0.driver_allocs),
+                   "driver_allocation_ms": float(mi1.driver_alloc_ms - mi0.driver_alloc_ms)}
+            if rep == 0:
+                first = res
+            else:
+                best = res if best is None else dict(res, **{k: min(res[k], best[k]) for k in ("concat_ms", "filter_unique_ms", "anchor_pairs_ms")})
+            if rep < 2:
+                del allp, uniq
+        best["filter_unique_GBps"] = 2 * nbytes / max(best["filter_unique_ms"] * 1e-3, 1e-9) / 1e9
+        out["post_passes"] = dict(best, first_pass={k: first[k] for k in ("concat_ms", "filter_unique_ms", "anchor_pairs_ms",
+                                                                         "driver_allocations", "driver_allocation_ms")})
         del sets, allp, uniq
     except Exception as e:      # reported, never fatal for the metric line
         out["post_passes"] = {"error": str(e)}
