@@ -34,6 +34,7 @@
 #include <thread>
 
 #include "cpu_share.h"
+#include "paf_swar.h"
 #include "tlm_common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -41,6 +42,8 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 namespace {
+
+using namespace tlm_swar;       // byte classification, the strict integer, the name hash: paf_swar.h (checked on the CPU tier)
 
 constexpr uint32_t TILE = 16u << 10;            // bytes of text per workgroup
 constexpr uint32_t TILE_THREADS = 256;
@@ -66,12 +69,6 @@ struct Tmp {
     void *p = nullptr;
     ~Tmp() { tlm_pool_free(p); }
 };
-
-// 0x80 in every byte of the result whose byte of `w` is a newline
-__device__ __forceinline__ uint32_t newline_bytes(uint32_t w) {
-    w ^= 0x0A0A0A0Au;
-    return ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w | 0x7F7F7F7Fu);
-}
 
 // ---- pass A: line starts per tile.  A line starts at the text's first byte and after every newline: the tile [b, e) holds
 // (b == 0 or a newline at b - 1) + the newlines of [b, e - 1).  16 bytes per lane and load (the buffer is 64 bytes longer than
@@ -132,48 +129,6 @@ static_assert(STRETCH_WORDS % 2 == 1, "an odd stride between the threads' words:
 constexpr uint32_t TOK_SLOTS = STRETCH_WORDS * 2;                         // a token and the blank after it: two bytes at least
 static_assert(STAGED_MAX < (1u << 14) * 2 && TILE_THREADS * TOK_SLOTS < 65536 && TOK_SLOTS < 64, "offsets and token counts are packed");
 
-// 0x80 in every byte of the result whose byte of `w` is whitespace: blank, \t \n \v \f \r (what operator>> skips)
-__device__ __forceinline__ uint32_t ws_bytes(uint32_t w) {
-    const uint32_t lo7 = w & 0x7F7F7F7Fu;
-    const uint32_t ge9 = (lo7 + 0x77777777u) | w, ge14 = (lo7 + 0x72727272u) | w;       // bit 7: byte >= 9, byte >= 14
-    const uint32_t y = w ^ 0x20202020u;
-    const uint32_t blank = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y);                      // bit 7: byte == ' '
-    return ((ge9 & ~ge14) | blank) & 0x80808080u;
-}
-// 0x80 in every byte that is NOT the digit value 0..9 (x = bytes ^ '0')
-__device__ __forceinline__ uint32_t nondigit_bytes(uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u; }
-// index of the lowest flagged byte (z != 0)
-__device__ __forceinline__ uint32_t first_byte(uint32_t z) { return ((uint32_t) __ffs((int) z) >> 3) - 1u; }
-__device__ __forceinline__ bool ws_char(uint32_t c) { return c == ' ' || c - 9u < 5u; }
-
-// the four bytes at byte position p of a word array (any alignment)
-__device__ __forceinline__ uint32_t window_word(const uint32_t *w, uint32_t p) {
-    return __builtin_amdgcn_alignbit(w[(p >> 2) + 1], w[p >> 2], (p & 3u) * 8u);
-}
-
-// names are hashed a word at a time (the last one masked to the name's bytes): the same value whatever the alignment, and
-// whichever of the two readers (LDS words, bytes out of HBM) met the name
-__device__ __forceinline__ uint32_t mix_word(uint32_t h, uint32_t w) {
-    w *= 0xCC9E2D51u;
-    w = (w << 15) | (w >> 17);
-    w *= 0x1B873593u;
-    h ^= w;
-    h = (h << 13) | (h >> 19);
-    return h * 5u + 0xE6546B64u;
-}
-__device__ __forceinline__ uint32_t mix_end(uint32_t h, uint32_t len) {
-    h ^= len;
-    h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    return h ^ (h >> 16);
-}
-constexpr uint32_t NAME_SEED = 0x9747B28Cu;
-
-// the low n (0..4 and more) bytes of a word
-__device__ __forceinline__ uint32_t low_bytes(uint32_t w, uint32_t n) { return n >= 4u ? w : w & ((1u << (8u * n)) - 1u); }
-
 // `own(i)` = byte i of the name being interned (LDS or HBM); `off` = where it stands in its file.  `own16`: the name's bytes
 // as four words, zero behind its end, when it has 16 bytes or fewer (`short_name`); the first occurrence a slot shows is then
 // fetched as five aligned words at once and compared a word at a time -- one memory latency per probe instead of one per byte.
@@ -204,10 +159,10 @@ __device__ inline uint32_t dict_intern(const Dict &d, const Texts &tx, const Own
                 const uint32_t *g = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(o) & ~(uintptr_t) 3);
                 const uint32_t sh = ((uint32_t) reinterpret_cast<uintptr_t>(o) & 3u) * 8u;
                 const uint32_t g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4];
-                same = low_bytes(__builtin_amdgcn_alignbit(g1, g0, sh), len) == own16.x
-                       && low_bytes(__builtin_amdgcn_alignbit(g2, g1, sh), len > 4u ? len - 4u : 0u) == own16.y
-                       && low_bytes(__builtin_amdgcn_alignbit(g3, g2, sh), len > 8u ? len - 8u : 0u) == own16.z
-                       && low_bytes(__builtin_amdgcn_alignbit(g4, g3, sh), len > 12u ? len - 12u : 0u) == own16.w;
+                same = low_bytes(funnel(g1, g0, sh), len) == own16.x
+                       && low_bytes(funnel(g2, g1, sh), len > 4u ? len - 4u : 0u) == own16.y
+                       && low_bytes(funnel(g3, g2, sh), len > 8u ? len - 8u : 0u) == own16.z
+                       && low_bytes(funnel(g4, g3, sh), len > 12u ? len - 12u : 0u) == own16.w;
             } else {
                 for (uint32_t i = 0; i < len && same; i++) same = o[i] == own(i);
             }
@@ -281,55 +236,6 @@ __device__ void parse_line(const Read &rd, uint64_t p, const uint64_t end, Line 
         }
         L.nt++;
     }
-}
-
-// the hash of a name read byte by byte: the words mix_word sees are those of the LDS reader
-template <class Read>
-__device__ uint32_t hash_bytes(const Read &rd, uint64_t at, uint32_t len) {
-    uint32_t h = NAME_SEED;
-    for (uint32_t i = 0; i < len; i += 4) {
-        uint32_t w = 0;
-        for (uint32_t k = 0; k < 4 && i + k < len; k++) w |= (uint32_t) (unsigned char) rd(at + i + k) << (8u * k);
-        h = mix_word(h, w);
-    }
-    return mix_end(h, len);
-}
-
-// the value of `c` (0..4) digit bytes standing in the low bytes of x (first digit lowest), x = text ^ '0'
-__device__ __forceinline__ uint32_t digit_group(uint32_t x, uint32_t c) {
-    const uint32_t v = c ? x << (8u * (4u - c)) : 0u;                  // right-aligned in the word, leading zeros below
-    const uint32_t pairs = (v * 10u + (v >> 8)) & 0x00FF00FFu;         // d0 d1 | d2 d3 -> two values below 100
-    return (pairs * 100u + (pairs >> 16)) & 0xFFFFu;
-}
-__device__ __forceinline__ uint32_t pow10_upto4(uint32_t c) { return c == 0 ? 1u : c == 1 ? 10u : c == 2 ? 100u : c == 3 ? 1000u : 10000u; }
-
-// The token at byte position `pos` of the staged text as the strict integer of the host tokeniser: [+-] then 1..10 digits,
-// then whitespace (or the end of the text: the bytes behind the staged text are newlines), inside the int32 range.
-__device__ __forceinline__ bool int_token(const uint32_t *sw, uint32_t pos, int32_t &value) {
-    const uint32_t wi = pos >> 2, sh = (pos & 3u) * 8u;
-    const uint32_t a0 = sw[wi], a1 = sw[wi + 1], a2 = sw[wi + 2], a3 = sw[wi + 3], a4 = sw[wi + 4];
-    uint32_t w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh);
-    uint32_t w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
-    const uint32_t w3 = __builtin_amdgcn_alignbit(a4, a3, sh);
-    const uint32_t c0 = w0 & 0xFFu;
-    const bool neg = c0 == '-';
-    if (neg || c0 == '+') {                 // the digits start a byte later
-        w0 = __builtin_amdgcn_alignbit(w1, w0, 8u);
-        w1 = __builtin_amdgcn_alignbit(w2, w1, 8u);
-        w2 = __builtin_amdgcn_alignbit(w3, w2, 8u);
-    }
-    const uint32_t x0 = w0 ^ 0x30303030u, x1 = w1 ^ 0x30303030u, x2 = w2 ^ 0x30303030u;
-    const uint32_t n0 = nondigit_bytes(x0), n1 = nondigit_bytes(x1), n2 = nondigit_bytes(x2);
-    // m = number of digits = index of the first byte that is none (12: twelve digits at least -- no integer)
-    const uint32_t m = n0 ? first_byte(n0) : n1 ? 4u + first_byte(n1) : n2 ? 8u + first_byte(n2) : 12u;
-    const uint32_t wt = m < 4u ? w0 : m < 8u ? w1 : w2;
-    const uint32_t term = (wt >> ((m & 3u) * 8u)) & 0xFFu;
-    const bool shaped = m >= 1u && m <= 10u && ws_char(term);
-    const uint32_t c_0 = min(m, 4u), c_1 = min(m - c_0, 4u), c_2 = min(m - c_0 - c_1, 4u);
-    const uint32_t g0 = digit_group(x0, c_0), g1 = digit_group(x1, c_1), g2 = digit_group(x2, c_2);
-    const unsigned long long mag = (unsigned long long) (g0 * pow10_upto4(c_1) + g1) * pow10_upto4(c_2) + g2;
-    value = (int32_t) (neg ? 0u - (uint32_t) mag : (uint32_t) mag);
-    return shaped && mag <= (neg ? 2147483648ull : 2147483647ull);
 }
 
 // flags: 1 = a line is not 16 clean tokens, 2 = too many line starts in a tile, 4 = a name of 65 535 bytes or more
