@@ -160,6 +160,7 @@ extern "C" void tlm_ctx_destroy(tlm_ctx *ctx) {
     (void) hipFree(c->side.ws.cursor);
     if (c->resident_host) (void) hipHostFree(c->resident_host);
     if (c->pinned_small) (void) hipHostFree(c->pinned_small);
+    if (c->xchg_pinned) (void) hipHostFree(c->xchg_pinned);
     if (c->peer_window) (void) hipIpcCloseMemHandle(c->peer_window);
     if (c->upload_window) (void) hipFree(c->upload_window);
     for (hipEvent_t e : c->phase_ev) (void) hipEventDestroy(e);

@@ -630,8 +630,20 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
     const uint64_t P = std::max<uint64_t>(max_paths, 1);
     const size_t slab = (size_t) P * SummaryRow::BYTES;
     Tmp d_slab, d_allslabs;
+    char *h_all = nullptr;
     auto fill = [&]() -> int {
         if (fault_here(ctx, "alloc")) return TLM_EHIP;
+        // the slabs of all ranks land in pinned host memory kept by the context (a pageable destination is staged by the
+        // runtime at a fraction of the link's rate: 16.7 MB of summaries per step for the A. thaliana-shaped config)
+        if (ctx->xchg_pinned_bytes < slab * world) {
+            if (ctx->xchg_pinned) (void) hipHostFree(ctx->xchg_pinned);
+            ctx->xchg_pinned = nullptr;
+            ctx->xchg_pinned_bytes = 0;
+            const size_t want = slab * world + (slab * world) / 4;
+            TLM_HIP(hipHostMalloc(&ctx->xchg_pinned, want, hipHostMallocDefault));
+            ctx->xchg_pinned_bytes = want;
+        }
+        h_all = (char *) ctx->xchg_pinned;
         TLM_CHECK(rank_paths[rank] == mine, TLM_EINTERNAL, "tlm_pathset_gather_summaries: local count mismatch");
         if (int rc = tlm_pool_alloc(&d_slab.p, slab, s)) return rc;
         if (!single)
@@ -650,17 +662,16 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
         }
         return TLM_OK;
     };
-    std::vector<char> h_all(slab * world);
     if (single) {
         if (int rc = fill()) return rc;
-        TLM_HIP(hipMemcpyAsync(h_all.data(), d_slab.p, slab, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_all, d_slab.p, slab, hipMemcpyDeviceToHost, s));
         TLM_HIP(hipEventRecord(ctx->ev1, s));
         TLM_HIP(hipStreamSynchronize(s));
     } else {
         if (int rc = agree(ctx, api, fill(), "tlm_pathset_gather_summaries (summary buffers)")) return rc;
         Collective col{ctx, api};
         TLM_NCCL(api, api->AllGather(d_slab.p, d_allslabs.p, slab, ncclUint8, (ncclComm_t) ctx->comm, s));
-        TLM_HIP(hipMemcpyAsync(h_all.data(), d_allslabs.p, slab * world, hipMemcpyDeviceToHost, s));
+        TLM_HIP(hipMemcpyAsync(h_all, d_allslabs.p, slab * world, hipMemcpyDeviceToHost, s));
         TLM_HIP(hipEventRecord(ctx->ev1, s));
         TLM_HIP(hipStreamSynchronize(s));
         col.done();
@@ -675,7 +686,7 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
     uint64_t at = 0;
     for (int b = 0; b < n_sets; b++)
         for (int r = 0; r < world; r++) {
-            const char *rb = h_all.data() + slab * r;
+            const char *rb = h_all + slab * r;
             uint64_t first = 0;                 // position of block b inside rank r's concatenated set
             for (int bb = 0; bb < b; bb++) first += g->counts[(size_t) r * per_rank + 2 * bb];
             const uint64_t np = g->counts[(size_t) r * per_rank + 2 * b];

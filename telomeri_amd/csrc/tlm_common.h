@@ -50,6 +50,9 @@ struct tlm_ctx {
     // pinned host memory for the few words the graph build reads back between its phases (counts, sizes): a device-to-host
     // copy into pageable memory goes through the runtime's staging path and may block the queueing thread
     void *pinned_small = nullptr;
+    // pinned host memory of the exchange (the summaries of every rank arrive here; grows, goes with the context)
+    void *xchg_pinned = nullptr;
+    size_t xchg_pinned_bytes = 0;
     void *upload_window = nullptr; // device memory shared with an upload helper process (tlm_upload_window_create)
     void *peer_window = nullptr;   // ... and, in the helper, the other process's window (tlm_upload_window_open)
     // host-side tidying that may wait (unpinning and unmapping 15 GB of uploaded text takes 0.65 s and blocks every
