@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
                     idx -= c;
                     t++;
                 }
-                return (uint32_t) s_tok[t * TOK_SLOTS + idx];
+                return (uint32_t) s_tok[t * TOK_SLOTS + min(idx, TOK_SLOTS - 1u)];      // (idx < s_cnt[t] here; the clamp keeps any other state inside the table)
             };
             // ---- every line 16 tokens
             for (uint32_t l = tid; l < n_fast; l += TILE_THREADS) {
