@@ -393,24 +393,12 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
                 unsigned long long slot0;
             };
             auto name_scan = [&](uint32_t pos) {
+                const NameScan ns = scan_name(s_words, pos);
                 Name nm;
                 nm.pos = pos;
-                nm.first16 = make_uint4(0u, 0u, 0u, 0u);
-                uint32_t h = NAME_SEED;
-                for (uint32_t k = 0;; k++) {
-                    const uint32_t w = window_word(s_words, pos + 4u * k);
-                    const uint32_t z = ws_bytes(w);
-                    const uint32_t rest = z ? first_byte(z) : 4u;
-                    const uint32_t part = low_bytes(w, rest);
-                    if (k == 0u) nm.first16.x = part;
-                    else if (k == 1u) nm.first16.y = part;
-                    else if (k == 2u) nm.first16.z = part;
-                    else if (k == 3u) nm.first16.w = part;
-                    if (rest) h = mix_word(h, part);
-                    nm.len = 4u * k + rest;
-                    if (z) break;
-                }
-                nm.hash = mix_end(h, nm.len);
+                nm.len = ns.len;
+                nm.hash = ns.hash;
+                nm.first16 = make_uint4(ns.w0, ns.w1, ns.w2, ns.w3);
                 nm.slot0 = dict.slot[nm.hash & dict.mask];
                 return nm;
             };

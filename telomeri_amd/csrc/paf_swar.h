@@ -77,18 +77,29 @@ TLM_HD uint32_t hash_bytes(const Read &rd, uint64_t at, uint32_t len) {
     }
     return mix_end(h, len);
 }
-// ... and out of a word array: the name at byte position pos ends at the first whitespace byte (there is one)
-TLM_HD uint32_t hash_words(const uint32_t *sw, uint32_t pos, uint32_t &len) {
+// ... and out of a word array: the name at byte position pos ends at the first whitespace byte (there is one).  Also its
+// first 16 bytes as four words, zero behind its end (the dictionary compares short names a word at a time).
+struct NameScan {
+    uint32_t len, hash, w0, w1, w2, w3;
+};
+TLM_HD NameScan scan_name(const uint32_t *sw, uint32_t pos) {
+    NameScan n{0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t h = NAME_SEED;
     for (uint32_t k = 0;; k++) {
         const uint32_t w = window_word(sw, pos + 4u * k);
         const uint32_t z = ws_bytes(w);
         const uint32_t rest = z ? first_byte(z) : 4u;
-        if (rest) h = mix_word(h, low_bytes(w, rest));
-        len = 4u * k + rest;
+        const uint32_t part = low_bytes(w, rest);
+        if (k == 0u) n.w0 = part;
+        else if (k == 1u) n.w1 = part;
+        else if (k == 2u) n.w2 = part;
+        else if (k == 3u) n.w3 = part;
+        if (rest) h = mix_word(h, part);
+        n.len = 4u * k + rest;
         if (z) break;
     }
-    return mix_end(h, len);
+    n.hash = mix_end(h, n.len);
+    return n;
 }
 
 // the value of `c` (0..4) digit bytes standing in the low bytes of x (first digit lowest), x = text ^ '0'

@@ -140,9 +140,14 @@ int main() {
                     }
                     std::vector<uint32_t> words(24);
                     std::memcpy(words.data(), buf.data(), 96);
-                    uint32_t got_len = 0;
-                    const uint32_t hw = hash_words(words.data(), 8 + align, got_len);
-                    CHECK(got_len == len, "hash_words: length %u, expected %u", got_len, len);
+                    const NameScan ns = scan_name(words.data(), 8 + align);
+                    const uint32_t got_len = ns.len, hw = ns.hash;
+                    CHECK(got_len == len, "scan_name: length %u, expected %u", got_len, len);
+                    const uint32_t first16[4] = {ns.w0, ns.w1, ns.w2, ns.w3};
+                    for (unsigned i = 0; i < 16; i++) {
+                        const unsigned want = i < len ? buf[8 + align + i] : 0u;
+                        CHECK(((first16[i >> 2] >> (8 * (i & 3))) & 0xFF) == want, "scan_name: byte %u of the first 16 of a %u-byte name", i, len);
+                    }
                     const uint32_t hb = hash_bytes([&](uint64_t p) { return (char) buf[p]; }, 8 + align, len);
                     CHECK(hw == hb, "hash of a %u-byte name at alignment %u: words %08x, bytes %08x", len, align, hw, hb);
                     equal_hashes += hw == prev;
