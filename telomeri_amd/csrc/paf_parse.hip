@@ -302,7 +302,7 @@ __global__ __launch_bounds__(TILE_THREADS) void parse_tiles_kernel(Texts tx, uin
                 if (o >= staged) break;
                 const uint32_t w = s_words[w_first + k];
                 const uint32_t zw = ws_bytes(w);
-                const uint32_t st = ~zw & ((zw << 8) | carry) & 0x80808080u;
+                const uint32_t st = token_start_bytes(zw, carry);
                 carry = zw >> 24;
                 for (uint32_t z = newline_bytes(w); z; z &= z - 1u) {         // (one word in twenty-five has a newline)
                     const uint32_t kk = first_byte(z), p = o + kk;

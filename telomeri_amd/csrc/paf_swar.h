@@ -35,6 +35,9 @@ TLM_HD uint32_t ws_bytes(uint32_t w) {
     const uint32_t blank = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y);                      // bit 7: byte == ' '
     return ((ge9 & ~ge14) | blank) & 0x80808080u;
 }
+// 0x80 in every byte at which a token starts: not whitespace, behind a byte that is (`zw` = ws_bytes of the word, `carry` = 0x80 if
+// the byte in front of the word is whitespace, else 0; the next word's carry is zw >> 24).  Two per word at most.
+TLM_HD uint32_t token_start_bytes(uint32_t zw, uint32_t carry) { return ~zw & ((zw << 8) | carry) & 0x80808080u; }
 // 0x80 in every byte that is NOT the digit value 0..9 (x = bytes ^ '0')
 TLM_HD uint32_t nondigit_bytes(uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u; }
 // index of the lowest flagged byte (z != 0, flags are bit 7 of a byte)

@@ -67,6 +67,28 @@ int main() {
                     CHECK(low_bytes(w, n) == want, "low_bytes(%08x, %u)", w, n);
                 }
             }
+    // ---- token starts over running text: word by word with the carry, against the byte-wise rule
+    for (int rep = 0; rep < 2000; rep++) {
+        std::vector<unsigned char> text(256);
+        for (auto &b : text) {
+            const unsigned r = rng() % 8;
+            b = r == 0 ? '\t' : r == 1 ? ' ' : r == 2 ? '\n' : (unsigned char) (33 + rng() % 94);
+        }
+        std::vector<uint32_t> words(64);
+        std::memcpy(words.data(), text.data(), 256);
+        const bool ws_in_front = rng() & 1;
+        uint32_t carry = ws_in_front ? 0x80u : 0u;
+        for (unsigned k = 0; k < 64; k++) {
+            const uint32_t zw = ws_bytes(words[k]), st = token_start_bytes(zw, carry);
+            carry = zw >> 24;
+            CHECK(__builtin_popcount(st) <= 2, "more than two token starts in a word");
+            for (unsigned j = 0; j < 4; j++) {
+                const unsigned p = 4 * k + j;
+                const bool prev_ws = p ? is_ws(text[p - 1]) : ws_in_front;
+                CHECK((((st >> (8 * j)) & 0x80u) != 0) == (!is_ws(text[p]) && prev_ws), "token start at byte %u", p);
+            }
+        }
+    }
     // ---- digit groups: every count, every digit string
     for (unsigned c = 0; c <= 4; c++) {
         unsigned lim = 1;
