@@ -2,13 +2,17 @@
 // (SURVEY.md §8f row 3).  Host code, as in the reference: O(#paths) pointer/map logic.  The final scaffold depends
 // on several accidents of the reference's implementation; each is restated and marked QUIRK.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
 #include <numeric>
 #include <set>
+#include <sstream>
 #include <stdexcept>
+#include <thread>
 
+#include "../csrc/cpu_share.h"
 #include "telomeri_host.hpp"
 
 // ---- PathWindow (src/PathWindow.cpp:6-39) -----------------------------------------------------------
@@ -252,7 +256,7 @@ struct StageClock {             // TLM_HOST_TIMING: where the stage's time goes
     }
 };
 
-bool settle_group(PathGroup &pg, StageClock &clk, GroupResult &out) {
+bool settle_group(PathGroup &pg, StageClock &clk, GroupResult &out, std::ostream &log) {
     clk.start();
     pg.discardNotFrequent();
     clk.discard_ms += clk.lap();
@@ -261,11 +265,11 @@ bool settle_group(PathGroup &pg, StageClock &clk, GroupResult &out) {
     pg.calculateValidPathNumber();
     clk.valid_ms += clk.lap();
     if (!pg.consensus) {
-        std::cout << "No consensus sequence for group!\n" << std::endl;
+        log << "No consensus sequence for group!\n" << std::endl;
         return false;
     }
     out = GroupResult{pg.consensus, pg.consensus->length(), pg.valid_path_number};
-    std::cout << "Consensus length: " << out.length << "    " << "Valid path number: " << out.valid_paths << std::endl;
+    log << "Consensus length: " << out.length << "    " << "Valid path number: " << out.valid_paths << std::endl;
     return true;
 }
 
@@ -290,32 +294,65 @@ void announce(const char *opening, const OverlapGraph::Node &from, const Overlap
     std::cout << opening << from.name << "' and anchor '" << to.name << closing << std::endl;
 }
 
+// The anchor pairs are independent of each other: their work is dealt to the host's threads, what they have to say is
+// kept per pair and printed afterwards, pair by pair, in the order of the reference's single loop.
+template <class Fn>
+void for_each_pair(size_t n, const Fn &fn) {
+    const unsigned nt = (unsigned) std::max<size_t>(1, std::min<size_t>(std::min(tlm_cpu_share(), 32u), n));
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+}
+
 }   // namespace
 
 long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>> &paths_between_anchors,
                                   std::map<AnchorPair, std::vector<PathGroup>> &groups_for_anchors,
                                   std::map<AnchorPair, const Path *> &consensus_for_anchors, const Parameters &params) {
     // every pair's groups first (the reference reports them all before it looks for any consensus)
-    for (auto &entry : paths_between_anchors) {
-        const AnchorPair &pair = entry.first;
+    std::vector<std::map<AnchorPair, std::vector<const Path *>>::iterator> pairs;
+    for (auto it = paths_between_anchors.begin(); it != paths_between_anchors.end(); ++it) pairs.push_back(it);
+    std::vector<std::vector<PathGroup>> made(pairs.size());
+    for_each_pair(pairs.size(), [&](size_t i) { made[i] = constructGroups(pairs[i]->second, params); });       // sorts the pair's paths in place
+    for (size_t i = 0; i < pairs.size(); i++) {
+        const AnchorPair &pair = pairs[i]->first;
         announce("====> Constructing groups for paths between anchor '", *pair.first, *pair.second, "'...");
-        groups_for_anchors[pair] = constructGroups(entry.second, params);       // sorts the pair's paths in place
+        groups_for_anchors[pair] = std::move(made[i]);
         announce("<==== Finished constructing groups for paths between anchor '", *pair.first, *pair.second, "'!\n");
     }
     const auto t_groups = std::chrono::steady_clock::now();
+    // ... then every pair's consensus
+    struct PairOutcome {
+        std::string log;
+        const Path *consensus = nullptr;
+        StageClock clk;
+    };
+    std::vector<std::map<AnchorPair, std::vector<PathGroup>>::iterator> grouped;
+    for (auto it = groups_for_anchors.begin(); it != groups_for_anchors.end(); ++it) grouped.push_back(it);
+    std::vector<PairOutcome> outcome(grouped.size());
+    for_each_pair(grouped.size(), [&](size_t i) {
+        std::ostringstream log;
+        std::vector<GroupResult> settled;
+        for (PathGroup &pg : grouped[i]->second) {
+            GroupResult r;
+            if (settle_group(pg, outcome[i].clk, r, log)) settled.push_back(r);
+        }
+        outcome[i].consensus = consensus_among(settled);
+        outcome[i].log = log.str();
+    });
     StageClock clk;
     long pairs_with_consensus = 0;
-    std::vector<GroupResult> settled;
-    for (auto &entry : groups_for_anchors) {
-        const AnchorPair &pair = entry.first;
+    for (size_t i = 0; i < grouped.size(); i++) {
+        const AnchorPair &pair = grouped[i]->first;
         announce("====> Finding consensus path in each group between anchor '", *pair.first, *pair.second, "'...");
-        settled.clear();
-        for (PathGroup &pg : entry.second) {
-            GroupResult r;
-            if (settle_group(pg, clk, r)) settled.push_back(r);
-        }
+        std::cout << outcome[i].log;
         std::cout << "Done finding consensus path in each group.\n";
-        const Path *final_consensus = consensus_among(settled);
+        const Path *final_consensus = outcome[i].consensus;
         consensus_for_anchors[pair] = final_consensus;
         if (final_consensus) {
             pairs_with_consensus++;
@@ -324,12 +361,15 @@ long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>
             std::cout << "Final consensus not found!\n";
         }
         announce("====> Done finding consensus between anchor '", *pair.first, *pair.second, "'!");
+        clk.discard_ms += outcome[i].clk.discard_ms;
+        clk.consensus_ms += outcome[i].clk.consensus_ms;
+        clk.valid_ms += outcome[i].clk.valid_ms;
     }
     if (std::getenv("TLM_HOST_TIMING"))
         std::cerr << "[host timing] selectConsensus: after the groups "
                   << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_groups).count()
-                  << " ms, of it discardNotFrequent " << clk.discard_ms << ", calculateConsensusPath " << clk.consensus_ms
-                  << ", calculateValidPathNumber " << clk.valid_ms << std::endl;
+                  << " ms (summed over the threads: discardNotFrequent " << clk.discard_ms << ", calculateConsensusPath " << clk.consensus_ms
+                  << ", calculateValidPathNumber " << clk.valid_ms << ")" << std::endl;
     return pairs_with_consensus;
 }
 

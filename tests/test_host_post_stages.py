@@ -212,6 +212,27 @@ def test_binary_dump_gives_the_text_dump_result(post, name):
         assert bad.returncode == 1 and "expected" in bad.stderr
 
 
+def test_scaffold_into_a_pipe(post):
+    """The scaffold file is normally grown to its size and mapped (the threads copy their pieces into the page cache); a
+    destination that cannot be mapped -- here a FIFO with a reader behind it -- gets the same bytes through the stream."""
+    import threading
+    meta = G.load_json("tiny.json")
+    ds = _dataset("tiny")
+    with tempfile.TemporaryDirectory() as tmp:
+        dump = G.gunzip_to(tmp, "tiny.dump.gz")
+        reads, contigs, out = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "out.fifo")
+        synth.write_fasta(ds, reads, contigs)
+        os.mkfifo(out)
+        got = []
+        reader = threading.Thread(target=lambda: got.append(open(out, "rb").read()))
+        reader.start()
+        res = subprocess.run([post, dump, reads, contigs, out], capture_output=True, text=True, timeout=120)
+        reader.join(timeout=60)
+        want = meta["scaffold"]
+        assert res.returncode == want["exit"], res.stderr
+        assert got and len(got[0]) == want["bytes"] and hashlib.md5(got[0]).hexdigest() == want["md5"]
+
+
 def test_sequence_index_file_is_created_exclusively(post, tmp_path):
     """The index a Scaffolder leaves for another process (Scaffolder::save_index; the upload helper writes it into /dev/shm)
     is created O_EXCL | O_NOFOLLOW with mode 0600: a link or a file somebody put at its name is not written through."""
