@@ -413,11 +413,13 @@ Path PathManager::constructConsensusPath(const std::map<AnchorPair, std::vector<
     }
     if (!seed) throw std::out_of_range("map::at");      // what the reference's consensus_paths.at() throws here
 
+    const auto t_fetch = std::chrono::steady_clock::now();
     {   // the node lists of all candidates in ONE fetch (any of them may be chained in)
         std::vector<const Path *> need;
         for (const auto &c : open) need.push_back(c.second.consensus);
         materialise(need);
     }
+    const auto t_chain = std::chrono::steady_clock::now();
     const Path *seed_path = open.at(*seed).consensus;
     if (!seed_path->materialised()) materialise(*seed_path);
     Path scaffold;                              // a plain Path: node and edge lists only
@@ -467,5 +469,9 @@ Path PathManager::constructConsensusPath(const std::map<AnchorPair, std::vector<
         }
         open.erase(*best);
     }
+    if (std::getenv("TLM_HOST_TIMING"))
+        std::cerr << "[host timing] scaffold path: node lists of the candidates "
+                  << std::chrono::duration<double, std::milli>(t_chain - t_fetch).count() << " ms, chaining "
+                  << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chain).count() << " ms" << std::endl;
     return scaffold;
 }
