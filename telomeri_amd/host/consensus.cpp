@@ -256,20 +256,27 @@ struct StageClock {             // TLM_HOST_TIMING: where the stage's time goes
     }
 };
 
-bool settle_group(PathGroup &pg, StageClock &clk, GroupResult &out, std::ostream &log) {
+// the part of settling a group that touches nothing but lengths: any thread may do it
+void settle_lengths(PathGroup &pg, StageClock &clk) {
     clk.start();
     pg.discardNotFrequent();
     clk.discard_ms += clk.lap();
     pg.calculateConsensusPath();
     clk.consensus_ms += clk.lap();
+}
+
+// ... and the part that COMPARES paths: equal hashes are settled by the node lists, which are fetched from the device --
+// from the owning ranks, as a collective, when the paths were gathered: in the reference's order, by the calling thread
+bool settle_group(PathGroup &pg, StageClock &clk, GroupResult &out) {
+    clk.start();
     pg.calculateValidPathNumber();
     clk.valid_ms += clk.lap();
     if (!pg.consensus) {
-        log << "No consensus sequence for group!\n" << std::endl;
+        std::cout << "No consensus sequence for group!\n" << std::endl;
         return false;
     }
     out = GroupResult{pg.consensus, pg.consensus->length(), pg.valid_path_number};
-    log << "Consensus length: " << out.length << "    " << "Valid path number: " << out.valid_paths << std::endl;
+    std::cout << "Consensus length: " << out.length << "    " << "Valid path number: " << out.valid_paths << std::endl;
     return true;
 }
 
@@ -314,15 +321,15 @@ void for_each_pair(size_t n, const Fn &fn) {
 long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>> &paths_between_anchors,
                                   std::map<AnchorPair, std::vector<PathGroup>> &groups_for_anchors,
                                   std::map<AnchorPair, const Path *> &consensus_for_anchors, const Parameters &params) {
-    // One task per anchor pair: its groups, then the consensus among them -- by the same thread, so that what the first
-    // half allocates (a frequency map per group) is given back by the thread that took it (two parallel loops made the
-    // threads free each other's memory: 135 ms of CPU time in `discardNotFrequent` for 23 ms of work).  The reference reports
-    // every pair's groups before it looks for any consensus: the reports are printed afterwards, in that order.
+    // One task per anchor pair for everything that only looks at LENGTHS -- the pair's groups, the infrequent lengths
+    // dropped, the consensus of every group picked -- by one thread, so that what the first half allocates (a frequency map
+    // per group) is given back by the thread that took it (two parallel loops made the threads free each other's memory:
+    // 135 ms of CPU time in `discardNotFrequent` for 23 ms of work).  What compares paths (the valid-path count: node
+    // lists may have to be fetched, a collective when the paths were gathered) and all reports follow on this thread, in
+    // the reference's order: every pair's groups are reported before any consensus is looked for.
     const auto t_start = std::chrono::steady_clock::now();
     struct PairOutcome {
         std::vector<PathGroup> groups;
-        std::string log;
-        const Path *consensus = nullptr;
         StageClock clk;
     };
     std::vector<std::map<AnchorPair, std::vector<const Path *>>::iterator> pairs;
@@ -331,14 +338,7 @@ long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>
     for_each_pair(pairs.size(), [&](size_t i) {
         PairOutcome &o = outcome[i];
         o.groups = constructGroups(pairs[i]->second, params);       // sorts the pair's paths in place
-        std::ostringstream log;
-        std::vector<GroupResult> settled;
-        for (PathGroup &pg : o.groups) {
-            GroupResult r;
-            if (settle_group(pg, o.clk, r, log)) settled.push_back(r);
-        }
-        o.consensus = consensus_among(settled);
-        o.log = log.str();
+        for (PathGroup &pg : o.groups) settle_lengths(pg, o.clk);
     });
     for (size_t i = 0; i < pairs.size(); i++) {
         const AnchorPair &pair = pairs[i]->first;
@@ -348,12 +348,17 @@ long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>
     }
     StageClock clk;
     long pairs_with_consensus = 0;
+    std::vector<GroupResult> settled;
     for (size_t i = 0; i < pairs.size(); i++) {
         const AnchorPair &pair = pairs[i]->first;
         announce("====> Finding consensus path in each group between anchor '", *pair.first, *pair.second, "'...");
-        std::cout << outcome[i].log;
+        settled.clear();
+        for (PathGroup &pg : groups_for_anchors[pair]) {
+            GroupResult r;
+            if (settle_group(pg, clk, r)) settled.push_back(r);
+        }
         std::cout << "Done finding consensus path in each group.\n";
-        const Path *final_consensus = outcome[i].consensus;
+        const Path *final_consensus = consensus_among(settled);
         consensus_for_anchors[pair] = final_consensus;
         if (final_consensus) {
             pairs_with_consensus++;
@@ -364,7 +369,6 @@ long PathManager::selectConsensus(std::map<AnchorPair, std::vector<const Path *>
         announce("====> Done finding consensus between anchor '", *pair.first, *pair.second, "'!");
         clk.discard_ms += outcome[i].clk.discard_ms;
         clk.consensus_ms += outcome[i].clk.consensus_ms;
-        clk.valid_ms += outcome[i].clk.valid_ms;
     }
     const auto t_groups = t_start;
     if (std::getenv("TLM_HOST_TIMING"))
@@ -430,6 +434,7 @@ Path PathManager::constructConsensusPath(const std::map<AnchorPair, std::vector<
     // QUIRK: only the seed's two anchors are ever excluded from the search; the seed's own candidate stays open
     const Anchor excluded[2] = {left_end, right_end};
 
+    std::vector<const Path *> in_front;         // the pieces that grew the scaffold to the left, nearest first
     while (!open.empty()) {
         const AnchorPair *best = nullptr;
         AnchorPair best_key;
@@ -461,13 +466,32 @@ Path PathManager::constructConsensusPath(const std::map<AnchorPair, std::vector<
         if (!piece->materialised()) materialise(*piece);
         const size_t m = piece->edges_.size();
         if (grow_left) {        // nodes 0..m-1 and all edges go in front; node m is the scaffold's current first node
-            scaffold.nodes_.insert(scaffold.nodes_.begin(), piece->nodes_.begin(), piece->nodes_.begin() + (long) m);
-            scaffold.edges_.insert(scaffold.edges_.begin(), piece->edges_.begin(), piece->edges_.end());
+            in_front.push_back(piece);      // (put there in one go below: every insertion at the front moved the whole scaffold)
         } else {                // node 0 is the scaffold's current last node
             scaffold.nodes_.insert(scaffold.nodes_.end(), piece->nodes_.begin() + 1, piece->nodes_.begin() + 1 + (long) m);
             scaffold.edges_.insert(scaffold.edges_.end(), piece->edges_.begin(), piece->edges_.end());
         }
         open.erase(*best);
+    }
+    if (!in_front.empty()) {
+        size_t more_nodes = 0, more_edges = 0;
+        for (const Path *piece : in_front) {
+            more_nodes += piece->edges_.size();
+            more_edges += piece->edges_.size();
+        }
+        std::vector<const OverlapGraph::Node *> nodes;
+        std::vector<const OverlapGraph::Edge *> edges;
+        nodes.reserve(more_nodes + scaffold.nodes_.size());
+        edges.reserve(more_edges + scaffold.edges_.size());
+        for (size_t k = in_front.size(); k-- > 0;) {        // the last one added stands first
+            const Path *piece = in_front[k];
+            nodes.insert(nodes.end(), piece->nodes_.begin(), piece->nodes_.begin() + (long) piece->edges_.size());
+            edges.insert(edges.end(), piece->edges_.begin(), piece->edges_.end());
+        }
+        nodes.insert(nodes.end(), scaffold.nodes_.begin(), scaffold.nodes_.end());
+        edges.insert(edges.end(), scaffold.edges_.begin(), scaffold.edges_.end());
+        scaffold.nodes_.swap(nodes);
+        scaffold.edges_.swap(edges);
     }
     if (std::getenv("TLM_HOST_TIMING"))
         std::cerr << "[host timing] scaffold path: node lists of the candidates "
