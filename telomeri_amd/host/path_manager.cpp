@@ -174,6 +174,15 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
     graph_ = &g;
     last_counters = Counters{0, 0, 0, 0, 0, 0.0};
     const Utils::Metrics metric_of[4] = {ma, mb, ma, mb};
+    {       // room for the four sets at once (grown set by set, the Path objects of the earlier sets were moved three times)
+        uint64_t all = 0;
+        for (int k = 0; k < 4; k++) {
+            uint64_t n = 0;
+            tlm_pathset_sizes(sets[k], &n, nullptr, nullptr);
+            all += n;
+        }
+        paths_.reserve(paths_.size() + all);
+    }
     for (int k = 0; k < 4; k++) {
         std::cout << (k < 2 ? "> Monte Carlo heuristic: " : "> Deterministic heuristic: ") << Utils::getMetricName(metric_of[k])
                   << std::endl;                                                 // PathManager.cpp:16,183
