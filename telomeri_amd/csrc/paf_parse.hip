@@ -1088,6 +1088,17 @@ extern "C" int tlm_paf_names(const tlm_paf *p, uint32_t *name_off_host, char *bl
     TLM_CHECK(p && p->finished, TLM_EINVAL, "tlm_paf_names: call tlm_paf_finish first");
     TLM_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
+    // (the caller's buffers are pageable: pinned for the duration of the copy, a copy of the 12 MB name blob runs at the
+    // link's rate instead of being staged through the runtime's bounce buffers -- 17 ms -> a few)
+    struct Pinned {
+        void *p = nullptr;
+        Pinned(void *ptr, size_t bytes) {
+            if (ptr && bytes >= (1u << 20) && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr;
+            else (void) hipGetLastError();
+        }
+        ~Pinned() { if (p) (void) hipHostUnregister(p); }
+    };
+    const Pinned pin_off(name_off_host, ((size_t) p->n_names + 1) * 4), pin_blob(blob_host, p->blob_bytes);
     if (name_off_host) TLM_HIP(hipMemcpyAsync(name_off_host, p->name_off, ((size_t) p->n_names + 1) * 4, hipMemcpyDeviceToHost, s));
     if (blob_host && p->blob_bytes) TLM_HIP(hipMemcpyAsync(blob_host, p->blob, p->blob_bytes, hipMemcpyDeviceToHost, s));
     if (is_ctg_host && p->n_names) TLM_HIP(hipMemcpyAsync(is_ctg_host, p->is_ctg, p->n_names, hipMemcpyDeviceToHost, s));
