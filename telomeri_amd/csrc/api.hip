@@ -677,7 +677,11 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 a.resident_flag = c->resident_dev;
             }
             TLM_HIP(hipEventRecord(ev0, s));
-            const int out_of_bounds = is_mc ? tlm_launch_walk_mc(s, launch_waves / WPB, sq, a, ctx->walk_accounting)
+            // the kernel without the selections for long lists and order-unsafe rows, where the graph has neither (it is the
+            // same walk; the smaller kernel leaves the register allocator more room on the paths that run)
+            bool lite = is_mc && g->info.max_degree <= 512u && !getenv("TLM_WALK_FULL_KERNEL");
+            for (int k = 0; k < n_slots; k++) lite = lite && g->info.unsafe_nodes[metrics[k]] == 0u;
+            const int out_of_bounds = is_mc ? tlm_launch_walk_mc(s, launch_waves / WPB, sq, a, ctx->walk_accounting, lite)
                                             : tlm_launch_walk_det(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
             if (out_of_bounds) return TLM_EINTERNAL;         // checked build only (the message is set)
             TLM_HIP(hipGetLastError());

@@ -1031,7 +1031,10 @@ __device__ __forceinline__ int step_class(uint32_t deg, bool compact, bool safe,
     return (compact ? 0 : 4) + k;
 }
 
-template <bool SQRT, bool ACCOUNT>
+// LITE: the graph has no list of more than 512 entries and no order-unsafe row (the host has looked: tlm_graph_info) -- the
+// selections for longer lists and the serial one are not compiled in.  The kernel sits at the edge of its register budget
+// (64 vector / 78 scalar at 8 waves per SIMD): code that never runs still shapes the allocation of the code that does.
+template <bool SQRT, bool ACCOUNT, bool LITE>
 __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after,
                         uint32_t *ring, int lane, uint32_t ui, uint32_t start, uint32_t seed, int64_t len0,
                         uint32_t *acct) {
@@ -1095,16 +1098,23 @@ __device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, u
         const bool anchor_nbr = ((rfl(rec.y) >> 28) & 1u) != 0;
         const bool compact = ((rfl(rec.y) >> 29) & 1u) != 0;
         // ---- selection scan (:53-115)
-        const Selection s = !safe        ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
-                            : __builtin_expect(compact && deg <= 768u, 1)
-                                ? (deg <= 256u   ? select_short_c<4, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
-                                   : deg <= 384u ? select_short_c<6, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
-                                   : deg <= 512u ? select_short_c<8, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
-                                                 : select_short_c<12, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk))
-                            : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
-                            : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
-                            : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
-                                          : select_long<SQRT>(a, vs, rng, after, lane, row, deg, start, anchor_nbr, draws);
+        const Selection s =
+            LITE ? (compact ? (deg <= 256u   ? select_short_c<4, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                               : deg <= 384u ? select_short_c<6, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                                             : select_short_c<8, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk))
+                            : (deg <= 256u   ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+                               : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+                                             : select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)))
+            : !safe ? select_serial<SQRT>(a, vs, rng, lane, row, deg, start, draws, false, 0.0)
+            : __builtin_expect(compact && deg <= 768u, 1)
+                ? (deg <= 256u   ? select_short_c<4, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                   : deg <= 384u ? select_short_c<6, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                   : deg <= 512u ? select_short_c<8, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk)
+                                 : select_short_c<12, SQRT>(a, vs, rng, lane, row, deg, n, draws, clk))
+            : deg <= 256u ? select_short<4, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+            : deg <= 384u ? select_short<6, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+            : deg <= 512u ? select_short<8, SQRT>(a, vs, rng, lane, row, deg, start, anchor_nbr, draws, clk)
+                          : select_long<SQRT>(a, vs, rng, after, lane, row, deg, start, anchor_nbr, draws);
         evals += s.evals;
         steps++;
         if (ACCOUNT) {
@@ -1781,7 +1791,7 @@ __device__ __forceinline__ WalkArgs slot_args(const WalkArgs &a, uint32_t cu, ui
 #ifndef TLM_MC_WAVES
 #define TLM_MC_WAVES 8
 #endif
-template <bool SQRT, bool ACCOUNT = false>
+template <bool SQRT, bool ACCOUNT = false, bool LITE = false>
 __global__ __launch_bounds__(WALK_BLOCK, TLM_MC_WAVES) void walk_mc_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t mt_s[WALK_WAVES_PER_BLOCK][624];
@@ -1830,7 +1840,7 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_MC_WAVES) void walk_mc_kernel(WalkA
         h.backtrack_attempts = a.backtrack_attempts;
         h.len_threshold = a.len_threshold;
         const int64_t len0 = (int64_t) rfl(ca->node_len[start_ref]);
-        mc_walk<SQRT, ACCOUNT>(h, ws, mt_s[wib], win_s[wib], after_s[wib], ring_s[wib], lane, cu, start,
+        mc_walk<SQRT, ACCOUNT, LITE>(h, ws, mt_s[wib], win_s[wib], after_s[wib], ring_s[wib], lane, cu, start,
                       walk_seed_dev(metric, start_ref, r), len0, ACCOUNT ? acct_s[wib] : nullptr);
     }
     if (ACCOUNT) {
@@ -1925,7 +1935,7 @@ static int chk_collect(hipStream_t s, const char *kernel) {
 }
 #endif
 
-int tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+int tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account, bool lite) {
 #ifdef TLM_CHECKED
     chk_arm(s, a);
 #endif
@@ -1943,7 +1953,10 @@ int tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const W
         (void) hipMemcpyToSymbol(HIP_SYMBOL(tlm_timing), z, sizeof(z));
     }
 #endif
-    if (sqrt_metric) hipLaunchKernelGGL(walk_mc_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+    if (lite) {
+        if (sqrt_metric) hipLaunchKernelGGL((walk_mc_kernel<true, false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((walk_mc_kernel<false, false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+    } else if (sqrt_metric) hipLaunchKernelGGL(walk_mc_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(walk_mc_kernel<false>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
 #ifdef TLM_TIMING
     {
