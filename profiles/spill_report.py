@@ -40,8 +40,8 @@ def metadata(asm):
 
 
 def demangle(n):
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+(walk_\w+_kernel)ILb(\d)ELb(\d)EEEv8WalkArgs", n)
-    return "%s<SQRT=%s, ACCOUNT=%s>" % (m.group(1), m.group(2), m.group(3)) if m else n
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+(walk_\w+_kernel)ILb(\d)ELb(\d)ELb(\d)EEEv8WalkArgs", n)
+    return "%s<SQRT=%s, ACCOUNT=%s, LITE=%s>" % (m.group(1), m.group(2), m.group(3), m.group(4)) if m else n
 
 
 def functions_of_source():
@@ -74,7 +74,7 @@ def attribute(asm, starts):
     depth = 0
     chain = []
     for ln in asm.splitlines():
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+walk_\w+_kernelILb\dELb\dEEEv8WalkArgs):", ln)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+walk_\w+_kernelILb\dELb\dELb\dEEEv8WalkArgs):", ln)
         if m:
             cur = demangle(m.group(1))
             res[cur] = collections.Counter()

@@ -574,7 +574,12 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         // persistent grid = what is resident at once: blocks/CU from the occupancy query (a block is 4
         // waves), optionally capped by the tuning knob; never more than 8 blocks (32 waves) per CU
         const bool sq = metrics[0] >= 2;
-        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq), 32 / WALK_WAVES_PER_BLOCK);
+        // the kernels without the selections for long lists (and, Monte-Carlo, for order-unsafe rows) where the graph has
+        // neither: the same walks; the smaller kernels leave the register allocator more room on the paths that run (the
+        // deterministic one then fits 8 waves per SIMD instead of 6)
+        bool lite = g->info.max_degree <= 512u && !getenv("TLM_WALK_FULL_KERNEL") && !ctx->walk_accounting;
+        for (int k = 0; is_mc && k < n_slots; k++) lite = lite && g->info.unsafe_nodes[metrics[k]] == 0u;
+        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq, lite), 32 / WALK_WAVES_PER_BLOCK);
         if (ctx->waves_per_cu) bpc = std::max(1, std::min(bpc, ctx->waves_per_cu / WALK_WAVES_PER_BLOCK));
         uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) bpc * WALK_WAVES_PER_BLOCK;
         constexpr uint32_t WPB = WALK_WAVES_PER_BLOCK;
@@ -677,12 +682,8 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
                 a.resident_flag = c->resident_dev;
             }
             TLM_HIP(hipEventRecord(ev0, s));
-            // the kernel without the selections for long lists and order-unsafe rows, where the graph has neither (it is the
-            // same walk; the smaller kernel leaves the register allocator more room on the paths that run)
-            bool lite = is_mc && g->info.max_degree <= 512u && !getenv("TLM_WALK_FULL_KERNEL");
-            for (int k = 0; k < n_slots; k++) lite = lite && g->info.unsafe_nodes[metrics[k]] == 0u;
             const int out_of_bounds = is_mc ? tlm_launch_walk_mc(s, launch_waves / WPB, sq, a, ctx->walk_accounting, lite)
-                                            : tlm_launch_walk_det(s, launch_waves / WPB, sq, a, ctx->walk_accounting);
+                                            : tlm_launch_walk_det(s, launch_waves / WPB, sq, a, ctx->walk_accounting, lite);
             if (out_of_bounds) return TLM_EINTERNAL;         // checked build only (the message is set)
             TLM_HIP(hipGetLastError());
             TLM_HIP(hipEventRecord(ev1, s));

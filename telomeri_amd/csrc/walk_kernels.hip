@@ -1572,7 +1572,7 @@ __device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
     else if (TLM_IN(CHK_MAP, n, TLM_N_NODES)) vs.bm[n >> 5] &= ~(1u << (n & 31));
 }
 
-template <bool SQRT, bool ACCOUNT>
+template <bool SQRT, bool ACCOUNT, bool LITE>
 __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, uint32_t *ring, int lane, uint32_t ui,
                          uint32_t start, uint32_t start_ref, uint32_t first_slot, uint32_t *acct) {
     Visited vs;
@@ -1644,6 +1644,14 @@ __device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win
                     lbytes += (!compact && deg > 512u && deg <= 768u ? ((deg + 11u) / 12u) * 96u + 16u : step_layout_bytes(deg, compact)) - 8u;
                     if (lane == 0) atomicAdd(acct + step_class(deg, compact, true, true), 1u);
                 }
+                if (LITE)       // (no list of more than 512 entries in this graph: the host has looked)
+                    pk = compact ? (deg <= 256u   ? det_select_regs<4, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
+                                    : deg <= 384u ? det_select_regs<6, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
+                                                  : det_select_regs<8, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node))
+                                 : (deg <= 256u   ? det_select_regs<4, SQRT>(a, vs, lane, row, deg, skip_n_best, node)
+                                    : deg <= 384u ? det_select_regs<6, SQRT>(a, vs, lane, row, deg, skip_n_best, node)
+                                                  : det_select_regs<8, SQRT>(a, vs, lane, row, deg, skip_n_best, node));
+                else
                 pk = compact && deg <= 768u
                          ? (deg <= 256u   ? det_select_regs<4, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
                             : deg <= 384u ? det_select_regs<6, SQRT, true>(a, vs, lane, row, deg, skip_n_best, node)
@@ -1854,8 +1862,11 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_MC_WAVES) void walk_mc_kernel(WalkA
 #ifndef TLM_DET_WAVES
 #define TLM_DET_WAVES 6
 #endif
-template <bool SQRT, bool ACCOUNT = false>
-__global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(WalkArgs a) {
+#ifndef TLM_DET_LITE_WAVES
+#define TLM_DET_LITE_WAVES 8
+#endif
+template <bool SQRT, bool ACCOUNT = false, bool LITE = false>
+__global__ __launch_bounds__(WALK_BLOCK, LITE ? TLM_DET_LITE_WAVES : TLM_DET_WAVES) void walk_det_kernel(WalkArgs a) {
     __shared__ __attribute__((aligned(WIN_WORDS * 4))) uint32_t win_s[WALK_WAVES_PER_BLOCK][WIN_WORDS];
     __shared__ uint32_t ring_s[WALK_WAVES_PER_BLOCK][2 * PATH_RING];
     __shared__ uint32_t acct_s[ACCOUNT ? WALK_WAVES_PER_BLOCK : 1][STEP_CLASSES];      // ACCOUNT builds only
@@ -1879,7 +1890,7 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(Wal
             if (a.det_off[mid] <= unit) lo = mid;
             else hi = mid;
         }
-        det_walk<SQRT, ACCOUNT>(b, ws, win_s[wib], ring_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
+        det_walk<SQRT, ACCOUNT, LITE>(b, ws, win_s[wib], ring_s[wib], lane, cu, rfl(a.w_anchors[lo]), rfl(a.anchors[lo]),
                        (uint32_t) (unit - a.det_off[lo]), ACCOUNT ? acct_s[wib] : nullptr);
     }
     if (ACCOUNT) {
@@ -1893,10 +1904,14 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_DET_WAVES) void walk_det_kernel(Wal
 
 }  // namespace
 
-int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric) {
+int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric, bool lite) {
     int n = 0;
     hipError_t e;
-    if (is_mc) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<true>, WALK_BLOCK, 0)
+    if (lite && is_mc) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<true, false, true>, WALK_BLOCK, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<false, false, true>, WALK_BLOCK, 0);
+    else if (lite) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<true, false, true>, WALK_BLOCK, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<false, false, true>, WALK_BLOCK, 0);
+    else if (is_mc) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<true>, WALK_BLOCK, 0)
                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<false>, WALK_BLOCK, 0);
     else e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<true>, WALK_BLOCK, 0)
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<false>, WALK_BLOCK, 0);
@@ -1978,7 +1993,7 @@ int tlm_launch_walk_mc(hipStream_t s, unsigned blocks, bool sqrt_metric, const W
     return 0;
 }
 
-int tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account) {
+int tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const WalkArgs &a, bool account, bool lite) {
 #ifdef TLM_CHECKED
     chk_arm(s, a);
 #endif
@@ -1990,7 +2005,10 @@ int tlm_launch_walk_det(hipStream_t s, unsigned blocks, bool sqrt_metric, const 
 #endif
         return 0;
     }
-    if (sqrt_metric) hipLaunchKernelGGL(walk_det_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+    if (lite) {
+        if (sqrt_metric) hipLaunchKernelGGL((walk_det_kernel<true, false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((walk_det_kernel<false, false, true>), dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
+    } else if (sqrt_metric) hipLaunchKernelGGL(walk_det_kernel<true>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(walk_det_kernel<false>, dim3(blocks), dim3(WALK_BLOCK), 0, s, a);
 #ifdef TLM_CHECKED
     return chk_collect(s, "walk_det_kernel");
