@@ -639,7 +639,7 @@ def test_walks_across_lane_widths(ctx):
 
 
 @pytest.mark.parametrize("seed", list(range(64)))
-def test_fuzz_small_graphs(ctx, seed):
+def test_fuzz_small_graphs(ctx, seed, monkeypatch):
     """Random small graphs with everything the generators above keep apart mixed together: nodes without a list,
     multi-edges, lists of one entry, several anchors next to each other or none reachable, metrics that are zero,
     negative zero, negative, huge, tiny or equal (ties in the deterministic ranks), random walk parameters."""
@@ -676,9 +676,15 @@ def test_fuzz_small_graphs(ctx, seed):
     og = po.Graph.from_csr(*args)
     wp = capi.WalkParams.default(rb_att=int(rng.integers(1, 40)), bt_att=int(rng.integers(0, 8)),
                                  len_thr=int(rng.choice([20_000, 200_000, 4_700_000])))
-    for metric in (capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_ES_SQRT, capi.METRIC_OS_SQRT):
-        _walk_both(ctx, dg, og, metric, wp, mc=True)
-        _walk_both(ctx, dg, og, metric, None, mc=False)
+    # Graphs without a list of more than 512 entries (and, Monte-Carlo, without an order-unsafe row) are walked by the LITE
+    # instantiations of the kernels (csrc/api.hip); every fourth seed also goes through the full kernels, which these small
+    # graphs would otherwise never reach on their short-list paths
+    for full in ((False, True) if seed % 4 == 0 else (False,)):
+        if full:
+            monkeypatch.setenv("TLM_WALK_FULL_KERNEL", "1")
+        for metric in (capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_ES_SQRT, capi.METRIC_OS_SQRT):
+            _walk_both(ctx, dg, og, metric, wp, mc=True)
+            _walk_both(ctx, dg, og, metric, None, mc=False)
 
 
 @pytest.mark.parametrize("seed", list(range(8)))
