@@ -368,7 +368,16 @@ tlm_ctx *OverlapGraph::context() {
     return ctx;
 }
 
-OverlapGraph::OverlapGraph() = default;
+// TLM_HOST_LEAN=1: a host that cannot call set_lean() / set_packed() -- the reference's own main() linked against these
+// classes (INTEGRATION.md option A) -- still keeps the adjacency and the paths' node lists on the device.  Default: every
+// public member is filled as the reference fills it.
+static bool env_host_lean() {
+    const char *e = std::getenv("TLM_HOST_LEAN");
+    return e && std::atoi(e) != 0;
+}
+bool telomeri_host_lean_default() { return env_host_lean(); }
+
+OverlapGraph::OverlapGraph() : lean_(env_host_lean()) {}
 
 
 // ---- PAF ingestion ---------------------------------------------------------
@@ -800,7 +809,13 @@ bool OverlapGraph::load(char *filepath, bool anchors) {
         return true;
     }
     if (!rebuild()) return false;
-    std::cout << "Loaded " << edges_.size() << '/' << ctr << " edges from " << filepath << std::endl;   // :150
+    size_t kept = edges_.size();        // (a lean graph has no edges_: the count comes from the device)
+    if (lean_) {
+        tlm_graph_info gi;
+        tlm_graph_get_info(dev_, &gi);
+        kept = (size_t) (gi.n_adj / 2);
+    }
+    std::cout << "Loaded " << kept << '/' << ctr << " edges from " << filepath << std::endl;   // :150
     return true;
 }
 

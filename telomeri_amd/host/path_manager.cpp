@@ -206,6 +206,9 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
     if (!packed_) materialiseAll();
 }
 
+bool telomeri_host_lean_default();      // overlap_graph.cpp: TLM_HOST_LEAN
+PathManager::PathManager() : packed_(telomeri_host_lean_default()) {}
+
 PathManager::~PathManager() {
     for (tlm_pathset *ps : dev_sets_) tlm_pathset_destroy(ps);
     if (gathered_) tlm_gathered_destroy(gathered_);

@@ -53,6 +53,31 @@ def graph_digest(d: po.RefDump) -> str:
     return h.hexdigest()
 
 
+def normalise_report(stdout: str) -> list:
+    """The reference program's stdout as comparable lines: lap times and directory names are run-specific."""
+    out = []
+    for ln in stdout.splitlines():
+        if ln.startswith("Done (") or ln.startswith("Total time:"):
+            continue
+        for key in ("Loaded ", "Writing result to: "):
+            if ln.startswith(key) and "/" in ln:
+                head, _, path = ln.rpartition(" ")
+                ln = head + " " + os.path.basename(path)
+        out.append(ln)
+    return out
+
+
+def run_program(cli, files, fasta_out) -> dict:
+    """The unmodified reference program (oracle/_ref/Telomeri) as a whole: exit code, report, scaffold."""
+    res = subprocess.run([po.REF_MAIN] + cli + files + [fasta_out], capture_output=True, text=True)
+    rec = {"args": cli, "exit": res.returncode, "stdout": normalise_report(res.stdout),
+           "stderr": normalise_report(res.stderr)}
+    if res.returncode == 0:
+        body = open(fasta_out, "rb").read()
+        rec.update({"md5": hashlib.md5(body).hexdigest(), "bytes": len(body)})
+    return rec
+
+
 def main() -> None:
     assert po.have_ref(), "build the reference first: make -C oracle ref"
     tmp = tempfile.mkdtemp(prefix="tlm_golden_")
@@ -78,6 +103,10 @@ def main() -> None:
             "graph_sha256": graph_digest(d),
             "paths": {str(b): len(p) for b, p in d.builders.items()},
         }
+    # the whole program on the fixture (empty rr file: no paths, "No consensus found!", exit 1 -- SURVEY.md §4)
+    nofile = os.path.join(tmp, "none.fa")
+    open(nofile, "w").close()
+    known["program"] = run_program([], [empty, REF_FIXTURE, nofile, nofile], os.path.join(tmp, "fx.fa"))
     json.dump(known, open(os.path.join(HERE, "ecoli_cr_known.json"), "w"), indent=1, sort_keys=True)
 
     # --- 2. synthetic sets with full dumps
@@ -103,6 +132,12 @@ def main() -> None:
             chain = [ln for ln in res.stdout.splitlines() if ln.startswith(("ctg", "read")) and "-" in ln]
             scaffold.update({"md5": hashlib.md5(body).hexdigest(), "bytes": len(body), "chain_md5": hashlib.md5(chain[-1].encode()).hexdigest(),
                              "consensus_lines": [ln for ln in res.stdout.splitlines() if ln.startswith(("Consensus length", "Final consensus"))]})
+        # the same program with the Monte-Carlo builders switched off (--rb-att 0: no trials): everything it prints and
+        # writes then depends on the deterministic builders alone, which the device reproduces bit for bit -- the report
+        # and the scaffold of tests/test_reference_main_on_hip.py (the reference's own main() on the HIP path)
+        det_cli = list(cli)
+        det_cli[det_cli.index("--rb-att") + 1] = "0"
+        det_only = run_program(det_cli, [rr, cr, reads, contigs], os.path.join(tmp, "det.fa"))
         # grouping with parameters that force several windows / groups (independent of the walk parameters)
         groups = {}
         for gp in (("2000", "500", "0.9"), ("500", "200", "0.5"), ("100", "50", "0.99")):
@@ -114,7 +149,8 @@ def main() -> None:
         gz_write(cr, os.path.join(HERE, name + "_cr.paf.gz"))
         gz_write(dump, os.path.join(HERE, name + ".dump.gz"))
         json.dump({"args": args, "paths": {str(b): len(p) for b, p in d.builders.items()},
-                   "nodes": len(d.node_name), "adj": int(d.adj.shape[0]), "scaffold": scaffold, "groups": groups},
+                   "nodes": len(d.node_name), "adj": int(d.adj.shape[0]), "scaffold": scaffold, "groups": groups,
+                   "program_det_only": det_only},
                   open(os.path.join(HERE, name + ".json"), "w"), indent=1, sort_keys=True)
         print(name, len(d.node_name), d.adj.shape[0], {b: len(p) for b, p in d.builders.items()})
 
