@@ -61,6 +61,15 @@ def test_low_coverage_backtracking():
     _compare(ds, ["--rb-att", "60", "--bt-att", "3"])
 
 
+@pytest.mark.parametrize("seed,args", [(21, ["--rb-att", "40"]), (33, ["--rb-att", "30", "--bt-att", "4"]),
+                                       (35, ["--filter-min", "--rb-att", "25", "--len-thr", "150000"])])
+def test_hostile_datasets(seed, args):
+    """The hostile generator (telomeri_amd.synth.make_hard_dataset: repeat families whose copies make hub lists and
+    far-apart neighbours, chimeric reads, log-normal reads, skewed contigs, contig <-> contig records, multi-edges):
+    graph and all four builders of the oracle against the unmodified reference."""
+    _compare(synth.make_config("hard_tiny", seed=seed), args)
+
+
 def test_token_stream_quirks_against_reference():
     """Malformed PAF text: where operator>> stops (OverlapGraph.cpp:109-127) -- record counts and graphs of the oracle's
     loader against the reference binary."""
