@@ -12,9 +12,10 @@ scored and turned into the CSR by the library; graph-build timings are reported 
 
 Strong scaling (north_star: "anchor contigs and their Monte-Carlo trial bundles shard across the 8 GPUs"): the
 workload is the WHOLE A. thaliana-shaped config -- all 200 anchors x the reference's default 2000 Monte-Carlo trials
-x {ES, OS} + the deterministic builders -- and rank r of N walks the contiguous bundle of ceil(200 / N) anchors
-number r (N = 1: everything; N = 8: 25 anchors per GPU).  `--anchors-per-gpu K` restricts every rank to K anchors
-(diagnostics; the line then says so).
+x {ES, OS} + the deterministic builders -- and rank r of N walks, of EVERY anchor, slice r of its trial bundle and of
+its first edges (`--partition sliced`, tlm_dist_unit_share: the ranks' work is equal whatever the anchors weigh;
+N = 8: 250 trials of each of the 200 anchors per GPU).  `--partition contiguous`: round 3's bundles of ceil(200 / N)
+whole anchors; `--anchors-per-gpu K` restricts every rank to K whole anchors (diagnostics; the line then says so).
 """
 import argparse
 import json
@@ -81,7 +82,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="athaliana", help="telomeri_amd.synth.CONFIGS entry")
-    ap.add_argument("--anchors-per-gpu", type=int, default=0, help="0 = ceil(all anchors / N): the whole config is walked")
+    ap.add_argument("--anchors-per-gpu", type=int, default=0, help="0 = the whole config is walked; K = K whole anchors per rank")
+    ap.add_argument("--partition", choices=("sliced", "contiguous"), default="sliced",
+                    help="N > 1: a slice of every anchor's units per rank (default) or bundles of whole anchors")
     ap.add_argument("--no-scaffold", action="store_true", help="skip the PAF-in / FASTA-out wall-clock leg (N = 1 only)")
     ap.add_argument("--scaffold-config", default=None, help="config of the scaffold leg (default: --config)")
     ap.add_argument("--rb-att", type=int, default=2000)
@@ -201,6 +204,17 @@ def main() -> None:
     mc_range = (a0 * args.rb_att, a1 * args.rb_att)
     _, det_off = g.anchor_table()
     d0, d1 = int(det_off[a0]), int(det_off[a1])
+    # the sliced partition: this rank's units as lists (a slice of every anchor's trials / first edges)
+    sliced = (world > 1 and args.partition == "sliced" and args.anchors_per_gpu == 0
+              and not (args.separate_launches or args.serial_builders or args.no_det))
+    mc_units = g.unit_share(rank, world, wp, False) if sliced else None
+    det_units = g.unit_share(rank, world, wp, True) if sliced else None
+
+    def walk_mc_pair():         # this rank's Monte-Carlo units under both metrics (accounting, post-passes: untimed)
+        return g.walk_list(False, capi.METRIC_ES, capi.METRIC_OS, wp, mc_units) if sliced else g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range)
+
+    def walk_det_pair():
+        return g.walk_list(True, capi.METRIC_ES, capi.METRIC_OS, wp, det_units) if sliced else g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
 
     exch = {}
     state = {"abi_exchange": use_abi_exchange, "fallback": None}
@@ -208,7 +222,10 @@ def main() -> None:
     def one_step():
         # the four builders of Main.cpp:237-243; the two metrics of a builder share one persistent launch
         sets, ctrs = [], []
-        if not (args.separate_launches or args.serial_builders or args.no_det):
+        if sliced:
+            sets = list(g.walk_builders_list(capi.METRIC_ES, capi.METRIC_OS, wp, mc_units, det_units))
+            ctrs = [("mc", sets[0].counters), ("mc", sets[1].counters), ("det", sets[2].counters), ("det", sets[3].counters)]
+        elif not (args.separate_launches or args.serial_builders or args.no_det):
             # one call: the deterministic launch is queued behind the Monte-Carlo launch on a second stream
             sets = list(g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, mc_range, (d0, d1)))
             ctrs = [("mc", sets[0].counters), ("mc", sets[1].counters), ("det", sets[2].counters), ("det", sets[3].counters)]
@@ -242,9 +259,18 @@ def main() -> None:
                 del gathered
                 done = True
             except capi.TlmError as e:
-                # the exchange calls fail on EVERY rank or on none: all ranks arrive here together and go on
-                # with the harness's gather for this and the remaining steps; the line says so
-                log("rank %d: the library's exchange failed (%s); the harness's gather takes over" % (rank, e))
+                # A failure that every rank AGREED on before data moved (the failing rank's own code there, TLM_EPEER on the
+                # others, communicator intact) is one all ranks see together: they go on with the harness's gather for this
+                # and the remaining steps, and the line says so.  A failure in the MIDDLE of a collective sequence aborts the
+                # communicator (include/telomeri_hip.h, "FAILING TOGETHER"): the peers may still sit inside RCCL, so this
+                # rank must END -- the launcher then ends the others -- instead of waiting for them in another collective.
+                broken = "aborted" in str(e)
+                log("rank %d: the library's exchange failed (%s)%s" % (rank, e, "; the communicator is gone: leaving the job" if broken
+                                                                        else "; the harness's gather takes over"))
+                if broken:
+                    sys.stdout.flush()
+                    sys.stderr.flush()
+                    os._exit(5)
                 state["abi_exchange"] = False
                 state["fallback"] = str(e)[:200]
         if not done and world > 1:      # the harness's own gather over torch.distributed (gloo rehearsals; fallback)
@@ -281,6 +307,11 @@ def main() -> None:
                 det_busy_ms += c.kernel_busy_ms
     sync()
     elapsed = time.time() - t0
+    # every rank's dominant kernel: average launch and its fraction of the yardstick (min / max over the ranks go into the line)
+    my_launch_ms = mc_ms / max(mc_launches, 1)
+    my_frac = 8.0 * mc_evals / (mc_ms * 1e-3) / 8e12 if mc_ms > 0 else 0.0
+    my_det_ms = det_busy_ms / max(args.steps, 1)
+    spread = None
     if world > 1:
         t = torch.tensor([elapsed, float(evals)], dtype=torch.float64, device=cdev)
         tmax = t.clone()
@@ -289,6 +320,13 @@ def main() -> None:
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         evals_all = float(tsum[1])
+        k = torch.tensor([my_launch_ms, my_frac, my_det_ms, float(mc_evals), -my_launch_ms, -my_frac, -my_det_ms, -float(mc_evals)],
+                         dtype=torch.float64, device=cdev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)        # one collective: maxima, and minima as maxima of the negatives
+        spread = {"avg_launch_ms_max": float(k[0]), "avg_launch_ms_min": -float(k[4]), "frac_max": float(k[1]), "frac_min": -float(k[5]),
+                  "walk_det_ms_per_step_max": float(k[2]), "walk_det_ms_per_step_min": -float(k[6]),
+                  "mc_evals_max": float(k[3]), "mc_evals_min": -float(k[7]),
+                  "of": "walk_mc_kernel of every rank (rank 0's figures are the block's own); evals: this rank's share per %d steps" % args.steps}
     else:
         evals_all = float(evals)
 
@@ -309,14 +347,14 @@ def main() -> None:
         if args.no_layout_accounting:
             raise RuntimeError("switched off")
         ctx.set_walk_accounting(True)
-        a, b = g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range)
+        a, b = walk_mc_pair()
         lb_mc, ev_mc = int(a.counters.layout_bytes), int(a.counters.evals) + int(b.counters.evals)
         a_classes = list(a.counters.step_class)
         del a, b
         layout["mc"] = (lb_mc, ev_mc)
         layout["mc_classes"] = [int(x) for x in a_classes]
-        if not args.no_det and d1 > d0:
-            a, b = g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1)
+        if not args.no_det and (d1 > d0 or sliced):
+            a, b = walk_det_pair()
             layout["det"] = (int(a.counters.layout_bytes), int(a.counters.evals) + int(b.counters.evals))
             layout["det_classes"] = [int(x) for x in a.counters.step_class]
             del a, b
@@ -351,7 +389,9 @@ def main() -> None:
                                                                          apg, args.rb_att),
                    "anchors_total": n_anchors, "anchors_walked": min(apg * world, n_anchors), "anchors_per_gpu": apg, "rebuild_attempts": args.rb_att, "backtrack_attempts": args.bt_att,
                    "len_threshold": args.len_thr, "seed_policy": "per-walk mt19937",
-                   "partition": "anchor bundles per rank, CSR replicated, one all-gather of Paths (inside the timed step)"},
+                   "partition": ("sliced: every rank walks slice r of EVERY anchor's trial bundle and first edges (tlm_dist_unit_share)"
+                                 if sliced else "contiguous bundles of whole anchors per rank")
+                                + ", CSR replicated, one exchange of Paths (inside the timed step)"},
         "roofline": roofline_block(ach, traffic, traffic_source, mc_ms, mc_launches, evals_per_launch, layout.get("mc"),
                                    layout.get("mc_classes")),
         "kernels": {"walk_mc_ms_per_step": mc_ms / max(args.steps, 1),
@@ -376,6 +416,8 @@ def main() -> None:
                     "filter_score_GBps": (36.0 + 13.0) * n_records / (gi.filter_ms * 1e-3) / 1e9 if gi.filter_ms else None},
         "paths_per_step": paths_total,
     }
+    if spread:
+        out["roofline"]["ranks"] = spread
     if world > 1:
         out["exchange"] = {"transport": ("tlm_pathset_gather_summaries (RCCL all-gather of 45-byte path summaries; node lists "
                                          "stay with their owners until tlm_gathered_fetch asks)" if exchange_mode == "lazy" else
@@ -390,9 +432,9 @@ def main() -> None:
     # SURVEY.md §8f row 1, outside the timed region: paths_ = concat of the four sets, filterUnique,
     # getPathsBetweenAnchors on the device
     try:
-        sets = list(g.walk_mc2(capi.METRIC_ES, capi.METRIC_OS, wp, *mc_range))
+        sets = list(walk_mc_pair())
         if not args.no_det:
-            sets += list(g.walk_det2(capi.METRIC_ES, capi.METRIC_OS, d0, d1))
+            sets += list(walk_det_pair())
         torch.cuda.synchronize(dev)
         # three times: the first pass obtains its two 5 GB results from the driver (the timed steps never concatenate; that
         # call takes 1 ms in one run and 250 ms in the next), the others find them in the library's cache -- the passes'
@@ -428,8 +470,8 @@ def main() -> None:
     except Exception as e:      # reported, never fatal for the metric line
         out["post_passes"] = {"error": str(e)}
 
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, g, wp, g.download(cold=False), mc_range, capi)
+    if not args.no_cpu_baseline:        # rank 0, outside the timed region; the same bounded sample at every N
+        out["cpu_baseline"] = cpu_baseline(args, g, wp, g.download(cold=False), (0, g.mc_units(wp)) if sliced else mc_range, capi)
     if world == 1 and not args.no_scaffold:
         # the metric's second half: PAF + FASTA TEXT in -> scaffold FASTA out through the C++ host program, on the same
         # config, reference argv and defaults (telomeri_amd/scaffold_bench.py; outside the timed region above)
@@ -554,7 +596,17 @@ def cpu_baseline(args, g, wp, h, mc_range, capi):
                 break
     except Exception:
         pass
+    ref_ratio = ref_src = None
+    try:        # the unmodified reference against this port, one thread each, same walks (build container; oracle/ref_vs_oracle_timing.py)
+        rp = os.path.join(ROOT, "profiles", "r03_reference_vs_oracle.json")
+        run = [r for r in json.load(open(rp))["runs"] if r["config"] == "toy"][0]
+        ref_ratio = round(float(run["reference_evals_per_s"]) / float(run["oracle_evals_per_s_1thread"]), 3)
+        ref_src = "profiles/r03_reference_vs_oracle.json (toy set, build container: the unmodified reference %.3g evals/s, this port %.3g)" % (
+            run["reference_evals_per_s"], run["oracle_evals_per_s_1thread"])
+    except Exception:
+        pass
     return {"value": call.evals / dtall, "unit": "evals/s", "cores": cores, "kind": "port",
+            "reference_over_port_1thread": ref_ratio, "reference_over_port_source": ref_src,
             "sample": "MC/ES units [%d,%d) of the same graph on %d threads (%.1fs); 1 thread: %d units, %.3g evals/s" % (
                 u0, u0 + nall, cores, dtall, n1, c1.evals / dt1),
             "value_1thread": c1.evals / dt1, "cpu_model": model, "sample_matches_device": same}

@@ -37,8 +37,10 @@ extern "C" {
 /* 1: filter_score, graph, walks, path sets.  2: path summaries / fetch, Edge records, stats, the exchange (tlm_dist_*,
  * tlm_pathset_allgather, tlm_pathset_gather_summaries), memory accounting, PAF text on the device.  3 (additions only):
  * TLM_EPEER and the fail-together contract of the exchange calls, TLM_RCCL_LIB, tlm_ctx_set_walk_accounting with
- * tlm_counters.layout_bytes / step_class, tlm_ctx_release_workspaces, tlm_graph_info.phase_host_ms / sync_wait_ms. */
-#define TLM_ABI_VERSION 3
+ * tlm_counters.layout_bytes / step_class, tlm_ctx_release_workspaces, tlm_graph_info.phase_host_ms / sync_wait_ms.
+ * 4 (additions only): walks over a LIST of units (tlm_walk_list, tlm_walk_builders_list) and the sliced partition
+ * (tlm_dist_unit_share); the exchange calls return paths_ order (ascending builder | unit) whatever the partition. */
+#define TLM_ABI_VERSION 4
 
 enum {
     TLM_OK = 0,
@@ -288,6 +290,16 @@ int tlm_walk_builders(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric
                       uint64_t mc_unit_begin, uint64_t mc_unit_end, uint64_t det_unit_begin, uint64_t det_unit_end,
                       tlm_pathset **out4, tlm_counters *counters4);
 
+/* (ABI 4) The same walks over a LIST of units -- host array, strictly ascending unit ids -- instead of a range: what a rank
+ * of a SLICED partition walks (tlm_dist_unit_share: a slice of every anchor's trials / first edges).  The Path sets hold
+ * exactly those units, ordered by unit; unit_stats are in list order.  metric_b < 0: one metric (out2[0] / ctr2[0] only).
+ * Same results, unit for unit, as the range calls (reference PathManager.cpp:20-29,194-204: the loops these units come from). */
+int tlm_walk_list(tlm_ctx *ctx, const tlm_graph *g, int deterministic, int metric_a, int metric_b, const tlm_walk_params *p,
+                  uint64_t n_units, const uint64_t *units, tlm_pathset **out2, tlm_counters *ctr2);
+int tlm_walk_builders_list(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, const tlm_walk_params *p,
+                           uint64_t n_mc_units, const uint64_t *mc_units, uint64_t n_det_units, const uint64_t *det_units,
+                           tlm_pathset **out4, tlm_counters *counters4);
+
 /* ---- a9: packed Path set -------------------------------------------------------------------- */
 /* path i = nodes[off[i] .. off[i+1]); slots[k] = position, inside nodes[k]'s list, of the edge to
  * nodes[k+1] (0xFFFFFFFF at a path's last node); unit[i] ascending; length[i] = Path::length(). */
@@ -397,6 +409,13 @@ void tlm_dist_finalize(tlm_ctx *ctx);
 int tlm_dist_rank(const tlm_ctx *ctx);          /* 0 without tlm_dist_init */
 int tlm_dist_world(const tlm_ctx *ctx);         /* 1 without tlm_dist_init */
 int tlm_dist_anchor_range(const tlm_graph *g, int rank, int world, uint32_t *anchor_begin, uint32_t *anchor_end);
+/* (ABI 4) The SLICED partition: rank r walks, of EVERY anchor, trials [rb r / world, rb (r + 1) / world) (deterministic = 0)
+ * or the same slice of the anchor's first-edge units (deterministic = 1).  Every rank gets the same share of every anchor's
+ * work, whatever the anchors weigh (contigs of 20 kb and of 2 Mb, hubs): no pilot run, no collective.  `units` (host,
+ * ascending; NULL = count only) feeds tlm_walk_list / tlm_walk_builders_list.  The exchange calls return paths_ order for
+ * any partition whose ranks own disjoint units. */
+int tlm_dist_unit_share(const tlm_graph *g, const tlm_walk_params *p, int rank, int world, int deterministic, uint64_t *units,
+                        uint64_t *n_units);
 
 typedef struct {
     uint64_t bytes_sent;           /* by this rank, to all peers together */

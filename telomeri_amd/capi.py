@@ -25,7 +25,14 @@ ULONG_MAX = (1 << 64) - 1
 
 
 class TlmError(RuntimeError):
-    pass
+    """A library call failed.  `code` = the TLM_E* status (include/telomeri_hip.h), None when no call was made."""
+
+    def __init__(self, msg: str, code: Optional[int] = None) -> None:
+        super().__init__(msg)
+        self.code = code
+
+
+EPEER = -5      # TLM_EPEER: another rank of the job failed, or this context's communicator was given up
 
 
 class FilterParams(C.Structure):
@@ -153,6 +160,9 @@ def lib() -> C.CDLL:
     L.tlm_walk_det2.argtypes = [V, V, C.c_int, C.c_int, C.c_uint64, C.c_uint64, P(V), P(Counters)]
     L.tlm_walk_builders.argtypes = [V, V, C.c_int, C.c_int, P(WalkParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                     P(V), P(Counters)]
+    L.tlm_walk_list.argtypes = [V, V, C.c_int, C.c_int, C.c_int, P(WalkParams), C.c_uint64, V, P(V), P(Counters)]
+    L.tlm_walk_builders_list.argtypes = [V, V, C.c_int, C.c_int, P(WalkParams), C.c_uint64, V, C.c_uint64, V, P(V), P(Counters)]
+    L.tlm_dist_unit_share.argtypes = [V, P(WalkParams), C.c_int, C.c_int, C.c_int, V, P(C.c_uint64)]
     L.tlm_pathset_sizes.argtypes = [V, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
     L.tlm_pathset_export.argtypes = [V, C.c_int, V, V, V, V, V]
     L.tlm_pathset_unit_stats.argtypes = [V, V]
@@ -196,7 +206,7 @@ def lib() -> C.CDLL:
 
 def _check(rc: int, what: str) -> None:
     if rc != 0:
-        raise TlmError("%s failed (%d): %s" % (what, rc, lib().tlm_last_error().decode()))
+        raise TlmError("%s failed (%d): %s" % (what, rc, lib().tlm_last_error().decode()), rc)
 
 
 def _np_ptr(a: Optional[np.ndarray]):
@@ -403,6 +413,35 @@ class Graph:
         a0, a1 = C.c_uint32(), C.c_uint32()
         _check(lib().tlm_dist_anchor_range(self._h, rank, world, C.byref(a0), C.byref(a1)), "tlm_dist_anchor_range")
         return int(a0.value), int(a1.value)
+
+    def unit_share(self, rank: int, world: int, wp: "WalkParams", deterministic: bool) -> np.ndarray:
+        """tlm_dist_unit_share: the units (ascending) of rank's share under the sliced partition."""
+        n = C.c_uint64()
+        _check(lib().tlm_dist_unit_share(self._h, C.byref(wp), rank, world, int(deterministic), None, C.byref(n)), "tlm_dist_unit_share")
+        units = np.zeros(int(n.value), np.uint64)
+        _check(lib().tlm_dist_unit_share(self._h, C.byref(wp), rank, world, int(deterministic), _np_ptr(units), C.byref(n)),
+               "tlm_dist_unit_share")
+        return units
+
+    def walk_list(self, deterministic: bool, metric_a: int, metric_b: int, wp: "WalkParams", units: np.ndarray):
+        """tlm_walk_list: one builder over a list of units under one (metric_b < 0) or two metrics."""
+        units = np.ascontiguousarray(units, np.uint64)
+        h = (C.c_void_p * 2)()
+        ctr = (Counters * 2)()
+        _check(lib().tlm_walk_list(self.ctx._h, self._h, int(deterministic), metric_a, metric_b, C.byref(wp), units.shape[0],
+                                   _np_ptr(units), h, ctr), "tlm_walk_list")
+        sets = tuple(PathSet(C.c_void_p(h[k]), ctr[k], self.ctx) for k in range(1 if metric_b < 0 else 2))
+        return sets[0] if metric_b < 0 else sets
+
+    def walk_builders_list(self, metric_a: int, metric_b: int, wp: "WalkParams", mc_units: np.ndarray, det_units: np.ndarray):
+        """tlm_walk_builders_list: MC a, MC b, DET a, DET b over lists of units."""
+        mc_units = np.ascontiguousarray(mc_units, np.uint64)
+        det_units = np.ascontiguousarray(det_units, np.uint64)
+        h = (C.c_void_p * 4)()
+        ctr = (Counters * 4)()
+        _check(lib().tlm_walk_builders_list(self.ctx._h, self._h, metric_a, metric_b, C.byref(wp), mc_units.shape[0],
+                                            _np_ptr(mc_units), det_units.shape[0], _np_ptr(det_units), h, ctr), "tlm_walk_builders_list")
+        return tuple(PathSet(C.c_void_p(h[k]), ctr[k], self.ctx) for k in range(4))
 
     def kept_records(self) -> np.ndarray:
         out = np.zeros(int(self.info().n_kept), np.uint32)

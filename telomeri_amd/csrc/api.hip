@@ -408,6 +408,7 @@ __global__ void scan_totals_kernel(uint32_t n_units, const UnitOut *__restrict__
 }
 
 __global__ __launch_bounds__(256) void pack_paths_kernel(uint32_t n_units, uint64_t unit_begin,
+                                                         const uint64_t *__restrict__ unit_ids,
                                                          const UnitOut *__restrict__ units,
                                                          const uint32_t *__restrict__ p_index,
                                                          const uint64_t *__restrict__ n_off,
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void pack_paths_kernel(uint32_t n_units, uint6
         const uint32_t pi = p_index[ui], n = u.nnodes;
         const uint64_t src = u.off, dst = n_off[ui];
         if (lane == 0) {
-            o_unit[pi] = unit_begin + ui;
+            o_unit[pi] = unit_ids ? unit_ids[ui] : unit_begin + ui;
             o_len[pi] = u.len;
             o_off[pi] = dst;
         }
@@ -445,11 +446,12 @@ struct UnitBufs {
     uint32_t *p_index = nullptr;
     uint64_t *n_off = nullptr, *totals = nullptr;
     uint32_t *work_list = nullptr;
+    uint64_t *unit_ids = nullptr;
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     ~UnitBufs() {
         tlm_pool_free(units); tlm_pool_free(p_index); tlm_pool_free(n_off); tlm_pool_free(totals);
-        tlm_pool_free(work_list); tlm_pool_free(scan_tmp);
+        tlm_pool_free(work_list); tlm_pool_free(unit_ids); tlm_pool_free(scan_tmp);
     }
 };
 
@@ -486,9 +488,12 @@ int ensure_arena(Workspace &w, hipStream_t stream, uint64_t need, uint64_t keep)
 // persistent launch share the work queue, which halves the share of the tail (walk lengths differ by 2.5x).
 // `lane` 1 = the side stream and its workspace; `launched` (optional) is set once the first kernel of the call is in its
 // stream, or when the call gives up earlier; `wait_for` (optional) is waited for before that first kernel is launched.
+// `unit_list` (optional, host, strictly ascending, `unit_end` entries with unit_begin = 0): the units of the call as a list
+// instead of a range -- what a rank of a sliced partition walks (tlm_dist_unit_share).
 int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const int *metrics, const tlm_walk_params *p,
               uint64_t unit_begin, uint64_t unit_end, tlm_pathset **out, tlm_counters *ctr, int lane = 0,
-              std::atomic<int> *launched = nullptr, std::atomic<int> *wait_for = nullptr, bool wait_resident = true) {
+              std::atomic<int> *launched = nullptr, std::atomic<int> *wait_for = nullptr, bool wait_resident = true,
+              const uint64_t *unit_list = nullptr) {
     struct Signal {         // whoever waits for this call's launch is let go when the call ends, whatever happened
         std::atomic<int> *f;
         std::atomic<int> *gate;
@@ -515,8 +520,16 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
     hipStream_t s = lane ? c->side.stream : ctx->stream;
     hipEvent_t ev0 = lane ? c->side.ev0 : ctx->ev0, ev1 = lane ? c->side.ev1 : ctx->ev1;
     const uint64_t total = is_mc ? tlm_mc_units(g, p) : tlm_det_units(g);
-    if (unit_end > total) unit_end = total;
-    if (unit_begin > unit_end) unit_begin = unit_end;
+    if (unit_list) {
+        TLM_CHECK(unit_begin == 0, TLM_EINVAL, "walk: a unit list starts at local index 0");
+        for (uint64_t i = 0; i < unit_end; i++)
+            TLM_CHECK(unit_list[i] < total && (i == 0 || unit_list[i - 1] < unit_list[i]), TLM_EINVAL,
+                      "walk: unit list entry %llu (%llu) is out of range or not ascending", (unsigned long long) i,
+                      (unsigned long long) unit_list[i]);
+    } else {
+        if (unit_end > total) unit_end = total;
+        if (unit_begin > unit_end) unit_begin = unit_end;
+    }
     const uint64_t n_units64 = unit_end - unit_begin;
     TLM_CHECK(n_units64 * (uint64_t) n_slots < (1ull << 31), TLM_ELIMIT, "walk: %llu units in one call (limit 2^31)",
               (unsigned long long) n_units64);
@@ -543,6 +556,11 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
     if (int rc = pmalloc(&u.n_off, n_units, s)) return rc;
     if (int rc = pmalloc(&u.totals, 2, s)) return rc;
     if (int rc = pmalloc(&u.work_list, n_all, s)) return rc;
+    if (unit_list && n_units) {
+        if (int rc = pmalloc(&u.unit_ids, n_units, s)) return rc;
+        TLM_HIP(hipMemcpyAsync(u.unit_ids, unit_list, (size_t) n_units * 8, hipMemcpyHostToDevice, s));
+        TLM_HIP(hipStreamSynchronize(s));           // (the caller's array is read now, not when the stream gets there)
+    }
     TLM_HIP(hipMemsetAsync(u.units, 0xFF, (size_t) (n_all ? n_all : 1) * sizeof(UnitOut), s));   // status = not run
 
     if (int rc = W.ensure_h_units(((size_t) n_all + 1) * sizeof(UnitOut))) return rc;
@@ -632,6 +650,17 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         a.units = u.units;
         a.n_ent = g->n_adj_pad;
         a.n_work_all = n_all;
+        a.unit_ids = u.unit_ids;
+        // a unit list: the longest run of units that share a start anchor stands in for "an anchor's trials" below
+        uint32_t list_run = 0;
+        if (unit_list && is_mc && p->rebuild_attempts > 0) {
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < n_units; i++) {
+                const bool same = i && unit_list[i] / (uint64_t) p->rebuild_attempts == unit_list[i - 1] / (uint64_t) p->rebuild_attempts;
+                run = same ? run + 1 : 1;
+                list_run = std::max(list_run, run);
+            }
+        }
 
         std::vector<uint32_t> work;     // empty = identity
         uint32_t n_work = n_all;
@@ -646,8 +675,9 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
             // 94.7 -> 92.1 ms; the A. thaliana-shaped graph (234; bound by instruction issue) is indifferent between a
             // quarter, a half and a whole anchor (738.4 / 737.6 / 742.6 ms).  Round 2 dealt quarters everywhere.
             const double mean_list = g->n_nodes ? (double) g->n_adj / (double) g->n_nodes : 0.0;
+            const int per_anchor = unit_list ? (int) list_run : (is_mc ? p->rebuild_attempts : 0);
             a.chunk = !work.empty() ? 8u
-                      : is_mc       ? (uint32_t) std::max(1, mean_list >= 300.0 ? p->rebuild_attempts : p->rebuild_attempts / 2)
+                      : is_mc       ? (uint32_t) std::max(1, mean_list >= 300.0 || unit_list ? per_anchor : per_anchor / 2)
                                     : 32u;
             if (const char *e = getenv("TLM_WALK_CHUNK")) a.chunk = (uint32_t) std::max(1, atoi(e));   // tuning experiments
             a.scratch = W.scratch;
@@ -774,7 +804,7 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         if (int rc = pmalloc(&ps->slots, ps->n_nodes_total, s)) return rc;
         if (n_units) {
             uint32_t blocks = std::min<uint32_t>((n_units + 3) / 4, 256u * 8u);
-            hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, du,
+            hipLaunchKernelGGL(pack_paths_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, n_units, unit_begin, u.unit_ids, du,
                                u.p_index, u.n_off, W.arena, ps->unit, ps->length, ps->off, ps->nodes, ps->slots);
             TLM_HIP(hipGetLastError());
         }
@@ -861,6 +891,55 @@ extern "C" int tlm_walk_builders(tlm_ctx *ctx, const tlm_graph *g, int metric_a,
     });
     const int rc_mc = det_first ? run_walks(ctx, g, true, 2, m, p, mc_begin, mc_end, out4, cm, 0, nullptr, &det_launched, false)
                                 : run_walks(ctx, g, true, 2, m, p, mc_begin, mc_end, out4, cm, 0, &mc_launched);
+    side.join();
+    if (rc_mc != TLM_OK || rc_det != TLM_OK) {
+        if (rc_mc == TLM_OK) tlm_set_error("%s", det_err);
+        for (int k = 0; k < 4; k++) {
+            tlm_pathset_destroy(out4[k]);
+            out4[k] = nullptr;
+        }
+        return rc_mc != TLM_OK ? rc_mc : rc_det;
+    }
+    if (ctr4) {
+        ctr4[0] = cm[0]; ctr4[1] = cm[1]; ctr4[2] = cd[0]; ctr4[3] = cd[1];
+    }
+    return TLM_OK;
+}
+
+/* (ABI 4) The same calls over a LIST of units (host array, strictly ascending) instead of a range: what a rank of a sliced
+ * partition walks (tlm_dist_unit_share).  Results: the Path set of exactly those units, ordered by unit; unit_stats in
+ * list order. */
+extern "C" int tlm_walk_list(tlm_ctx *ctx, const tlm_graph *g, int deterministic, int metric_a, int metric_b,
+                             const tlm_walk_params *p, uint64_t n_units, const uint64_t *units, tlm_pathset **out2,
+                             tlm_counters *ctr2) {
+    TLM_CHECK(deterministic || p, TLM_EINVAL, "tlm_walk_list: null parameters");
+    TLM_CHECK(units || !n_units, TLM_EINVAL, "tlm_walk_list: null unit list");
+    const int m[2] = {metric_a, metric_b};
+    static const uint64_t none = 0;
+    return run_walks(ctx, g, !deterministic, metric_b < 0 ? 1 : 2, m, deterministic ? nullptr : p, 0, n_units, out2, ctr2, 0, nullptr,
+                     nullptr, true, units ? units : &none);
+}
+
+extern "C" int tlm_walk_builders_list(tlm_ctx *ctx, const tlm_graph *g, int metric_a, int metric_b, const tlm_walk_params *p,
+                                      uint64_t n_mc, const uint64_t *mc_units, uint64_t n_det, const uint64_t *det_units,
+                                      tlm_pathset **out4, tlm_counters *ctr4) {
+    TLM_CHECK(ctx && g && out4 && p && (mc_units || !n_mc) && (det_units || !n_det), TLM_EINVAL, "tlm_walk_builders_list: null argument");
+    for (int k = 0; k < 4; k++) out4[k] = nullptr;
+    static const uint64_t none = 0;
+    if (!mc_units) mc_units = &none;
+    if (!det_units) det_units = &none;
+    const int m[2] = {metric_a, metric_b};
+    tlm_counters cd[2], cm[2];
+    std::memset(cd, 0, sizeof(cd));
+    std::memset(cm, 0, sizeof(cm));
+    std::atomic<int> mc_launched{0};
+    int rc_det = TLM_OK;
+    char det_err[512] = "";
+    std::thread side([&] {          // as tlm_walk_builders: the deterministic launch starts in the Monte-Carlo launch's tail
+        rc_det = run_walks(ctx, g, false, 2, m, nullptr, 0, n_det, out4 + 2, cd, 1, nullptr, &mc_launched, true, det_units);
+        if (rc_det != TLM_OK) std::snprintf(det_err, sizeof(det_err), "%s", tlm_last_error());
+    });
+    const int rc_mc = run_walks(ctx, g, true, 2, m, p, 0, n_mc, out4, cm, 0, &mc_launched, nullptr, true, mc_units);
     side.join();
     if (rc_mc != TLM_OK || rc_det != TLM_OK) {
         if (rc_mc == TLM_OK) tlm_set_error("%s", det_err);

@@ -318,6 +318,35 @@ extern "C" int tlm_dist_anchor_range(const tlm_graph *g, int rank, int world, ui
     return TLM_OK;
 }
 
+/* The SLICED partition (ABI 4; the default of the hosts since round 4): rank r of `world` walks, of EVERY anchor, the slice
+ * [rb * r / world, rb * (r + 1) / world) of its Monte-Carlo trials and the slice [d * r / world, d * (r + 1) / world) of its
+ * d deterministic units.  Trials of one anchor are independent walks of the same neighbourhood (per-walk seeds), so every
+ * rank gets the same share of every anchor's work whatever the anchors weigh: hostile config, 8 ranks: max / mean 1.007
+ * against 1.64 for contiguous bundles (profiles/r04_predicted_scaling_athaliana_hard.json).  units: ascending, or null to
+ * ask for the count alone. */
+extern "C" int tlm_dist_unit_share(const tlm_graph *g, const tlm_walk_params *p, int rank, int world, int deterministic,
+                                   uint64_t *units, uint64_t *n_units) {
+    TLM_CHECK(g && n_units && world >= 1 && rank >= 0 && rank < world && (deterministic || p), TLM_EINVAL,
+              "tlm_dist_unit_share: bad argument");
+    const uint64_t na = g->h_anchors.size(), R = (uint64_t) rank, W = (uint64_t) world;
+    uint64_t n = 0;
+    if (!deterministic) {
+        const uint64_t rb = (uint64_t) std::max(p->rebuild_attempts, 0);
+        const uint64_t t0 = rb * R / W, t1 = rb * (R + 1) / W;
+        for (uint64_t a = 0; a < na; a++)
+            for (uint64_t t = t0; t < t1; t++, n++)
+                if (units) units[n] = a * rb + t;
+    } else {
+        for (uint64_t a = 0; a < na; a++) {
+            const uint64_t base = g->h_det_off[a], d = g->h_det_off[a + 1] - base;
+            for (uint64_t k = d * R / W; k < d * (R + 1) / W; k++, n++)
+                if (units) units[n] = base + k;
+        }
+    }
+    *n_units = n;
+    return TLM_OK;
+}
+
 extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *const *sets, tlm_pathset **out,
                                      tlm_exchange_info *info) {
     TLM_CHECK(ctx && sets && out && n_sets >= 1 && n_sets <= 8, TLM_EINVAL, "tlm_pathset_allgather: bad argument");
@@ -513,10 +542,17 @@ extern "C" int tlm_pathset_allgather(tlm_ctx *ctx, int n_sets, tlm_pathset *cons
         info->bytes_sent = sent;
         info->bytes_received = received;
         info->slot_bits = wide ? 32 : 16;
-        info->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
     }
+    // blocks were placed builder by builder in rank order, which IS paths_ order when every rank walked a contiguous range
+    // of units; the blocks of a sliced partition interleave: ascending (builder | unit) is restored here
     guard.p = nullptr;
-    *out = ps;
+    tlm_pathset *sorted = nullptr;
+    if (int rc = tlm_pathset_sort_by_unit(ctx, ps, &sorted)) {
+        tlm_pathset_destroy(ps);
+        return rc;
+    }
+    if (info) info->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wall).count();
+    *out = sorted;
     return TLM_OK;
 }
 
@@ -534,7 +570,7 @@ struct tlm_gathered {
     int world = 1, rank = 0, n_sets = 0;
     tlm_pathset *local = nullptr;           // this rank's sets, concatenated (builder tags in `unit`)
     std::vector<uint64_t> counts;           // [world][n_sets][2]
-    // every path of the job, in paths_ order (builder by builder, rank order inside)
+    // every path of the job, in paths_ order (ascending builder tag | unit)
     std::vector<uint64_t> unit, hash, local_index;      // local_index: position inside the owner's concatenated set
     std::vector<int64_t> length;
     std::vector<uint32_t> front, back, n_nodes, owner;
@@ -677,36 +713,58 @@ extern "C" int tlm_pathset_gather_summaries(tlm_ctx *ctx, int n_sets, tlm_pathse
         col.done();
     }
 
-    // ---- paths_ order on the host: builder by builder, rank order inside
+    // ---- paths_ order on the host: ascending (builder tag | unit).  Every rank's slab is ascending (tlm_pathset_concat:
+    // builder by builder, units ascending inside), so this is a merge of `world` sorted runs; with contiguous bundles it
+    // degenerates to "builder by builder, rank order inside", with a sliced partition the ranks alternate anchor by anchor
     uint64_t total = 0;
     for (int r = 0; r < world; r++) total += rank_paths[r];
     g->unit.resize(total); g->hash.resize(total); g->local_index.resize(total); g->length.resize(total);
     g->front.resize(total); g->back.resize(total); g->n_nodes.resize(total); g->owner.resize(total);
     g->dup.resize(total); g->block_first.assign(total, 0);
-    uint64_t at = 0;
-    for (int b = 0; b < n_sets; b++)
-        for (int r = 0; r < world; r++) {
-            const char *rb = h_all + slab * r;
-            uint64_t first = 0;                 // position of block b inside rank r's concatenated set
-            for (int bb = 0; bb < b; bb++) first += g->counts[(size_t) r * per_rank + 2 * bb];
-            const uint64_t np = g->counts[(size_t) r * per_rank + 2 * b];
-            for (uint64_t i = 0; i < np; i++, at++) {
-                const uint64_t k = first + i;
-                std::memcpy(&g->unit[at], rb + 8 * k, 8);
-                std::memcpy(&g->length[at], rb + 8 * P + 8 * k, 8);
-                std::memcpy(&g->hash[at], rb + 16 * P + 8 * k, 8);
-                std::memcpy(&g->front[at], rb + 24 * P + 4 * k, 4);
-                std::memcpy(&g->back[at], rb + 28 * P + 4 * k, 4);
-                std::memcpy(&g->n_nodes[at], rb + 32 * P + 4 * k, 4);
-                g->dup[at] = (uint8_t) rb[36 * P + k];
-                g->owner[at] = (uint32_t) r;
-                g->local_index[at] = k;
-                if (i == 0) {                   // its predecessor in paths_ order lives in another block: decided by the
-                    g->block_first[at] = 1;     // caller through tlm_gathered_fetch when the summaries coincide
-                    g->dup[at] = 0;
+    {
+        std::vector<uint64_t> head(world, 0);
+        auto unit_of = [&](int r, uint64_t k) {
+            uint64_t u;
+            std::memcpy(&u, h_all + slab * r + 8 * k, 8);
+            return u;
+        };
+        int prev_r = -1;
+        uint64_t prev_k = 0, prev_unit = 0;
+        for (uint64_t at = 0; at < total; at++) {
+            int r = -1;
+            uint64_t best = 0;
+            for (int q = 0; q < world; q++) {
+                if (head[q] >= rank_paths[q]) continue;
+                const uint64_t u = unit_of(q, head[q]);
+                if (r < 0 || u < best) {        // (equal units on two ranks cannot happen: a unit has one owner; lowest rank first)
+                    r = q;
+                    best = u;
                 }
             }
+            const uint64_t k = head[r]++;
+            const char *rb = h_all + slab * r;
+            g->unit[at] = best;
+            std::memcpy(&g->length[at], rb + 8 * P + 8 * k, 8);
+            std::memcpy(&g->hash[at], rb + 16 * P + 8 * k, 8);
+            std::memcpy(&g->front[at], rb + 24 * P + 4 * k, 4);
+            std::memcpy(&g->back[at], rb + 28 * P + 4 * k, 4);
+            std::memcpy(&g->n_nodes[at], rb + 32 * P + 4 * k, 4);
+            g->dup[at] = (uint8_t) rb[36 * P + k];
+            g->owner[at] = (uint32_t) r;
+            g->local_index[at] = k;
+            // the owner compared path k with path k - 1 of ITS set: that flag stands iff k - 1 is also the predecessor in
+            // paths_ order; otherwise the predecessor lives elsewhere and the caller settles it (tlm_gathered_fetch) when the
+            // two summaries coincide
+            // (a builder's first path is marked too, as before: Path sets of different builder calls meet there)
+            if (!(r == prev_r && k == prev_k + 1) || (best >> 56) != (prev_unit >> 56)) {
+                g->block_first[at] = 1;
+                g->dup[at] = 0;
+            }
+            prev_r = r;
+            prev_k = k;
+            prev_unit = best;
         }
+    }
     if (info) {
         float ms = 0;
         (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);

@@ -16,6 +16,7 @@
 #include "tlm_common.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
@@ -236,6 +237,79 @@ extern "C" int tlm_pathset_concat(tlm_ctx *ctx, int n, tlm_pathset *const *sets,
     TLM_HIP(hipMemcpyAsync(ps->off + np, &nn, 8, hipMemcpyHostToDevice, s));
     TLM_HIP(hipStreamSynchronize(s));
     TLM_HIP(hipGetLastError());
+    *out = ps;
+    return TLM_OK;
+}
+
+namespace {
+
+__global__ void count_descents_kernel(uint64_t n, const uint64_t *__restrict__ unit, uint32_t *__restrict__ descents) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        c += unit[i] < unit[i - 1];
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(descents, c);
+}
+
+__global__ void iota_kernel(uint64_t n, uint64_t *__restrict__ idx) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) idx[i] = i;
+}
+
+__global__ void sorted_counts_kernel(uint64_t n, const uint64_t *__restrict__ order, const uint64_t *__restrict__ off,
+                                     const int64_t *__restrict__ length, uint64_t *__restrict__ cnt, int64_t *__restrict__ o_length) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t j = order[i];
+        cnt[i] = off[j + 1] - off[j];
+        o_length[i] = length[j];
+    }
+}
+
+}   // namespace
+
+/* paths_ order is ascending (builder tag | unit): a set assembled from blocks that interleave in that order (the full
+ * exchange of a sliced partition) is brought into it here -- radix sort of the units, scan of the node counts, one gather.
+ * Consumes `in`; hands it back untouched when it is ascending already. */
+int tlm_pathset_sort_by_unit(tlm_ctx *ctx, tlm_pathset *in, tlm_pathset **out) {
+    TLM_CHECK(ctx && in && out && in->ctx == ctx, TLM_EINVAL, "tlm_pathset_sort_by_unit: bad argument");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = in->n_paths;
+    *out = in;
+    if (n < 2) return TLM_OK;
+    Tmp cnt, key2, idx, idx2, tmp, ncnt;
+    if (int rc = tlm_pool_alloc(&cnt.p, 4, s)) return rc;
+    TLM_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
+    hipLaunchKernelGGL(count_descents_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, in->unit, (uint32_t *) cnt.p);
+    uint32_t descents = 0;
+    TLM_HIP(hipMemcpyAsync(&descents, cnt.p, 4, hipMemcpyDeviceToHost, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    if (!descents) return TLM_OK;
+    tlm_pathset *ps = nullptr;
+    if (int rc = alloc_pathset(ctx, n, in->n_nodes_total, &ps)) return rc;
+    struct Drop {
+        tlm_pathset *p;
+        ~Drop() { tlm_pathset_destroy(p); }
+    } drop{ps};
+    if (int rc = tlm_pool_alloc(&idx.p, n * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&idx2.p, n * 8, s)) return rc;
+    if (int rc = tlm_pool_alloc(&ncnt.p, n * 8, s)) return rc;
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, (uint64_t *) idx.p);
+    size_t tb = 0, tb2 = 0;
+    TLM_HIP(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *) in->unit, (unsigned long long *) ps->unit, (unsigned long long *) idx.p,
+                                      (unsigned long long *) idx2.p, (size_t) n, 0, 64, s));
+    TLM_HIP(rocprim::exclusive_scan(nullptr, tb2, (uint64_t *) ncnt.p, ps->off, (uint64_t) 0, (size_t) n, rocprim::plus<uint64_t>(), s));
+    if (int rc = tlm_pool_alloc(&tmp.p, std::max<size_t>(std::max(tb, tb2), 16), s)) return rc;
+    TLM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (unsigned long long *) in->unit, (unsigned long long *) ps->unit, (unsigned long long *) idx.p,
+                                      (unsigned long long *) idx2.p, (size_t) n, 0, 64, s));
+    hipLaunchKernelGGL(sorted_counts_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, (const uint64_t *) idx2.p, in->off, in->length,
+                       (uint64_t *) ncnt.p, ps->length);
+    TLM_HIP(rocprim::exclusive_scan(tmp.p, tb2, (uint64_t *) ncnt.p, ps->off, (uint64_t) 0, (size_t) n, rocprim::plus<uint64_t>(), s));
+    hipLaunchKernelGGL(fetch_kernel, dim3(blocks_for(n, 4)), dim3(256), 0, s, n, (const uint64_t *) idx2.p, (const uint64_t *) ps->off,
+                       in->off, in->nodes, in->slots, ps->nodes, ps->slots);
+    TLM_HIP(hipMemcpyAsync(ps->off + n, &in->n_nodes_total, 8, hipMemcpyHostToDevice, s));
+    TLM_HIP(hipStreamSynchronize(s));
+    TLM_HIP(hipGetLastError());
+    drop.p = in;            // the unsorted set goes, the sorted one is the result
     *out = ps;
     return TLM_OK;
 }

@@ -125,6 +125,8 @@ struct tlm_pathset {
     std::vector<tlm_unit_stat> stats;   // host copy
 };
 
+int tlm_pathset_sort_by_unit(tlm_ctx *ctx, tlm_pathset *in, tlm_pathset **out);     // pathset_ops.hip (consumes `in`)
+
 // Every device buffer of the library comes from its own per-device cache (device_pool.hip): blocks are hipMalloc'd once
 // and re-used by later requests of (nearly) the same size; hipMalloc / hipFree of hundreds of megabytes per builder call
 // cost milliseconds and synchronise the device.  Nothing process-wide (the device's default memory pool) is touched.

@@ -74,6 +74,9 @@ struct WalkArgs {
     // sizes the checked build (-DTLM_CHECKED) compares indices with; unused kernel arguments cost no registers
     uint64_t n_ent;                 // entries of the walk-layout arrays (ents / met / d16 / qt): zero block + padded rows
     uint32_t n_work_all;            // entries of `units`
+    // (ABI 4) the units of the call as an ascending LIST instead of the range [unit_begin, unit_begin + n_units): unit of
+    // local index ui = unit_ids[ui]; null = the range.  Read once per walk, where the unit becomes (anchor, trial / edge).
+    const uint64_t *unit_ids;
 };
 
 constexpr int WALK_RNG_WORDS = 640;             // raw std::mt19937 state of a wave (624 words), kept in HBM between twists

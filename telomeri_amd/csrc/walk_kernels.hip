@@ -1829,7 +1829,8 @@ __global__ __launch_bounds__(WALK_BLOCK, TLM_MC_WAVES) void walk_mc_kernel(WalkA
         const uint32_t n_units = ca->n_units;
         const bool slot1 = cu >= n_units;                  // at most two slots
         const uint32_t ui = cu - (slot1 ? n_units : 0u);
-        const uint64_t unit = ca->unit_begin + ui;
+        const uint64_t *ids = ca->unit_ids;
+        const uint64_t unit = ids ? ((__attribute__((address_space(4))) const uint64_t *) ids)[ui] : ca->unit_begin + ui;
         const uint64_t rb = (uint64_t) ca->rebuild_attempts;
         const uint32_t a_rank = (uint32_t) (unit / rb);
         const uint32_t r = (uint32_t) (unit % rb);
@@ -1883,7 +1884,8 @@ __global__ __launch_bounds__(WALK_BLOCK, LITE ? TLM_DET_LITE_WAVES : TLM_DET_WAV
     while (next_work(lane, q, cu)) {
         uint32_t ui;
         const WalkArgs b = slot_args(a, cu, ui);
-        const uint64_t unit = a.unit_begin + ui;
+        const uint64_t *ids = cold_args()->unit_ids;        // (from the kernarg segment: not a register across the walk)
+        const uint64_t unit = ids ? ((__attribute__((address_space(4))) const uint64_t *) ids)[ui] : a.unit_begin + ui;
         uint32_t lo = 0, hi = a.n_anchors;          // largest k with det_off[k] <= unit
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) / 2;

@@ -101,6 +101,21 @@ void PathManager::gather() {
               << " bytes sent, " << xi.device_ms << " ms)." << std::endl;
 }
 
+// Which units a rank of a multi-process job walks.  "sliced" (default): of EVERY anchor the rank's slice of the trials /
+// first edges (tlm_dist_unit_share: balanced whatever the anchors weigh); "contiguous" (TLM_PARTITION=contiguous): round
+// 3's bundles of whole anchors (tlm_dist_anchor_range).  The exchange returns paths_ order either way.
+static bool partition_is_sliced() {
+    const char *e = std::getenv("TLM_PARTITION");
+    return !(e && std::string(e) == "contiguous");
+}
+static std::vector<uint64_t> unit_share(tlm_ctx *ctx, tlm_graph *dg, const tlm_walk_params &wp, bool det) {
+    uint64_t n = 0;
+    if (tlm_dist_unit_share(dg, &wp, tlm_dist_rank(ctx), tlm_dist_world(ctx), det ? 1 : 0, nullptr, &n) != TLM_OK) die_tlm("unit share");
+    std::vector<uint64_t> u(n);
+    if (tlm_dist_unit_share(dg, &wp, tlm_dist_rank(ctx), tlm_dist_world(ctx), det ? 1 : 0, u.data(), &n) != TLM_OK) die_tlm("unit share");
+    return u;
+}
+
 void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, bool mc) {
     tlm_ctx *ctx = OverlapGraph::context();
     tlm_graph *dg = g.device_graph();
@@ -114,7 +129,8 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
     tlm_counters c{};
     // this rank's share of the units: the anchors of its bundle (all of them in a one-process job)
     uint64_t u0 = 0, u1 = mc ? tlm_mc_units(dg, &wp) : tlm_det_units(dg);
-    if (tlm_dist_world(ctx) > 1) {
+    const bool sliced = tlm_dist_world(ctx) > 1 && partition_is_sliced();
+    if (tlm_dist_world(ctx) > 1 && !sliced) {
         uint32_t a0 = 0, a1 = 0;
         if (tlm_dist_anchor_range(dg, tlm_dist_rank(ctx), tlm_dist_world(ctx), &a0, &a1) != TLM_OK) die_tlm("anchor range");
         if (mc) {
@@ -130,7 +146,13 @@ void PathManager::build(const OverlapGraph &g, const Utils::Metrics &metric, boo
             u1 = det_off[a1];
         }
     }
-    const int rc = mc ? tlm_walk_mc(ctx, dg, m, &wp, u0, u1, &ps, &c) : tlm_walk_det(ctx, dg, m, u0, u1, &ps, &c);
+    int rc;
+    if (sliced) {
+        const std::vector<uint64_t> units = unit_share(ctx, dg, wp, !mc);
+        rc = tlm_walk_list(ctx, dg, mc ? 0 : 1, m, -1, &wp, units.size(), units.data(), &ps, &c);
+    } else {
+        rc = mc ? tlm_walk_mc(ctx, dg, m, &wp, u0, u1, &ps, &c) : tlm_walk_det(ctx, dg, m, u0, u1, &ps, &c);
+    }
     if (rc != TLM_OK) {
         std::cerr << "telomeri_hip: walk failed: " << tlm_last_error() << std::endl;
         std::exit(1);
@@ -154,7 +176,8 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
     }
     tlm_walk_params wp{params_.rebuild_attempts, params_.backtrack_attempts, params_.len_threshold};
     uint64_t mc0 = 0, mc1 = tlm_mc_units(dg, &wp), d0 = 0, d1 = tlm_det_units(dg);
-    if (tlm_dist_world(ctx) > 1) {
+    const bool sliced = tlm_dist_world(ctx) > 1 && partition_is_sliced();
+    if (tlm_dist_world(ctx) > 1 && !sliced) {
         uint32_t a0 = 0, a1 = 0;
         if (tlm_dist_anchor_range(dg, tlm_dist_rank(ctx), tlm_dist_world(ctx), &a0, &a1) != TLM_OK) die_tlm("anchor range");
         tlm_graph_info gi;
@@ -169,7 +192,11 @@ void PathManager::buildAll(const OverlapGraph &g, const Utils::Metrics &ma, cons
     tlm_pathset *sets[4] = {nullptr, nullptr, nullptr, nullptr};
     tlm_counters c[4];
     const auto t_call = std::chrono::steady_clock::now();
-    if (tlm_walk_builders(ctx, dg, (int) ma, (int) mb, &wp, mc0, mc1, d0, d1, sets, c) != TLM_OK) die_tlm("walk");
+    if (sliced) {
+        const std::vector<uint64_t> mcu = unit_share(ctx, dg, wp, false), detu = unit_share(ctx, dg, wp, true);
+        if (tlm_walk_builders_list(ctx, dg, (int) ma, (int) mb, &wp, mcu.size(), mcu.data(), detu.size(), detu.data(), sets, c) != TLM_OK)
+            die_tlm("walk");
+    } else if (tlm_walk_builders(ctx, dg, (int) ma, (int) mb, &wp, mc0, mc1, d0, d1, sets, c) != TLM_OK) die_tlm("walk");
     const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     graph_ = &g;
     last_counters = Counters{0, 0, 0, 0, 0, 0.0};

@@ -2,7 +2,7 @@
 
     python tests/exchange_worker.py <dataset> <rank> <world> <id file> <out dir>
 
-Every rank builds the same graph on cuda:0, walks the anchor bundle tlm_dist_anchor_range gives it, then runs the
+Every rank builds the same graph on cuda:0, walks its share of the units (sliced or contiguous partition), then runs the
 product's exchange -- tlm_pathset_allgather, tlm_pathset_gather_summaries + tlm_gathered_fetch -- through the library's own
 communicator, with tests/fake_rccl underneath (TLM_RCCL_LIB, set by the parent).  What it received goes into
 <out dir>/rank<r>.npz; a failure is written to rank<r>.err (code + message) and the exit status is 3.
@@ -60,8 +60,12 @@ def make_graph(ctx, dataset: str):
 
 
 def rank_sets(dg, wp, rank: int, world: int):
-    """The four builder sets of one rank's anchor bundle (the unit ranges PathManager::build uses)."""
+    """The four builder sets of one rank's share: its slices of every anchor's units (tlm_dist_unit_share, the hosts'
+    default) or, with TLM_TEST_PARTITION=contiguous, its bundle of whole anchors (the unit ranges of round 3)."""
     from telomeri_amd import capi
+    if os.environ.get("TLM_TEST_PARTITION", "sliced") == "sliced":
+        return list(dg.walk_builders_list(capi.METRIC_ES, capi.METRIC_OS, wp, dg.unit_share(rank, world, wp, False),
+                                          dg.unit_share(rank, world, wp, True)))
     a0, a1 = dg.anchor_range(rank, world)
     _, det_off = dg.anchor_table()
     rb = wp.rebuild_attempts

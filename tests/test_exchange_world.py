@@ -63,8 +63,9 @@ def one_process(ctx, dataset):
     return dg, wp, sets, want
 
 
+@pytest.mark.parametrize("partition", ["sliced", "contiguous"])
 @pytest.mark.parametrize("dataset,world", [("toy", 2), ("quirks", 2), ("toy", 4), ("quirks", 3), ("hub", 2)])
-def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world):
+def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world, partition):
     dg, wp, sets, want = one_process(ctx, dataset)
     h = want.to_host()
     front, back, count, hsh = want.summary()
@@ -72,7 +73,7 @@ def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world):
     n = len(h)
     assert n > 0
     with tempfile.TemporaryDirectory() as tmp:
-        outs = run_ranks(fake_rccl, dataset, world, tmp)
+        outs = run_ranks(fake_rccl, dataset, world, tmp, {"TLM_TEST_PARTITION": partition})
         for r, (rc, out) in enumerate(outs):
             err = os.path.join(tmp, "rank%d.err" % r)
             assert rc == 0, "rank %d: %s\n%s" % (r, open(err).read() if os.path.exists(err) else "", out[-2000:])
@@ -82,8 +83,21 @@ def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world):
     builder = (h.unit >> np.uint64(56)).astype(np.int64)
     unit = (h.unit & np.uint64((1 << 56) - 1)).astype(np.int64)
     anchor = np.where(builder < 2, unit // wp.rebuild_attempts, np.searchsorted(det_off.astype(np.int64), unit, side="right") - 1)
-    ranges = [dg.anchor_range(r, world) for r in range(world)]
-    owner = np.array([next(r for r, (a0, a1) in enumerate(ranges) if a0 <= a < a1) for a in anchor], np.uint32)
+    if partition == "contiguous":
+        ranges = [dg.anchor_range(r, world) for r in range(world)]
+        owner = np.array([next(r for r, (a0, a1) in enumerate(ranges) if a0 <= a < a1) for a in anchor], np.uint32)
+    else:       # sliced: the rank whose share holds the unit (tlm_dist_unit_share)
+        owner = np.full(n, 0xFFFFFFFF, np.uint32)
+        for r in range(world):
+            for det in (False, True):
+                mine = np.isin(unit, dg.unit_share(r, world, wp, det).astype(np.int64)) & ((builder >= 2) == det)
+                assert np.all(owner[mine] == 0xFFFFFFFF)
+                owner[mine] = r
+        assert np.all(owner != 0xFFFFFFFF)
+        # the shares are disjoint and cover every unit
+        for det, total in ((False, dg.mc_units(wp)), (True, dg.det_units())):
+            allu = np.concatenate([dg.unit_share(r, world, wp, det) for r in range(world)])
+            assert allu.shape[0] == total and np.unique(allu).shape[0] == total
     seqs = [h.nodes[off[i]:off[i + 1]].tobytes() for i in range(n)]
     first = np.r_[True, (builder[1:] != builder[:-1]) | (owner[1:] != owner[:-1])]
     dup = np.array([(not first[i]) and seqs[i] == seqs[i - 1] for i in range(n)])
@@ -117,12 +131,14 @@ def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world):
     assert all(int(e["full_info"][2]) == (32 if wide else 16) for e in res)
     if dataset == "hub":
         assert wide, "the hub graph is there to force 32-bit slots"
-        # only the first rank's paths hold such a slot: the others learn it from the sizes exchange
-        assert not ((h.slots != 0xFFFFFFFF) & (h.slots >= 0xFFFF))[np.repeat(owner != 0, count)].any()
+        if partition == "contiguous":       # only the first rank's paths hold such a slot: the others learn it from the sizes exchange
+            assert not ((h.slots != 0xFFFFFFFF) & (h.slots >= 0xFFFF))[np.repeat(owner != 0, count)].any()
     if dataset == "quirks":
         assert dup.any(), "quirks is there for its runs of identical paths"
-    if (dataset, world) == ("toy", 4):
+    if (dataset, world, partition) == ("toy", 4, "contiguous"):
         assert any(e["local_paths"].sum() == 0 for e in res), "4 ranks over 3 anchors: one rank has nothing to send"
+    if partition == "sliced" and world > 1:
+        assert int(first.sum()) > 4 * world or n < 8 * world, "sliced shares interleave: many blocks"
 
 
 @pytest.mark.parametrize("point", ["prep", "alloc", "group", "fetch"])
@@ -223,3 +239,47 @@ def test_host_program_ranks_end_together(fake_rccl):
         rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
         assert "injected failure" in rank1
         assert "rank 0 failed" in res.stderr or "a rank ended with status" in res.stderr
+
+
+# ---- bench.py as a two-rank job on one GPU (gloo for the harness's own small collectives, the library's exchange through
+# ---- the stand-in): the N > 1 line is a measured line, and a rank that loses its communicator ends the job -----------------
+def _bench(fake, extra_env, timeout=420, extra_args=()):
+    import json
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "toy", "--gpus", "2", "--share-gpu", "--dist-backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--rb-att", "40", "--no-scaffold", "--cpu-seconds", "1"] + list(extra_args)
+    env = dict(os.environ, TLM_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_S="60", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None), time.time() - t0
+
+
+@pytest.mark.parametrize("partition", ["sliced", "contiguous"])
+def test_bench_two_ranks_line_is_a_measured_line(fake_rccl, partition):
+    res, line, _ = _bench(fake_rccl, {}, extra_args=["--partition", partition])
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert partition in line["config"]["partition"]
+    assert "tlm_pathset_gather_summaries" in line["exchange"]["transport"]
+    # rank 0 carries the CPU baseline at N > 1 too (the same bounded sample), with the reference / port ratio beside it
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["sample_matches_device"] is True
+    assert 0.3 < cb["reference_over_port_1thread"] < 0.7
+    # the dominant kernel of EVERY rank: min / max over the ranks
+    rk = line["roofline"]["ranks"]
+    assert 0 < rk["avg_launch_ms_min"] <= line["roofline"]["avg_launch_ms"] <= rk["avg_launch_ms_max"]
+    assert 0 < rk["frac_min"] <= rk["frac_max"]
+    if partition == "sliced":       # every rank walks half of every anchor's trials: equal unit counts, near-equal work
+        assert rk["mc_evals_max"] / rk["mc_evals_min"] < 1.6
+
+
+def test_bench_rank_that_loses_its_communicator_ends_the_job(fake_rccl):
+    """a failure in the middle of the grouped transfers aborts the communicator; the failing rank must LEAVE (the
+    launcher ends the others) instead of waiting for its peers in the harness's gather until a collective timeout."""
+    res, line, seconds = _bench(fake_rccl, {"TLM_EXCHANGE_FAULT": "1:group", "TLM_EXCHANGE": "full"}, timeout=300)
+    assert res.returncode != 0, res.stdout[-500:]
+    assert line is None
+    assert seconds < 150, "the job took %.0f s to end" % seconds
+    assert "the communicator is gone" in res.stderr or "ended with status" in res.stderr

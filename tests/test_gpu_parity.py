@@ -206,6 +206,58 @@ def test_walks_quirks_all_metrics(ctx, metric):
     assert ps.n_paths + pd.n_paths > 0
 
 
+@pytest.mark.parametrize("name,rb", [("toy", 30), ("quirks", 24), ("hard_tiny", 40)])
+def test_unit_lists_equal_unit_ranges(ctx, name, rb):
+    """(ABI 4) tlm_walk_list / tlm_walk_builders_list: a LIST of units returns, unit for unit, what the range calls return
+    for those units -- random sublists, and the sliced shares of 3 ranks put together again (tlm_dist_unit_share)."""
+    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    dg = H.device_graph(ctx, ds, capi.FilterParams.default("min" if name == "quirks" else "avg"))
+    wp = capi.WalkParams.default(rb_att=rb, bt_att=6)
+    whole = dg.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp)
+    whole_h = [ps.to_host() for ps in whole]
+    whole_st = [ps.unit_stats() for ps in whole]
+    rng = np.random.default_rng(7)
+
+    def check(sets, mc_units, det_units):
+        for k, ps in enumerate(sets):
+            units = (mc_units if k < 2 else det_units).astype(np.int64)
+            np.testing.assert_array_equal(ps.unit_stats(), whole_st[k][units])
+            h, w = ps.to_host(), whole_h[k]
+            sel = np.isin(w.unit.astype(np.int64), units)
+            np.testing.assert_array_equal(h.unit, w.unit[sel])
+            np.testing.assert_array_equal(h.length, w.length[sel])
+            cnt = np.diff(w.off.astype(np.int64))
+            np.testing.assert_array_equal(h.nodes, w.nodes[np.repeat(sel, cnt)])
+            np.testing.assert_array_equal(h.slots, w.slots[np.repeat(sel, cnt)])
+            assert ps.counters.evals == int(whole_st[k]["evals"][units].sum())
+
+    n_mc, n_det = dg.mc_units(wp), dg.det_units()
+    mc_units = np.sort(rng.choice(n_mc, size=n_mc // 3, replace=False)).astype(np.uint64)
+    det_units = np.sort(rng.choice(n_det, size=max(1, n_det // 2), replace=False)).astype(np.uint64)
+    check(dg.walk_builders_list(capi.METRIC_ES, capi.METRIC_OS, wp, mc_units, det_units), mc_units, det_units)
+    one = dg.walk_list(False, capi.METRIC_OS, -1, wp, mc_units)          # single builder, single metric
+    np.testing.assert_array_equal(one.unit_stats(), whole_st[1][mc_units.astype(np.int64)])
+    two = dg.walk_list(True, capi.METRIC_ES, capi.METRIC_OS, wp, det_units)
+    np.testing.assert_array_equal(two[1].unit_stats(), whole_st[3][det_units.astype(np.int64)])
+    # the sliced partition: three ranks' shares are disjoint, cover everything, and each walks exactly its units
+    world = 3
+    shares = [(dg.unit_share(r, world, wp, False), dg.unit_share(r, world, wp, True)) for r in range(world)]
+    for det, total in ((0, n_mc), (1, n_det)):
+        allu = np.concatenate([sh[det] for sh in shares])
+        assert allu.shape[0] == total and np.unique(allu).shape[0] == total
+    for mcu, detu in shares:
+        assert np.all(np.diff(mcu.astype(np.int64)) > 0) and np.all(np.diff(detu.astype(np.int64)) > 0)
+        assert abs(mcu.shape[0] - n_mc / world) <= dg.info().n_anchors          # a slice of EVERY anchor's trials
+        check(dg.walk_builders_list(capi.METRIC_ES, capi.METRIC_OS, wp, mcu, detu), mcu, detu)
+    # refused: a list that is not ascending, a unit that does not exist
+    with pytest.raises(capi.TlmError):
+        dg.walk_list(False, capi.METRIC_ES, -1, wp, np.array([5, 5], np.uint64))
+    with pytest.raises(capi.TlmError):
+        dg.walk_list(True, capi.METRIC_ES, -1, wp, np.array([n_det], np.uint64))
+    empty = dg.walk_builders_list(capi.METRIC_ES, capi.METRIC_OS, wp, np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+    assert [ps.n_paths for ps in empty] == [0, 0, 0, 0]
+
+
 def test_walk_unit_ranges_concatenate(ctx):
     """Sharding contract: any partition of the units yields the same paths."""
     ds = synth.make_config("tiny")
