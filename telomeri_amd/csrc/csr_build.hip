@@ -219,8 +219,23 @@ __global__ __launch_bounds__(256) void row_ptr_kernel(uint64_t n_adj, uint32_t n
 struct KeptFields {
     uint4 a;    // qn, tn, q_start, q_end          (node indices of query and target)
     uint4 b;    // t_start, t_end, ES bits, OS bits
-    uint4 c;    // SI bits, strand | anchor(qn) << 1 | anchor(tn) << 2, -, -
+    uint4 c;    // SI bits, strand | anchor(qn) << 1 | anchor(tn) << 2 | proper overlap << 3 (see proper_sides), -, -
 };
+
+// Is an overlap a PROPER one -- a dovetail or a containment: on each side at least one of the two sequences ends (within
+// 1000 bp, and the overhangs are at most a fifth of the aligned span; the classification assemblers use) -- or an INTERNAL
+// match, where both sequences run on past the overlap on the same side (two reads sharing a repeat copy; a chimeric read
+// against the reads of one of its loci)?  Used by the walk-order numbering only (graph_finish).
+__host__ __device__ inline bool proper_sides(int64_t q5, int64_t q3, int64_t t5, int64_t t3, int64_t span) {
+    const int64_t e5 = q5 < t5 ? q5 : t5, e3 = q3 < t3 ? q3 : t3;      // what BOTH sequences have beyond the overlap
+    return e5 <= 1000 && e3 <= 1000 && 5 * span >= 4 * (span + e5 + e3);
+}
+__host__ __device__ inline bool proper_overlap(int64_t qs, int64_t qe, int64_t ql, int64_t ts, int64_t te, int64_t tl, bool minus) {
+    const int64_t span = (qe - qs) < (te - ts) ? (qe - qs) : (te - ts);
+    if (proper_sides(qs, ql - qe, ts, tl - te, span)) return true;
+    // a '-' record names the query's coordinates on its own strand: its left end meets the target's right side
+    return minus && proper_sides(ql - qe, qs, ts, tl - te, span);
+}
 
 __global__ __launch_bounds__(256) void kept_fields_kernel(FileTable ft, uint64_t n_kept,
                                                           const uint32_t *__restrict__ kept_rec,
@@ -238,7 +253,8 @@ __global__ __launch_bounds__(256) void kept_fields_kernel(FileTable ft, uint64_t
         o.a = make_uint4(qn, tn, (uint32_t) f.q_start[r], (uint32_t) f.q_end[r]);
         o.b = make_uint4((uint32_t) f.t_start[r], (uint32_t) f.t_end[r], __float_as_uint(r_es[g]), __float_as_uint(r_os[g]));
         const uint32_t st = f.strand ? (f.strand[r] != 0 ? 1u : 0u) : 0u;
-        o.c = make_uint4(__float_as_uint(r_si[g]), st | ((uint32_t) node_anchor[qn] << 1) | ((uint32_t) node_anchor[tn] << 2), 0u, 0u);
+        const uint32_t proper = proper_overlap(f.q_start[r], f.q_end[r], f.q_len[r], f.t_start[r], f.t_end[r], f.t_len[r], st != 0) ? 8u : 0u;
+        o.c = make_uint4(__float_as_uint(r_si[g]), st | ((uint32_t) node_anchor[qn] << 1) | ((uint32_t) node_anchor[tn] << 2) | proper, 0u, 0u);
         out[k] = o;
     }
 }
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(256) void gather_kernel(uint64_t n_adj, const uint3
                                                      uint2 *__restrict__ ent_os, uint32_t *__restrict__ q_start,
                                                      uint32_t *__restrict__ q_end, uint32_t *__restrict__ t_start,
                                                      uint32_t *__restrict__ t_end, float *__restrict__ si,
-                                                     uint8_t *__restrict__ strand) {
+                                                     uint8_t *__restrict__ strand, uint8_t *__restrict__ proper) {
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
     for (uint64_t d = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; d < n_adj; d += stride) {
         const uint32_t e = sorted_e[d];
@@ -267,6 +283,7 @@ __global__ __launch_bounds__(256) void gather_kernel(uint64_t n_adj, const uint3
         t_end[d] = swapped ? qe : te;
         si[d] = __uint_as_float(f.c.x);
         strand[d] = (uint8_t) (f.c.y & 1u);
+        proper[d] = (uint8_t) ((f.c.y >> 3) & 1u);      // (both entries of an overlap: the classification is symmetric)
     }
 }
 
@@ -355,6 +372,48 @@ __global__ void det_count_kernel(uint32_t n_anchors, const uint32_t *__restrict_
 // the whole N-bit set; numbering the nodes by (nearest anchor, BFS level from it, reference index) puts the
 // neighbours of a node into a window of a few hundred ids, so a wave's 64 probes fall into one or two cache
 // lines.  The renumbering is internal to the walk layout: every result is reported in reference indices.
+// Which entries the numbering follows (round 4).  Real overlap sets (minimap2 on real reads, reference run.sh:38-45) hold
+// what the analytic friendly sets do not: INTERNAL matches (proper_sides above), which join loci that are megabases apart;
+// a BFS that follows them reaches the whole graph in half a dozen levels and the numbering loses every locality (hostile
+// config: 99 % of the Monte-Carlo steps probed outside the LDS band, a band move every 3.7 steps, 87 % of the steps on
+// 8-byte rows).  So the BFS follows PROPER overlaps only (proper[e], one byte per entry, written by gather_kernel from the
+// record it copies anyway), and a node most of whose list is internal matches (a read inside a repeat family, a chimeric
+// read) is not expanded while anything else is left to expand.  A numbering heuristic only: every entry is walked as
+// before, results do not depend on it.
+
+// proper[] of a graph adopted as CSR (tlm_graph_from_csr with the cold columns): from the entry arrays
+__global__ __launch_bounds__(256) void proper_flags_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                                           const uint2 *__restrict__ ents, const uint32_t *__restrict__ q_start,
+                                                           const uint32_t *__restrict__ q_end, const uint32_t *__restrict__ t_start,
+                                                           const uint32_t *__restrict__ t_end, const uint8_t *__restrict__ strand,
+                                                           const uint32_t *__restrict__ node_len, uint8_t *__restrict__ proper) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t n = wave; n < n_nodes; n += n_waves) {        // in the owner's list t_index == owner (OverlapGraph.cpp:243-248)
+        const uint32_t r0 = row_ptr[n], r1 = row_ptr[n + 1];
+        for (uint32_t e = r0 + lane; e < r1; e += 64)
+            proper[e] = proper_overlap(q_start[e], q_end[e], node_len[ents[e].x & 0x7FFFFFFFu], t_start[e], t_end[e], node_len[n],
+                                       strand && strand[e]) ? 1 : 0;
+    }
+}
+
+// suspect[n] = 1: more than a quarter of n's list are internal matches (never an anchor: the BFS starts there)
+__global__ __launch_bounds__(256) void suspect_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
+                                                      const uint8_t *__restrict__ proper,
+                                                      const uint8_t *__restrict__ node_anchor, uint8_t *__restrict__ suspect) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t n = wave; n < n_nodes; n += n_waves) {
+        const uint32_t r0 = row_ptr[n], deg = row_ptr[n + 1] - r0;
+        uint32_t internal = 0;
+        for (uint32_t j = lane; j < deg; j += 64) internal += proper[r0 + j] ? 0u : 1u;
+        for (int d = 32; d > 0; d >>= 1) internal += __shfl_xor(internal, d);
+        if (lane == 0) suspect[n] = (!node_anchor[n] && 4u * internal > deg) ? 1 : 0;
+    }
+}
+
 __global__ void bfs_init_kernel(uint32_t n_anchors, const uint32_t *__restrict__ anchors, unsigned long long *__restrict__ key,
                                 uint32_t *__restrict__ frontier) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,25 +424,50 @@ __global__ void bfs_init_kernel(uint32_t n_anchors, const uint32_t *__restrict__
 
 // One level.  The size of the frontier is read from device memory (counts[0]; the next level's goes to counts[1]): the
 // host queues a batch of levels without waiting for any of them (a level past the last one finds an empty frontier).
+// `proper` null (a graph adopted as CSR without the cold columns): every entry is followed, nothing is deferred.
 __global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t *__restrict__ counts, const uint32_t *__restrict__ frontier,
                                                          uint32_t level, const uint32_t *__restrict__ row_ptr,
-                                                         const uint2 *__restrict__ ents, unsigned long long *__restrict__ key,
-                                                         uint32_t *__restrict__ next) {
+                                                         const uint2 *__restrict__ ents, const uint8_t *__restrict__ proper,
+                                                         const uint8_t *__restrict__ suspect, unsigned long long *__restrict__ key,
+                                                         uint32_t *__restrict__ next, uint32_t *__restrict__ deferred,
+                                                         uint32_t *__restrict__ n_deferred) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_f = counts[0];
     uint32_t *n_next = counts + 1;
+    const bool classify = proper != nullptr;
     for (uint32_t f = wave; f < n_f; f += n_waves) {
         const uint32_t u = frontier[f];
         const unsigned long long nk = ((unsigned long long) (level + 1) << 32) | (key[u] & 0xFFFFFFFFull);
         for (uint32_t e = row_ptr[u] + lane; e < row_ptr[u + 1]; e += 64) {
+            if (classify && !proper[e]) continue;
             const uint32_t v = ents[e].x & 0x7FFFFFFFu;
             // the minimum over all discoverers of v in this level is deterministic; exactly one of them sees "unseen"
             const unsigned long long old = atomicMin(&key[v], nk);
-            if (old == ~0ull) next[atomicAdd(n_next, 1u)] = v;
+            if (old == ~0ull) {
+                if (classify && suspect[v]) deferred[atomicAdd(n_deferred, 1u)] = v;      // expanded only when nothing else is left
+                else next[atomicAdd(n_next, 1u)] = v;
+            }
         }
     }
+}
+
+// Between two levels: an empty next frontier with deferred nodes waiting -> they are the next frontier.
+// (two launches: the decision by one thread, the copy by a grid)
+__global__ void bfs_stall_decide_kernel(uint32_t *__restrict__ next_count, uint32_t *__restrict__ n_deferred, uint32_t *__restrict__ moved) {
+    const uint32_t nd = *n_deferred;
+    if (*next_count == 0u && nd != 0u) {
+        *moved = nd;
+        *next_count = nd;
+        *n_deferred = 0u;
+    } else {
+        *moved = 0u;
+    }
+}
+__global__ void bfs_stall_copy_kernel(const uint32_t *__restrict__ moved, const uint32_t *__restrict__ deferred, uint32_t *__restrict__ next) {
+    const uint32_t n = *moved;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) next[i] = deferred[i];
 }
 
 __global__ void bfs_sortkey_kernel(uint32_t n_nodes, const unsigned long long *__restrict__ key,
@@ -655,7 +739,27 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
     ph.mark(PH_OTHER);
     if (localize) {
         constexpr uint32_t BATCH = 16;      // levels queued per host round trip
-        DevBuf key, f0, f1, cnt, sortkey, sortkey_out, ids;
+        DevBuf key, f0, f1, cnt, sortkey, sortkey_out, ids, suspect, deferred, stall;
+        // the numbering follows proper overlaps and defers nodes whose lists are mostly internal matches (see proper_entry)
+        const bool classify = g->q_end && g->t_end && !std::getenv("TLM_ORDER_ALL_EDGES");
+        DevBuf proper_made;
+        const uint8_t *proper = nullptr;
+        if (classify && g->proper_tmp) {
+            proper = g->proper_tmp;         // written by gather_kernel
+        } else if (classify) {
+            if (int rc = dev_alloc(proper_made, (size_t) g->n_adj + 1)) return rc;
+            hipLaunchKernelGGL(proper_flags_kernel, dim3(grid_for(std::min<uint64_t>((uint64_t) N * 64, 1u << 20))), dim3(256), 0, s, N,
+                               g->row_ptr, g->ent_es, g->q_start, g->q_end, g->t_start, g->t_end, g->strand, g->node_len,
+                               proper_made.as<uint8_t>());
+            proper = proper_made.as<uint8_t>();
+        }
+        if (int rc = dev_alloc(suspect, (size_t) N)) return rc;
+        if (int rc = dev_alloc(deferred, (size_t) N * 4)) return rc;
+        if (int rc = dev_alloc(stall, 16)) return rc;
+        TLM_HIP(hipMemsetAsync(stall.p, 0, 16, s));
+        if (classify)
+            hipLaunchKernelGGL(suspect_kernel, dim3(grid_for(std::min<uint64_t>((uint64_t) N * 64, 1u << 20))), dim3(256), 0, s, N,
+                               g->row_ptr, proper, g->node_anchor, suspect.as<uint8_t>());
         if (int rc = dev_alloc(key, (size_t) N * 8)) return rc;
         if (int rc = dev_alloc(f0, (size_t) N * 4)) return rc;
         if (int rc = dev_alloc(f1, (size_t) N * 4)) return rc;
@@ -680,8 +784,15 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
             TLM_HIP(hipMemcpyAsync(cnt.p, h_cnt, cnt_bytes, hipMemcpyHostToDevice, s));     // {frontier size, 0, ..., 0}
             for (uint32_t j = 0; j < BATCH; j++) {
                 hipLaunchKernelGGL(bfs_expand_kernel, dim3(bfs_grid), dim3(256), 0, s, cnt.as<uint32_t>() + j,
-                                   fr[(level + j) & 1u], level + j, g->row_ptr, g->ent_es, key.as<unsigned long long>(),
-                                   fr[(level + j + 1) & 1u]);
+                                   fr[(level + j) & 1u], level + j, g->row_ptr, g->ent_es, proper, suspect.as<uint8_t>(),
+                                   key.as<unsigned long long>(), fr[(level + j + 1) & 1u], deferred.as<uint32_t>(),
+                                   stall.as<uint32_t>());
+                if (classify) {
+                    hipLaunchKernelGGL(bfs_stall_decide_kernel, dim3(1), dim3(1), 0, s, cnt.as<uint32_t>() + j + 1, stall.as<uint32_t>(),
+                                       stall.as<uint32_t>() + 1);
+                    hipLaunchKernelGGL(bfs_stall_copy_kernel, dim3(256), dim3(256), 0, s, stall.as<uint32_t>() + 1,
+                                       deferred.as<uint32_t>(), fr[(level + j + 1) & 1u]);
+                }
             }
             TLM_HIP(hipMemcpyAsync(h_got, cnt.p, cnt_bytes, hipMemcpyDeviceToHost, s));
             if (int rc = ph.sync()) return rc;
@@ -964,6 +1075,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     if (int rc = dev_alloc_keep(&g->si, A)) return rc;
     if (int rc = dev_alloc_keep(&g->strand, A)) return rc;
     TLM_HIP(hipMemsetAsync(g->row_ptr, 0, ((size_t) N + 1) * 4, s));
+    DevBuf proper;      // one byte per adjacency entry: proper overlap? (graph_finish numbers the nodes along those)
     if (A) {
         DevBuf owner, eidx, sorted_owner, sorted_e;
         if (int rc = dev_alloc(owner, A * 4)) return rc;
@@ -989,13 +1101,17 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
         hipLaunchKernelGGL(kept_fields_kernel, dim3(grid_for(K)), dim3(256), 0, s, ft, K, g->kept_rec,
                            node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(), r_os.as<float>(),
                            r_es.as<float>(), kf.as<KeptFields>());
+        if (int rc = dev_alloc(proper, (size_t) A + 1)) return rc;
         hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, sorted_e.as<uint32_t>(),
                            kf.as<KeptFields>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start, g->t_end, g->si,
-                           g->strand);
+                           g->strand, proper.as<uint8_t>());
+        g->proper_tmp = proper.as<uint8_t>();       // for the walk-order numbering of graph_finish only
         ph.mark(PH_GATHER);
     }
     // 6.
-    if (int rc = graph_finish(ctx, g, ph)) return rc;
+    const int rc_finish = graph_finish(ctx, g, ph);
+    g->proper_tmp = nullptr;
+    if (rc_finish) return rc_finish;
     TLM_HIP(hipEventRecord(ctx->ev1, s));
     TLM_HIP(hipEventSynchronize(ctx->ev1));
     float ms = 0;

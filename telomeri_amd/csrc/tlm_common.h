@@ -85,6 +85,7 @@ struct tlm_graph {
     uint32_t *q_start = nullptr, *t_start = nullptr, *q_end = nullptr, *t_end = nullptr;
     float *si = nullptr;
     uint8_t *strand = nullptr;
+    const uint8_t *proper_tmp = nullptr;   // during tlm_graph_build only: 1 = proper overlap (csr_build.hip, walk-order numbering)
     uint32_t *node_len = nullptr;
     uint8_t *node_anchor = nullptr;
     uint8_t *node_flags = nullptr;

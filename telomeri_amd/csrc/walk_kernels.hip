@@ -91,10 +91,16 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builti
 // are read from the kernarg segment where they are used, through a pointer the optimiser cannot see through: loads
 // from it cannot be hoisted above the walk loop, so they do not occupy scalar registers while a walk is stepping.
 // WalkArgs is the only kernel parameter (offset 0 of the segment).
+// ONLY FOR CODE THAT IS INLINED INTO THE KERNEL: in a function that stays a real call the intrinsic below yields a NULL
+// pointer (a callee is not handed the kernarg segment), and every "cold" argument is then read from address 0 -- round 3's
+// kernel that "died on a null address" when a check made mc_walk too large for the inliner, and round 4's first far filter
+// (profiles/experiments/r04_far_filter_bisect.md).  Every function that calls cold_args() is __forceinline__ (mc_walk,
+// det_walk, finish_unit, next_work, the kernels themselves), and tests/test_capi_library.py::test_cold_args_only_in_kernels
+// reads the ISA: no function other than the kernels may contain the marker of the asm statement below.
 typedef __attribute__((address_space(4))) const WalkArgs ColdArgs;
 __device__ __forceinline__ ColdArgs *cold_args() {
     uint64_t p = (uint64_t) __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
+    asm volatile("; cold_args" : "+s"(p));
     return (ColdArgs *) p;
 }
 
@@ -234,11 +240,12 @@ __device__ __forceinline__ double mt_canonical(Rng &g, int lane) {
 
 // ---------------------------------------------------------------------------------------------
 
-// (not checked in the checked build: this helper is inlined into every probe of every lane width, and a check here --
-// a conditional call in the innermost divergent code -- made hipcc 7.2 produce a kernel whose walks differed from run to run
-// although no check ever fired (bisected to this site, gpurun_out/r03 notes in DESIGN.md).  The ids that reach it are
-// neighbour ids of the graph, validated when a neighbour is CHOSEN (row_record) and by the graph tests.)
-__device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t n) { return (bm[n >> 5] >> (n & 31)) & 1u; }
+// (the ids that reach it are neighbour ids of the graph, validated when a neighbour is CHOSEN (row_record) and by the graph
+// tests; round 3 could not put an index check here -- see visited_test for what that was)
+__device__ __forceinline__ bool bm_test(const uint32_t *bm, uint32_t n) {
+    // (the map is GLOBAL memory and is read as such: see visited_test)
+    return (((__attribute__((address_space(1))) const uint32_t *) bm)[n >> 5] >> (n & 31)) & 1u;
+}
 
 // Visited set of a Monte-Carlo walk.  Node ids are walk-order indices (graph build: nearest anchor, BFS level), so
 // the nodes a walk meets lie in a band of ids around its start anchor.  The band [lo, lo + WIN_BITS) lives in LDS
@@ -259,9 +266,22 @@ __device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) {
     return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const uint32_t *) p;
 }
 
+// The slow-path probe of one id (a lane whose entry holds an anchor, an id outside the band, the serial and backtracking
+// scans).  Band (LDS) and map (global memory) are read THROUGH THEIR OWN ADDRESS SPACES.  Round 3's form read both through
+// generic pointers; the optimiser turned "band or map" into ONE flat load through a pointer picked from a two-entry table it
+// kept in scratch, and every attempt to put a third outcome into the far branch (round 3: an index check; round 4: a
+// filter in front of the map) came out of that transformation as a kernel whose walks differed from run to run -- although
+// the far branch was never reached (counted: 0 calls on the graph that showed it,
+// tests/test_gpu_parity.py::test_walks_across_lane_widths).  With typed address spaces there is no pointer to choose
+// between: a ds_read under one predicate, a global_load under another, no scratch table, 250 flat loads in the file
+// instead of 984 (profiles/experiments/r04_far_filter_bisect.md).
 __device__ __forceinline__ bool visited_test(const Visited &v, uint32_t n) {      // slow paths only
     const uint32_t d = n - v.lo;
-    return d < WIN_BITS ? ((v.win[d >> 5] >> (d & 31u)) & 1u) != 0 : bm_test(v.bm, n);
+    if (d < WIN_BITS) {
+        const uint32_t w = ((__attribute__((address_space(3))) const uint32_t *) (uintptr_t) lds_addr(v.win))[d >> 5];
+        return ((w >> (d & 31u)) & 1u) != 0;
+    }
+    return bm_test(v.bm, n);
 }
 
 __device__ __forceinline__ int64_t edge_delta(const uint2 *qt_tab, uint32_t e) {
@@ -315,7 +335,7 @@ struct WaveScratch {
 };
 
 // End of a walk: publish the unit's outcome, copy an accepted path into the arena, clear the bitmap.
-__device__ inline void finish_unit(const WaveScratch &ws, int lane, uint32_t ui, uint8_t status, uint32_t m,
+__device__ __forceinline__ void finish_unit(const WaveScratch &ws, int lane, uint32_t ui, uint8_t status, uint32_t m,
                                    uint32_t nlog, int64_t len_final, uint32_t steps, uint64_t evals, uint32_t draws) {
     ColdArgs *ca = cold_args();
     const uint32_t n_out = m + 1;
@@ -794,14 +814,14 @@ __device__ __forceinline__ Selection select_short_c(const HotArgs &a, const Visi
 }
 
 template <bool SQRT>
-__device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane, uint32_t row,
-                                   uint32_t deg, uint32_t start, uint32_t &draws, bool have_u, double u_given);
+__device__ __forceinline__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane, uint32_t row,
+                                                   uint32_t deg, uint32_t start, uint32_t &draws, bool have_u, double u_given);
 
 // Lists longer than 512 entries, chunks of 512.  Pass 1 (:53-67): total over the unvisited neighbours; the running
 // sum after each of the first AFTER_SLOTS chunks is parked in LDS: the prefix is non-decreasing, so pass 2
 // (:107-114) only has to look into the one chunk where it crosses `random`.
 template <bool SQRT>
-__device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, double *after,
+__device__ __forceinline__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, double *after,
                                               int lane, uint32_t row, uint32_t deg, uint32_t start, bool anchor_nbr,
                                               uint32_t &draws) {
     constexpr int K = 8;
@@ -898,7 +918,7 @@ __device__ Selection select_long(const HotArgs &a, const Visited &vs, Rng &rng, 
 // one candidate after the other in list order, as PathManager.cpp:64,109 makes them.  Rare; never on real overlaps.
 // `have_u`: the step's draw was already made by the caller (select_long, when u * total came out as 0).
 template <bool SQRT>
-__device__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
+__device__ __forceinline__ Selection select_serial(const HotArgs &a, const Visited &vs, Rng &rng, int lane,
                                                 uint32_t row, uint32_t deg, uint32_t start, uint32_t &draws, bool have_u,
                                                 double u_given) {
     Selection s{-1, 0u, 0u, 0u, 0u, deg};
@@ -1035,7 +1055,7 @@ __device__ __forceinline__ int step_class(uint32_t deg, bool compact, bool safe,
 // selections for longer lists and the serial one are not compiled in.  The kernel sits at the edge of its register budget
 // (64 vector / 78 scalar at 8 waves per SIMD): code that never runs still shapes the allocation of the code that does.
 template <bool SQRT, bool ACCOUNT, bool LITE>
-__device__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after,
+__device__ __forceinline__ void mc_walk(const HotArgs &a, const WaveScratch &ws, uint32_t *mt, uint32_t *win, double *after,
                         uint32_t *ring, int lane, uint32_t ui, uint32_t start, uint32_t seed, int64_t len0,
                         uint32_t *acct) {
     // `start` and every node id below are walk-order indices
@@ -1461,7 +1481,7 @@ __device__ __forceinline__ DetPick det_select_regs(const WalkArgs &a, const Visi
 
 // Longer lists: chunks of 256 entries, the first one kept in registers, the others re-read pass by pass (L1 / L2).
 template <bool SQRT>
-__device__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
+__device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
                                    uint32_t skip_n_best) {
     struct { const uint2 *ents; } a{ents_tab};
     bool go_back = false;
@@ -1573,7 +1593,7 @@ __device__ __forceinline__ void visited_clear(const Visited &vs, uint32_t n) {
 }
 
 template <bool SQRT, bool ACCOUNT, bool LITE>
-__device__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, uint32_t *ring, int lane, uint32_t ui,
+__device__ __forceinline__ void det_walk(const WalkArgs &a, const WaveScratch &ws, uint32_t *win, uint32_t *ring, int lane, uint32_t ui,
                          uint32_t start, uint32_t start_ref, uint32_t first_slot, uint32_t *acct) {
     Visited vs;
     vs.win = win;

@@ -114,6 +114,10 @@ def main() -> None:
         "tiny": (synth.make_config("tiny"), ["--rb-att", "60"]),
         "sparse": (synth.make_config("sparse"), ["--rb-att", "80", "--bt-att", "3"]),
         "quirks": (H.quirks_dataset(), ["--filter-min", "--rb-att", "50", "--bt-att", "5", "--sqrt"]),
+        # the hostile generator at a size the reference runs in a second (repeat families, chimeric reads, skewed contigs)
+        "hard_tiny": (synth.make_config("hard_tiny"), ["--rb-att", "40"]),
+        # 40 Mb paths: the int accumulator of PathGroup.cpp:66-68 overflows (f3's quirks that only bite at size)
+        "overflow": (H.overflow_dataset(), ["--len-thr", "100000000", "--rb-att", "200"]),
     }
     for name, (ds, args) in sets.items():
         rr, cr = os.path.join(tmp, name + "_rr.paf"), os.path.join(tmp, name + "_cr.paf")

@@ -101,6 +101,24 @@ def quirks_dataset(seed: int = 5) -> synth.Dataset:
     return dataclasses.replace(ds, rr=rr, cr=cr)
 
 
+def overflow_dataset(seed: int = 51) -> synth.Dataset:
+    """Contigs that CLAIM 40 Mb (the cr file's target-length column; the geometry stays small): every path is ~40 Mb long, and
+    the `int` accumulator of PathGroup::calculateConsensusPath (reference PathGroup.cpp:66-68, std::accumulate(..., 0, ...))
+    overflows after 54 paths.  Run with --len-thr 100000000."""
+    ds = synth.make_dataset("overflow", seed=seed, genome_len=220_000, n_contigs=3, contig_len=32_000, n_reads=300,
+                            read_len_lo=4_000, read_len_hi=12_000)
+    return dataclasses.replace(ds, cr=dataclasses.replace(ds.cr, t_len=ds.cr.t_len + 40_000_000))
+
+
+def dataset_by_name(name: str) -> synth.Dataset:
+    """The dataset behind a committed golden set (tests/golden/<name>.json) or a named config."""
+    if name == "quirks":
+        return quirks_dataset()
+    if name == "overflow":
+        return overflow_dataset()
+    return synth.make_config(name)
+
+
 def write_binary_dump(dirname: str, names, csr, paths) -> None:
     """The input of `telomeri_post --binary <dir>` (host/post_tool.cpp): the graph as raw CSR arrays and a packed Path set
     (paths_ AFTER filterUnique), for comparisons at sizes where the text dump would be tens of GB."""

@@ -8,6 +8,8 @@ import pytest
 
 from telomeri_amd import capi
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_library_exports_every_declared_symbol():
     L = capi.lib()
@@ -50,3 +52,36 @@ def test_product_sources_do_not_reference_the_oracle():
                     if "pyoracle" in txt or "telomeri_oracle" in txt or "import oracle" in txt or "from oracle" in txt:
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_cold_args_only_in_kernels():
+    """csrc/walk_kernels.hip reads its "cold" kernel arguments through __builtin_amdgcn_kernarg_segment_ptr() (cold_args()).
+    In a function that stays a REAL CALL that intrinsic yields a null pointer: the arguments would be read from address 0
+    (round 3's kernel that "died on a null address", round 4's first far filter).  So every user of cold_args() must have been
+    inlined into a kernel: the ISA of the shipped flags is read here -- the marker of cold_args()'s asm statement may occur in
+    kernel bodies only, and every non-kernel function is one of the known leaf helpers."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "telomeri_amd", "csrc", "walk_kernels.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "wk.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
+                        "--cuda-device-only", "-S", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    kernels = set(re.findall(r"\.amdhsa_kernel (\S+)", txt))
+    assert len(kernels) == 12, kernels          # {MC, DET} x {plain, sqrt} x {full, lite, accounting}
+    seen_kernels = 0
+    for body in re.split(r"\n(?=[_A-Za-z0-9\.]+:\s+; @)", txt):
+        m = re.match(r"([_A-Za-z0-9\.]+):\s+; @", body)
+        if not m:
+            continue
+        name, marks = m.group(1), body.count("; cold_args")
+        if name in kernels:
+            seen_kernels += 1
+            assert marks >= 3, name
+            continue
+        assert marks == 0, "%s is a real call and reads the kernarg segment (a null pointer there)" % name
+        assert any(k in name for k in ("mt_seed", "mt_twist", "band_slide", "select_long", "select_serial", "det_select_long")), name
+    assert seen_kernels == 12

@@ -182,7 +182,7 @@ def _dataset_dir(tmp, name):
     import helpers as H
     from telomeri_amd import synth
     meta = G.load_json(name + ".json")
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     d = os.path.join(tmp, name)
     os.makedirs(d)
     os.rename(G.gunzip_to(tmp, name + "_rr.paf.gz"), os.path.join(d, "rr_overlaps.paf"))

@@ -210,7 +210,7 @@ def test_walks_quirks_all_metrics(ctx, metric):
 def test_unit_lists_equal_unit_ranges(ctx, name, rb):
     """(ABI 4) tlm_walk_list / tlm_walk_builders_list: a LIST of units returns, unit for unit, what the range calls return
     for those units -- random sublists, and the sliced shares of 3 ranks put together again (tlm_dist_unit_share)."""
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     dg = H.device_graph(ctx, ds, capi.FilterParams.default("min" if name == "quirks" else "avg"))
     wp = capi.WalkParams.default(rb_att=rb, bt_att=6)
     whole = dg.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp)
@@ -336,7 +336,7 @@ def test_builders_call_equals_separate_calls(ctx, config, rb):
 def test_filter_unique_and_anchor_pairs_on_device(ctx, name, mode):
     """SURVEY.md §8f row 1 on the packed Path sets: concat (paths_ of one PathManager), filterUnique,
     getPathsBetweenAnchors -- against the oracle's restatement (pinned to the reference in test_oracle_golden.py)."""
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     fp = capi.FilterParams.default(mode)
     dg = H.device_graph(ctx, ds, fp)
     og = H.oracle_graph(ds, H.to_oracle_fp(fp))
@@ -498,7 +498,7 @@ def test_pathset_summary_and_fetch(ctx):
 @pytest.mark.parametrize("name", ["toy", "quirks"])
 def test_graph_edges_and_stats(ctx, name):
     """tlm_graph_edges / tlm_graph_get_stats (lean hosts) against the downloaded CSR."""
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     dg = H.device_graph(ctx, ds, capi.FilterParams.default("min" if name == "quirks" else "avg"))
     c = dg.download(cold=True)
     deg = np.diff(c.row_ptr.astype(np.int64))

@@ -30,7 +30,7 @@ def _flags(args):
     return [a for a in args if a != "--sqrt"]
 
 
-@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks", "hard_tiny", "overflow"])
 def test_cli_against_reference_dump(binary, name):
     meta = G.load_json(name + ".json")
     fp, wp = G.args_to_params(meta["args"])
@@ -99,7 +99,7 @@ def _write_dump(path, g, csr, paths):
             fh.write("p %d %d %s %s\n" % (length, len(nodes), " ".join(map(str, nodes)), " ".join(map(str, slots))))
 
 
-@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks", "hard_tiny", "overflow"])
 def test_cli_scaffold_end_to_end(binary, name):
     """PAF in -> scaffold FASTA out on the GPU host program; expected = the (reference-validated, see
     test_host_post_stages.py) host stages applied to the oracle's per-walk-seeded paths."""
@@ -107,7 +107,7 @@ def test_cli_scaffold_end_to_end(binary, name):
     import helpers as H
     meta = G.load_json(name + ".json")
     fp, wp = G.args_to_params(meta["args"])
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     post = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_post")
     with tempfile.TemporaryDirectory() as tmp:
         rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
@@ -180,7 +180,7 @@ def test_lean_host_equals_materialised_host(binary, name):
     from telomeri_amd import synth
     import helpers as H
     meta = G.load_json(name + ".json")
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     with tempfile.TemporaryDirectory() as tmp:
         rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
         reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
@@ -305,7 +305,7 @@ def test_cli_through_the_gathered_representation(binary, name, mode):
     from telomeri_amd import synth
     import helpers as H
     meta = G.load_json(name + ".json")
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     with tempfile.TemporaryDirectory() as tmp:
         rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
         reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")

@@ -28,18 +28,28 @@ def post():
 
 
 def _dataset(name):
-    return H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    return H.dataset_by_name(name)
 
 
-@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+def _grouping_flags(args):
+    """The flags of a set that the host stages (not the walks) read: telomeri_post takes them as the reference's main() does."""
+    out = []
+    for k, a in enumerate(args):
+        if a in ("--len-thr", "--w-size", "--r-thr"):
+            out += [a, args[k + 1]]
+    return out
+
+
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks", "hard_tiny", "overflow"])
 def test_scaffold_and_groups_against_golden(post, name):
     meta = G.load_json(name + ".json")
     ds = _dataset(name)
+    post = [post] + _grouping_flags(meta["args"])
     with tempfile.TemporaryDirectory() as tmp:
         dump = G.gunzip_to(tmp, name + ".dump.gz")
         reads, contigs, out = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "out.fa")
         synth.write_fasta(ds, reads, contigs)
-        res = subprocess.run([post, dump, reads, contigs, out], capture_output=True, text=True, timeout=120)
+        res = subprocess.run(post + [dump, reads, contigs, out], capture_output=True, text=True, timeout=120)
         want = meta["scaffold"]
         assert res.returncode == want["exit"], res.stderr
         body = open(out, "rb").read()
@@ -47,7 +57,7 @@ def test_scaffold_and_groups_against_golden(post, name):
         # the sequence files as telomeri_hip gets them from its helper process (scanned by one Scaffolder, read from its
         # index by another): the same scaffold
         out2 = os.path.join(tmp, "out2.fa")
-        res2 = subprocess.run([post, dump, reads, contigs, out2], capture_output=True, text=True, timeout=120,
+        res2 = subprocess.run(post + [dump, reads, contigs, out2], capture_output=True, text=True, timeout=120,
                               env=dict(os.environ, TLM_POST_VIA_INDEX="1"))
         assert res2.returncode == want["exit"], res2.stderr
         assert open(out2, "rb").read() == body
@@ -57,7 +67,7 @@ def test_scaffold_and_groups_against_golden(post, name):
         assert got_lines == want["consensus_lines"]
         for params, report in meta["groups"].items():
             g_out = os.path.join(tmp, "groups.txt")
-            subprocess.run([post, "--groups", g_out] + params.split() + [dump, "x", "y", "z"], check=True, capture_output=True)
+            subprocess.run([post[0], "--groups", g_out] + params.split() + [dump, "x", "y", "z"], check=True, capture_output=True)
             assert open(g_out).read() == report, params
 
 
@@ -98,6 +108,32 @@ def test_scaffold_against_live_reference(post, seed, args):
             subprocess.run([post, "--groups", mg, *gp, dump, "x", "y", "z"], check=True, capture_output=True)
             txt = open(gd).read()
             assert open(mg).read() == txt[txt.index("\nG ") + 1:]
+
+
+@live
+def test_int_accumulator_overflow_against_live_reference(post):
+    """PathGroup.cpp:66-68: std::accumulate(..., 0, ...) adds path lengths into an int.  With ~40 Mb paths it wraps after 54
+    of them; what the reference then picks as "the first path at least as long as the average" is whatever the wrapped
+    average says -- telomeri_post must pick the same (another seed than the golden set's)."""
+    ds = H.overflow_dataset(seed=52)
+    args = ["--len-thr", "100000000", "--rb-att", "120"]
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = os.path.join(tmp, "rr.paf"), os.path.join(tmp, "cr.paf")
+        reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
+        synth.write_paf(ds, ds.rr, rr)
+        synth.write_paf(ds, ds.cr, cr)
+        synth.write_fasta(ds, reads, contigs, seed=52)
+        ref_out, my_out, dump = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "mine.fa"), os.path.join(tmp, "d.dump")
+        ref = subprocess.run([po.REF_MAIN] + args + [rr, cr, reads, contigs, ref_out], capture_output=True, text=True)
+        subprocess.run([po.REF_DUMP] + args + [rr, cr, dump], check=True, stdout=subprocess.DEVNULL)
+        mine = subprocess.run([post, "--len-thr", "100000000", dump, reads, contigs, my_out], capture_output=True, text=True)
+        assert ref.returncode == 0 == mine.returncode, ref.stderr + mine.stderr
+        # the accumulator did overflow: more than 2^31 / 40 Mb paths between one pair of anchors
+        n_paths = int([ln for ln in ref.stdout.splitlines() if ln.startswith("- total_num:")][0].split()[-1])
+        assert n_paths * 40_000_000 > 2 ** 33
+        pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Consensus length", "Final consensus", "ctg", "read", "===="))]
+        assert pick(mine.stdout) == pick(ref.stdout) and len(pick(ref.stdout)) > 8
+        assert open(my_out, "rb").read() == open(ref_out, "rb").read()
 
 
 def test_scaffolder_fastq_and_single_node(post):

@@ -63,7 +63,7 @@ def test_load_missing_file_fails():
     assert not g.load_paf("/nonexistent/x.paf", False, po.FilterParams.default())
 
 
-@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks", "hard_tiny", "overflow"])
 def test_synthetic_sets_graph_and_paths(name):
     meta = G.load_json(name + ".json")
     fp, wp = G.args_to_params(meta["args"])

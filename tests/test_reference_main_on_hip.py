@@ -106,7 +106,7 @@ def _normalise(text):
 def _inputs(tmp, name):
     from telomeri_amd import synth
     import helpers as H
-    ds = H.quirks_dataset() if name == "quirks" else synth.make_config(name)
+    ds = H.dataset_by_name(name)
     rr, cr = G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
     reads, contigs = os.path.join(tmp, "reads.fa"), os.path.join(tmp, "contigs.fa")
     synth.write_fasta(ds, reads, contigs)
@@ -116,7 +116,7 @@ def _inputs(tmp, name):
 @pytest.mark.gpu
 @needs_binary
 @pytest.mark.parametrize("lean", [False, True])
-@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks", "hard_tiny", "overflow"])
 def test_report_and_scaffold_equal_the_reference_program(name, lean):
     want = G.load_json(name + ".json")["program_det_only"]
     with tempfile.TemporaryDirectory() as tmp:
@@ -156,7 +156,7 @@ HIP_ONLY = ("load breakdown:", "edge-extension evals:", "Anchor pairs with paths
 
 @pytest.mark.gpu
 @needs_binary
-@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks"])
+@pytest.mark.parametrize("name", ["tiny", "sparse", "quirks", "hard_tiny", "overflow"])
 def test_same_report_and_bytes_as_telomeri_hip(name):
     """Under the sets' own arguments (Monte-Carlo included, per-walk seeds): the reference's main() and telomeri_hip's are two
     callers of the same classes -- same report from "Loading overlaps..." on, same scaffold bytes."""
