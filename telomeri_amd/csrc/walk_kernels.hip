@@ -1479,9 +1479,11 @@ __device__ __forceinline__ DetPick det_select_regs(const WalkArgs &a, const Visi
     return r;
 }
 
-// Longer lists: chunks of 256 entries, the first one kept in registers, the others re-read pass by pass (L1 / L2).
+// Longer lists, the general form: chunks of 256 entries, the first one kept in registers, the others re-read pass by pass
+// (five passes over the list).  Since round 4 only the fallback of det_select_long below: lists with a negative metric, and
+// the case where the choice may be rank deg-1.
 template <bool SQRT>
-__device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
+__device__ __forceinline__ DetPick det_select_long_general(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
                                    uint32_t skip_n_best) {
     struct { const uint2 *ents; } a{ents_tab};
     bool go_back = false;
@@ -1577,6 +1579,114 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
         }
     }
     return DetPick{go_back, chosen, chosen_nbr, chosen_anchor, pushed};
+}
+
+// Longer lists (round 4): det_select_fast's reasoning, chunk by chunk.  On the hostile graphs 8 % of the deterministic steps
+// stand on lists of more than 768 entries -- hubs of up to 22 000 -- and carry 58 % of the evals; the general form above reads
+// such a list five times (HBM traffic of the launch: 2.0x the bytes its steps ask for, profiles/r04_hard_summary.json).
+// With every metric's sign bit clear the fp32 bit patterns order as operator> does, and the two exclusions of :299-308 are
+// checked after the choice, so:
+//   pass A (whole list, 512 entries a time, probes included): the largest unvisited key, the smallest and the largest
+//          metric of the list;
+//   pass B (up to the first hit): the first position of that key -- the choice (:299-315) -- and, after a go-back, of
+//          the list's maximum (rank 0: if that IS the choice, pass A again without it);
+//   pass C (up to the first hit, never past the choice): the first entry with the chosen neighbour (:340-347).
+// Everything else -- a negative metric anywhere, a choice that may be rank deg-1 -- goes to the general form.
+template <bool SQRT>
+__device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
+                                                   uint32_t skip_n_best) {
+    constexpr int K = 8;
+    constexpr uint32_t C = 64u * K;
+    auto ord_bits = [](uint32_t mb) { return SQRT ? __float_as_uint(sqrtf(__uint_as_float(mb))) : mb; };
+    // ---- pass A: lc = largest key among the unvisited entries (key = metric bits | bit 31), extrema of the metric
+    uint32_t excluded = 0xFFFFFFFFu;                    // position knocked out after a go-back (rank 0), if it was the choice
+    uint32_t oc = 0u, omin = ~0u, omax = 0u;
+    for (int round = 0; round < 2; round++) {
+        uint32_t lc = 0u, lmin = ~0u, lall = 0u, orr = 0u;
+        for (uint32_t base = 0; base < deg; base += C) {
+            uint32_t nb[K], mb[K], vis[K];
+            lane_load<K>(ents_tab, row, base, deg, lane, nb, mb);
+            lane_probe<K>(vs, nb, vis);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t pos = base + (uint32_t) K * (uint32_t) lane + (uint32_t) k;
+                const uint32_t ob = ord_bits(mb[k]);
+                if (pos < deg) {
+                    orr |= SQRT ? (ob | mb[k]) : ob;
+                    lmin = min(lmin, ob);
+                    lall = max(lall, ob);
+                    if (pos != excluded) lc = max(lc, (ob | 0x80000000u) & ~vis[k]);
+                }
+            }
+        }
+        if (__builtin_expect(__ballot((int) orr < 0) != 0, 0)) return det_select_long_general<SQRT>(ents_tab, vs, lane, row, deg, skip_n_best);
+        oc = wave_max_u32(lc);
+        if (round == 0) {
+            omin = wave_min_u32(lmin);
+            omax = wave_max_u32(lall);
+        }
+        if (oc == 0u) return DetPick{true, 0u, 0u, false, 0u};                      // :318: nothing unvisited
+        // ---- pass B: first position of the key (and of the list's maximum, when rank 0 is excluded)
+        uint32_t p = 0xFFFFFFFFu, e = 0u, best_i = 0xFFFFFFFFu;
+        const bool want_best = round == 0 && skip_n_best != 0u && (oc & 0x7FFFFFFFu) == omax;     // only then can the choice be rank 0
+        for (uint32_t base = 0; base < deg && (p == 0xFFFFFFFFu || (want_best && best_i == 0xFFFFFFFFu)); base += C) {
+            uint32_t nb[K], mb[K], vis[K];
+            lane_load<K>(ents_tab, row, base, deg, lane, nb, mb);
+            bool maybe = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) maybe |= ord_bits(mb[k]) == (oc & 0x7FFFFFFFu);
+            if (!__ballot(maybe)) continue;             // no entry of this chunk carries the metric: no probes needed
+            lane_probe<K>(vs, nb, vis);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t pos = base + (uint32_t) K * (uint32_t) lane + (uint32_t) k;
+                const uint32_t ob = ord_bits(mb[k]);
+                const bool valid = pos < deg;
+                if (p == 0xFFFFFFFFu || want_best) {
+                    const uint64_t hm = __ballot(valid && pos != excluded && ((ob | 0x80000000u) & ~vis[k]) == oc);
+                    if (hm) {
+                        const int fl = __ffsll((unsigned long long) hm) - 1;
+                        const uint32_t pk = base + (uint32_t) K * (uint32_t) fl + (uint32_t) k;
+                        if (pk < p) {
+                            p = pk;
+                            e = readlane_u32(nb[k], fl);
+                        }
+                    }
+                    if (want_best) {
+                        const uint64_t bm = __ballot(valid && ob == omax);
+                        if (bm) best_i = min(best_i, base + (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
+                    }
+                }
+            }
+        }
+        if (want_best && p == best_i) {                 // the choice is rank 0, skipped for the rest of the walk (:299): once more without it
+            excluded = best_i;
+            continue;
+        }
+        if (p >= deg) return DetPick{true, 0u, 0u, false, 0u};
+        if (__builtin_expect(!(omin < (oc & 0x7FFFFFFFu)), 0))                       // may be rank deg-1: the general form decides
+            return det_select_long_general<SQRT>(ents_tab, vs, lane, row, deg, skip_n_best);
+        // ---- pass C (:340-347): the first entry, in list order, that names the chosen neighbour (the anchor bit belongs to the
+        // neighbour: equal words <=> equal neighbours); it lies at or before the choice
+        uint32_t pushed = p;
+        for (uint32_t base = 0; base <= p; base += C) {
+            uint32_t nb[K], mb[K];
+            lane_load<K>(ents_tab, row, base, deg, lane, nb, mb);
+            uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t pos = base + (uint32_t) K * (uint32_t) lane + (uint32_t) k;
+                const uint64_t hm = __ballot(pos < deg && nb[k] == e);
+                if (hm) best = min(best, base + (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
+            }
+            if (best != 0xFFFFFFFFu) {
+                pushed = best;
+                break;
+            }
+        }
+        return DetPick{false, p, e & 0x7FFFFFFFu, (e >> 31) != 0, pushed};
+    }
+    return DetPick{true, 0u, 0u, false, 0u};            // (not reached: the second round either chooses or goes back)
 }
 
 // set / clear a visited flag (lane 0 only)
