@@ -108,6 +108,7 @@ struct CtxImpl : tlm_ctx {
     // "every workgroup of the Monte-Carlo launch has started": a host-mapped word the kernel sets (tlm_walk_builders)
     uint32_t *resident_host = nullptr, *resident_dev = nullptr;
     std::atomic<int> gate_released{0};
+    bool force_full_kernel = false;     // TLM_WALK_FULL_KERNEL, read once when the context is made (tests, diagnostics)
 };
 
 extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
@@ -118,11 +119,12 @@ extern "C" int tlm_ctx_create(int device, tlm_ctx **out) {
     TLM_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     TLM_HIP(hipGetDeviceProperties(&prop, device));
-    TLM_CHECK(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 || getenv("TLM_ALLOW_ANY_ARCH"), TLM_EHIP,
+    TLM_CHECK(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0, TLM_EHIP,
               "tlm_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     CtxImpl *c = new CtxImpl();
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
+    c->force_full_kernel = getenv("TLM_WALK_FULL_KERNEL") != nullptr;
     int prio_lo = 0, prio_hi = 0;
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // numerically lower = higher priority
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
@@ -595,9 +597,10 @@ int run_walks(tlm_ctx *ctx, const tlm_graph *g, bool is_mc, int n_slots, const i
         // the kernels without the selections for long lists (and, Monte-Carlo, for order-unsafe rows) where the graph has
         // neither: the same walks; the smaller kernels leave the register allocator more room on the paths that run (the
         // deterministic one then fits 8 waves per SIMD instead of 6)
-        bool lite = g->info.max_degree <= 512u && !getenv("TLM_WALK_FULL_KERNEL") && !ctx->walk_accounting;
+        bool lite = g->info.max_degree <= 512u && !c->force_full_kernel && !ctx->walk_accounting;
         for (int k = 0; is_mc && k < n_slots; k++) lite = lite && g->info.unsafe_nodes[metrics[k]] == 0u;
-        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq, lite), 32 / WALK_WAVES_PER_BLOCK);
+        // (the instantiation that is LAUNCHED: the accounting builds hold more LDS and registers than the product's)
+        int bpc = std::min(tlm_walk_blocks_per_cu(is_mc, sq, lite, ctx->walk_accounting != 0), 32 / WALK_WAVES_PER_BLOCK);
         if (ctx->waves_per_cu) bpc = std::max(1, std::min(bpc, ctx->waves_per_cu / WALK_WAVES_PER_BLOCK));
         uint32_t waves = (uint32_t) ctx->n_cus * (uint32_t) bpc * WALK_WAVES_PER_BLOCK;
         constexpr uint32_t WPB = WALK_WAVES_PER_BLOCK;

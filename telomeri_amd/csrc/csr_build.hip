@@ -265,8 +265,10 @@ __global__ __launch_bounds__(256) void gather_kernel(uint64_t n_adj, const uint3
                                                      uint2 *__restrict__ ent_os, uint32_t *__restrict__ q_start,
                                                      uint32_t *__restrict__ q_end, uint32_t *__restrict__ t_start,
                                                      uint32_t *__restrict__ t_end, float *__restrict__ si,
-                                                     uint8_t *__restrict__ strand, uint8_t *__restrict__ proper) {
+                                                     uint8_t *__restrict__ strand, uint8_t *__restrict__ proper,
+                                                     uint32_t *__restrict__ n_internal) {
     const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    uint32_t internal = 0;
     for (uint64_t d = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; d < n_adj; d += stride) {
         const uint32_t e = sorted_e[d];
         const bool swapped = (e & 1u) != 0;
@@ -284,7 +286,11 @@ __global__ __launch_bounds__(256) void gather_kernel(uint64_t n_adj, const uint3
         si[d] = __uint_as_float(f.c.x);
         strand[d] = (uint8_t) (f.c.y & 1u);
         proper[d] = (uint8_t) ((f.c.y >> 3) & 1u);      // (both entries of an overlap: the classification is symmetric)
+        internal += ((f.c.y >> 3) & 1u) ^ 1u;
     }
+    // how many entries are internal matches (saturating): a graph without any is numbered along all its entries, as before
+    for (int d = 32; d > 0; d >>= 1) internal += __shfl_xor(internal, d);
+    if ((threadIdx.x & 63) == 0 && internal) atomicOr(n_internal, 1u);
 }
 
 // step 6a: is every roulette sum over a subset of this node's list independent of the order of
@@ -386,25 +392,32 @@ __global__ __launch_bounds__(256) void proper_flags_kernel(uint32_t n_nodes, con
                                                            const uint2 *__restrict__ ents, const uint32_t *__restrict__ q_start,
                                                            const uint32_t *__restrict__ q_end, const uint32_t *__restrict__ t_start,
                                                            const uint32_t *__restrict__ t_end, const uint8_t *__restrict__ strand,
-                                                           const uint32_t *__restrict__ node_len, uint8_t *__restrict__ proper) {
+                                                           const uint32_t *__restrict__ node_len, uint8_t *__restrict__ proper,
+                                                           uint32_t *__restrict__ n_internal) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t n = wave; n < n_nodes; n += n_waves) {        // in the owner's list t_index == owner (OverlapGraph.cpp:243-248)
         const uint32_t r0 = row_ptr[n], r1 = row_ptr[n + 1];
-        for (uint32_t e = r0 + lane; e < r1; e += 64)
-            proper[e] = proper_overlap(q_start[e], q_end[e], node_len[ents[e].x & 0x7FFFFFFFu], t_start[e], t_end[e], node_len[n],
-                                       strand && strand[e]) ? 1 : 0;
+        bool internal = false;
+        for (uint32_t e = r0 + lane; e < r1; e += 64) {
+            const bool ok = proper_overlap(q_start[e], q_end[e], node_len[ents[e].x & 0x7FFFFFFFu], t_start[e], t_end[e], node_len[n],
+                                           strand && strand[e]);
+            proper[e] = ok ? 1 : 0;
+            internal |= !ok;
+        }
+        if (__ballot(internal) && lane == 0) atomicOr(n_internal, 1u);
     }
 }
 
 // suspect[n] = 1: more than a quarter of n's list are internal matches (never an anchor: the BFS starts there)
 __global__ __launch_bounds__(256) void suspect_kernel(uint32_t n_nodes, const uint32_t *__restrict__ row_ptr,
-                                                      const uint8_t *__restrict__ proper,
+                                                      const uint8_t *__restrict__ proper, const uint32_t *__restrict__ n_internal,
                                                       const uint8_t *__restrict__ node_anchor, uint8_t *__restrict__ suspect) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    if (*n_internal == 0u) return;           // (nothing to classify: bfs_expand_kernel does not look at `suspect` then)
     for (uint32_t n = wave; n < n_nodes; n += n_waves) {
         const uint32_t r0 = row_ptr[n], deg = row_ptr[n + 1] - r0;
         uint32_t internal = 0;
@@ -428,6 +441,7 @@ __global__ void bfs_init_kernel(uint32_t n_anchors, const uint32_t *__restrict__
 __global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t *__restrict__ counts, const uint32_t *__restrict__ frontier,
                                                          uint32_t level, const uint32_t *__restrict__ row_ptr,
                                                          const uint2 *__restrict__ ents, const uint8_t *__restrict__ proper,
+                                                         const uint32_t *__restrict__ n_internal,
                                                          const uint8_t *__restrict__ suspect, unsigned long long *__restrict__ key,
                                                          uint32_t *__restrict__ next, uint32_t *__restrict__ deferred,
                                                          uint32_t *__restrict__ n_deferred) {
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t *__restrict__ 
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n_f = counts[0];
     uint32_t *n_next = counts + 1;
-    const bool classify = proper != nullptr;
+    const bool classify = proper != nullptr && *n_internal != 0u;      // (a graph of proper overlaps only: every entry, as before)
     for (uint32_t f = wave; f < n_f; f += n_waves) {
         const uint32_t u = frontier[f];
         const unsigned long long nk = ((unsigned long long) (level + 1) << 32) | (key[u] & 0xFFFFFFFFull);
@@ -451,23 +465,6 @@ __global__ __launch_bounds__(256) void bfs_expand_kernel(uint32_t *__restrict__ 
             }
         }
     }
-}
-
-// Between two levels: an empty next frontier with deferred nodes waiting -> they are the next frontier.
-// (two launches: the decision by one thread, the copy by a grid)
-__global__ void bfs_stall_decide_kernel(uint32_t *__restrict__ next_count, uint32_t *__restrict__ n_deferred, uint32_t *__restrict__ moved) {
-    const uint32_t nd = *n_deferred;
-    if (*next_count == 0u && nd != 0u) {
-        *moved = nd;
-        *next_count = nd;
-        *n_deferred = 0u;
-    } else {
-        *moved = 0u;
-    }
-}
-__global__ void bfs_stall_copy_kernel(const uint32_t *__restrict__ moved, const uint32_t *__restrict__ deferred, uint32_t *__restrict__ next) {
-    const uint32_t n = *moved;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) next[i] = deferred[i];
 }
 
 __global__ void bfs_sortkey_kernel(uint32_t n_nodes, const unsigned long long *__restrict__ key,
@@ -742,16 +739,21 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         DevBuf key, f0, f1, cnt, sortkey, sortkey_out, ids, suspect, deferred, stall;
         // the numbering follows proper overlaps and defers nodes whose lists are mostly internal matches (see proper_entry)
         const bool classify = g->q_end && g->t_end && !std::getenv("TLM_ORDER_ALL_EDGES");
-        DevBuf proper_made;
+        DevBuf proper_made, internal_made;
         const uint8_t *proper = nullptr;
+        const uint32_t *n_internal = nullptr;
         if (classify && g->proper_tmp) {
-            proper = g->proper_tmp;         // written by gather_kernel
+            proper = g->proper_tmp;         // written by gather_kernel, with the "any internal match at all?" word behind it
+            n_internal = g->n_internal_tmp;
         } else if (classify) {
             if (int rc = dev_alloc(proper_made, (size_t) g->n_adj + 1)) return rc;
+            if (int rc = dev_alloc(internal_made, 4)) return rc;
+            TLM_HIP(hipMemsetAsync(internal_made.p, 0, 4, s));
             hipLaunchKernelGGL(proper_flags_kernel, dim3(grid_for(std::min<uint64_t>((uint64_t) N * 64, 1u << 20))), dim3(256), 0, s, N,
                                g->row_ptr, g->ent_es, g->q_start, g->q_end, g->t_start, g->t_end, g->strand, g->node_len,
-                               proper_made.as<uint8_t>());
+                               proper_made.as<uint8_t>(), internal_made.as<uint32_t>());
             proper = proper_made.as<uint8_t>();
+            n_internal = internal_made.as<uint32_t>();
         }
         if (int rc = dev_alloc(suspect, (size_t) N)) return rc;
         if (int rc = dev_alloc(deferred, (size_t) N * 4)) return rc;
@@ -759,7 +761,7 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         TLM_HIP(hipMemsetAsync(stall.p, 0, 16, s));
         if (classify)
             hipLaunchKernelGGL(suspect_kernel, dim3(grid_for(std::min<uint64_t>((uint64_t) N * 64, 1u << 20))), dim3(256), 0, s, N,
-                               g->row_ptr, proper, g->node_anchor, suspect.as<uint8_t>());
+                               g->row_ptr, proper, n_internal, g->node_anchor, suspect.as<uint8_t>());
         if (int rc = dev_alloc(key, (size_t) N * 8)) return rc;
         if (int rc = dev_alloc(f0, (size_t) N * 4)) return rc;
         if (int rc = dev_alloc(f1, (size_t) N * 4)) return rc;
@@ -771,9 +773,11 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
         hipLaunchKernelGGL(bfs_init_kernel, dim3((na + 255) / 256), dim3(256), 0, s, na, g->anchors,
                            key.as<unsigned long long>(), f0.as<uint32_t>());
         uint32_t level = 0;
-        static_assert(128 + 2 * (BATCH + 1) * 4 <= TLM_PINNED_SMALL_BYTES, "the BFS counters fit the pinned words");
+        static_assert(128 + (2 * (BATCH + 1) + 1) * 4 <= TLM_PINNED_SMALL_BYTES, "the BFS counters fit the pinned words");
         uint32_t *const h_cnt = (uint32_t *) ((char *) ctx->pinned_small + 128);        // up: this batch's initial counters
         uint32_t *const h_got = h_cnt + (BATCH + 1);                                    // down: what the batch counted
+        uint32_t *const h_deferred = h_got + (BATCH + 1);                               // down: nodes waiting in `deferred`
+        *h_deferred = 0u;
         constexpr size_t cnt_bytes = (BATCH + 1) * sizeof(uint32_t);
         std::memset(h_cnt, 0, cnt_bytes);
         h_cnt[0] = na;
@@ -784,24 +788,28 @@ static int graph_finish(tlm_ctx *ctx, tlm_graph *g, Phases &ph) {
             TLM_HIP(hipMemcpyAsync(cnt.p, h_cnt, cnt_bytes, hipMemcpyHostToDevice, s));     // {frontier size, 0, ..., 0}
             for (uint32_t j = 0; j < BATCH; j++) {
                 hipLaunchKernelGGL(bfs_expand_kernel, dim3(bfs_grid), dim3(256), 0, s, cnt.as<uint32_t>() + j,
-                                   fr[(level + j) & 1u], level + j, g->row_ptr, g->ent_es, proper, suspect.as<uint8_t>(),
+                                   fr[(level + j) & 1u], level + j, g->row_ptr, g->ent_es, proper, n_internal, suspect.as<uint8_t>(),
                                    key.as<unsigned long long>(), fr[(level + j + 1) & 1u], deferred.as<uint32_t>(),
                                    stall.as<uint32_t>());
-                if (classify) {
-                    hipLaunchKernelGGL(bfs_stall_decide_kernel, dim3(1), dim3(1), 0, s, cnt.as<uint32_t>() + j + 1, stall.as<uint32_t>(),
-                                       stall.as<uint32_t>() + 1);
-                    hipLaunchKernelGGL(bfs_stall_copy_kernel, dim3(256), dim3(256), 0, s, stall.as<uint32_t>() + 1,
-                                       deferred.as<uint32_t>(), fr[(level + j + 1) & 1u]);
-                }
             }
             TLM_HIP(hipMemcpyAsync(h_got, cnt.p, cnt_bytes, hipMemcpyDeviceToHost, s));
+            if (classify) TLM_HIP(hipMemcpyAsync(h_deferred, stall.p, 4, hipMemcpyDeviceToHost, s));
             if (int rc = ph.sync()) return rc;
             uint32_t j = 1;
             while (j <= BATCH && h_got[j] != 0) j++;        // level + j - 1 = the last level with a frontier
             done = j <= BATCH;
             level += done ? j : BATCH;
             TLM_CHECK(level <= N + BATCH, TLM_EINTERNAL, "BFS did not terminate");
-            const uint32_t carry = h_got[BATCH];
+            uint32_t carry = h_got[BATCH];
+            if (done && classify && *h_deferred != 0u) {
+                // the frontier has died with deferred nodes waiting (a stall: once or twice per hostile graph, never on a
+                // graph of proper overlaps): they are the next frontier.  Decided here, where the host reads the counters
+                // anyway -- two more kernels per level for this cost 8 ms on the 47 levels of the headline graph
+                carry = *h_deferred;
+                TLM_HIP(hipMemcpyAsync(fr[level & 1u], deferred.p, (size_t) carry * 4, hipMemcpyDeviceToDevice, s));
+                TLM_HIP(hipMemsetAsync(stall.p, 0, 4, s));
+                done = false;
+            }
             std::memset(h_cnt, 0, cnt_bytes);
             h_cnt[0] = carry;
         }
@@ -1075,7 +1083,7 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
     if (int rc = dev_alloc_keep(&g->si, A)) return rc;
     if (int rc = dev_alloc_keep(&g->strand, A)) return rc;
     TLM_HIP(hipMemsetAsync(g->row_ptr, 0, ((size_t) N + 1) * 4, s));
-    DevBuf proper;      // one byte per adjacency entry: proper overlap? (graph_finish numbers the nodes along those)
+    DevBuf proper, n_internal;      // one byte per adjacency entry: proper overlap? (graph_finish numbers the nodes along those)
     if (A) {
         DevBuf owner, eidx, sorted_owner, sorted_e;
         if (int rc = dev_alloc(owner, A * 4)) return rc;
@@ -1102,15 +1110,19 @@ extern "C" int tlm_graph_build(tlm_ctx *ctx, const tlm_filter_params *p, const t
                            node_of_name.as<uint32_t>(), g->node_anchor, r_si.as<float>(), r_os.as<float>(),
                            r_es.as<float>(), kf.as<KeptFields>());
         if (int rc = dev_alloc(proper, (size_t) A + 1)) return rc;
+        if (int rc = dev_alloc(n_internal, 4)) return rc;
+        TLM_HIP(hipMemsetAsync(n_internal.p, 0, 4, s));
         hipLaunchKernelGGL(gather_kernel, dim3(grid_for(A)), dim3(256), 0, s, A, sorted_e.as<uint32_t>(),
                            kf.as<KeptFields>(), g->ent_es, g->ent_os, g->q_start, g->q_end, g->t_start, g->t_end, g->si,
-                           g->strand, proper.as<uint8_t>());
+                           g->strand, proper.as<uint8_t>(), n_internal.as<uint32_t>());
         g->proper_tmp = proper.as<uint8_t>();       // for the walk-order numbering of graph_finish only
+        g->n_internal_tmp = n_internal.as<uint32_t>();
         ph.mark(PH_GATHER);
     }
     // 6.
     const int rc_finish = graph_finish(ctx, g, ph);
     g->proper_tmp = nullptr;
+    g->n_internal_tmp = nullptr;
     if (rc_finish) return rc_finish;
     TLM_HIP(hipEventRecord(ctx->ev1, s));
     TLM_HIP(hipEventSynchronize(ctx->ev1));

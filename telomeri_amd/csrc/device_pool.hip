@@ -117,6 +117,23 @@ void uncache(Pool &P, Block *b) {
 
 thread_local double t_malloc_ms = 0;
 
+// Events that have completed order nothing any more, and one event need not be waited for twice: without this a released
+// remainder that is never taken whole gained an event with every alloc / free cycle next to it (splits copy the list,
+// merges append) -- hipEvents leaked and every taker on another stream queued O(cycles) waits.
+void prune(std::vector<Pending> &pend) {
+    size_t keep = 0;
+    for (size_t i = 0; i < pend.size(); i++) {
+        bool dup = false;
+        for (size_t j = 0; j < keep && !dup; j++) dup = pend[j] == pend[i];
+        if (dup) continue;
+        if (pend[i]->stream != DEAD_STREAM && hipEventQuery(pend[i]->ev) == hipSuccess) continue;       // done: nothing to wait for
+        (void) hipGetLastError();           // (hipErrorNotReady is the expected answer, not an error to keep)
+        if (keep != i) pend[keep] = pend[i];
+        keep++;
+    }
+    pend.resize(keep);
+}
+
 }  // namespace
 
 double tlm_pool_thread_malloc_ms() { return t_malloc_ms; }
@@ -132,11 +149,15 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
     {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.cached.lower_bound(need);
+        // (the rule looks at what was ASKED for: every request is rounded up to 4 KiB / 2 MiB, so the rounded size can never
+        // be below SPLIT_MIN's megabyte in the range where it matters -- round 3 compared the rounded size and a 4-byte flag
+        // carved the front off a 15 GB text segment, which one long-lived small buffer then pinned through every trim)
+        const bool may_split = bytes >= SPLIT_MIN;
         // The smallest released block that holds the request.  Taken whole when it is not much larger (1/8 + 64 KiB; half
         // again for requests of 256 MiB and more: a job's big buffers follow each other, each a little smaller than one the
         // previous stage has just let go); otherwise its front is split off, unless the request is small.
         const size_t slack = need >= (256u << 20) ? need / 2 : need / 8 + (64u << 10);
-        if (it != P.cached.end() && (it->first <= need + slack || need >= SPLIT_MIN)) {
+        if (it != P.cached.end() && (it->first <= need + slack || may_split)) {
             b = it->second;
             P.cached.erase(it);
             P.info.cached_bytes -= b->bytes;
@@ -147,6 +168,7 @@ int tlm_pool_alloc(void **out, size_t bytes, hipStream_t s) {
                 rest->off = b->off + need;
                 rest->bytes = b->bytes - need;
                 rest->stream = b->stream;
+                prune(b->pend);
                 rest->pend = b->pend;               // both parts wait for whoever used the whole
                 b->bytes = need;
                 b->seg->blocks[rest->off] = rest;
@@ -244,6 +266,7 @@ void tlm_pool_free(void *p, bool device_is_synced) {
         b->pend.insert(b->pend.end(), n->pend.begin(), n->pend.end());
         seg->blocks.erase(next);
         delete n;
+        prune(b->pend);
     }
     if (self != seg->blocks.begin()) {
         auto prev = std::prev(self);
@@ -252,6 +275,7 @@ void tlm_pool_free(void *p, bool device_is_synced) {
             uncache(P, q);
             q->bytes += b->bytes;
             q->pend.insert(q->pend.end(), b->pend.begin(), b->pend.end());
+            prune(q->pend);
             if (q->stream != b->stream) q->stream = b->stream;      // (only a label: the events carry the ordering)
             seg->blocks.erase(self);
             delete b;

@@ -143,9 +143,15 @@ struct Collective {
     }
 };
 
-// test hook: TLM_EXCHANGE_FAULT="<rank>:<point>" makes that rank behave as if a local step had failed at <point>
-// (prep, alloc, group, fetch); tests/test_exchange_world2.py checks that every rank then fails, none hangs
+// test hook, CHECKED BUILD ONLY (make EXTRA=-DTLM_CHECKED -> telomeri_amd/lib_checked; the product library has no such
+// switch): TLM_EXCHANGE_FAULT="<rank>:<point>" makes that rank behave as if a local step had failed at <point> (prep, alloc,
+// group, fetch); tests/test_exchange_world.py checks that every rank then fails, none hangs
 bool fault_here(const tlm_ctx *ctx, const char *point) {
+#ifndef TLM_CHECKED
+    (void) ctx;
+    (void) point;
+    return false;
+#else
     const char *f = getenv("TLM_EXCHANGE_FAULT");
     if (!f) return false;
     char *colon = nullptr;
@@ -153,6 +159,7 @@ bool fault_here(const tlm_ctx *ctx, const char *point) {
     if (!colon || *colon != ':' || r != ctx->rank || std::strcmp(colon + 1, point) != 0) return false;
     tlm_set_error("injected failure at '%s' on rank %d (TLM_EXCHANGE_FAULT)", point, ctx->rank);
     return true;
+#endif
 }
 
 // Swap the ranks' local status; TLM_OK only if every rank is fine.  With a failure somewhere every rank returns: the
@@ -282,7 +289,15 @@ extern "C" int tlm_dist_init(tlm_ctx *ctx, int rank, int world, const uint8_t *i
         TLM_HIP(hipStreamSynchronize(ctx->stream));
     }
     ncclComm_t comm = nullptr;
-    TLM_NCCL(api, api->CommInitRank(&comm, world, id, rank));
+    {
+        const ncclResult_t r = api->CommInitRank(&comm, world, id, rank);
+        if (r != ncclSuccess) {                 // (no communicator: tlm_dist_finalize has nothing to do, the scratch goes here)
+            tlm_pool_free(ctx->xchg_scratch, true);
+            ctx->xchg_scratch = nullptr;
+            tlm_set_error("ncclCommInitRank failed: %s", api->GetErrorString ? api->GetErrorString(r) : "?");
+            return TLM_EHIP;
+        }
+    }
     ctx->comm = comm;
     ctx->comm_broken = false;
     ctx->rank = rank;
@@ -291,7 +306,15 @@ extern "C" int tlm_dist_init(tlm_ctx *ctx, int rank, int world, const uint8_t *i
 }
 
 extern "C" void tlm_dist_finalize(tlm_ctx *ctx) {
-    if (!ctx || (!ctx->comm && !ctx->comm_broken)) return;
+    if (!ctx) return;
+    if (!ctx->comm && !ctx->comm_broken) {      // never initialised (or initialisation failed): only the scratch may be left
+        if (ctx->xchg_scratch) {
+            (void) hipSetDevice(ctx->device);
+            tlm_pool_free(ctx->xchg_scratch);
+            ctx->xchg_scratch = nullptr;
+        }
+        return;
+    }
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     if (ctx->comm) {

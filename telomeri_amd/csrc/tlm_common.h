@@ -86,6 +86,7 @@ struct tlm_graph {
     float *si = nullptr;
     uint8_t *strand = nullptr;
     const uint8_t *proper_tmp = nullptr;   // during tlm_graph_build only: 1 = proper overlap (csr_build.hip, walk-order numbering)
+    const uint32_t *n_internal_tmp = nullptr;      // ... and a word that is non-zero when any entry is an internal match
     uint32_t *node_len = nullptr;
     uint8_t *node_anchor = nullptr;
     uint8_t *node_flags = nullptr;

@@ -91,7 +91,7 @@ constexpr int WALK_BLOCK = TLM_WALK_BLOCK;      // independent waves of a workgr
 constexpr int WALK_WAVES_PER_BLOCK = WALK_BLOCK / 64;
 
 // resident workgroups per CU of the kernel (occupancy query): the persistent grid is sized from it
-int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric, bool lite);
+int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric, bool lite, bool account);
 // account: the build of the kernel that also sums the layout bytes its steps ask for into cursor[10..11] (tlm_counters.layout_bytes)
 // -> 0; the checked build (-DTLM_CHECKED) waits for the launch and returns 1, with the error text set, when a kernel formed
 // an index outside one of its arrays (the access itself was skipped)

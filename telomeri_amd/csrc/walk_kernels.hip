@@ -2036,17 +2036,20 @@ __global__ __launch_bounds__(WALK_BLOCK, LITE ? TLM_DET_LITE_WAVES : TLM_DET_WAV
 
 }  // namespace
 
-int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric, bool lite) {
+int tlm_walk_blocks_per_cu(bool is_mc, bool sqrt_metric, bool lite, bool account) {
     int n = 0;
     hipError_t e;
-    if (lite && is_mc) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<true, false, true>, WALK_BLOCK, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<false, false, true>, WALK_BLOCK, 0);
-    else if (lite) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<true, false, true>, WALK_BLOCK, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<false, false, true>, WALK_BLOCK, 0);
-    else if (is_mc) e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<true>, WALK_BLOCK, 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_mc_kernel<false>, WALK_BLOCK, 0);
-    else e = sqrt_metric ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<true>, WALK_BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, walk_det_kernel<false>, WALK_BLOCK, 0);
+    auto ask = [&](auto kernel) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, WALK_BLOCK, 0); };
+    if (account) {          // (accounting launches are never LITE)
+        if (is_mc) e = sqrt_metric ? ask(walk_mc_kernel<true, true>) : ask(walk_mc_kernel<false, true>);
+        else e = sqrt_metric ? ask(walk_det_kernel<true, true>) : ask(walk_det_kernel<false, true>);
+    } else if (lite) {
+        if (is_mc) e = sqrt_metric ? ask(walk_mc_kernel<true, false, true>) : ask(walk_mc_kernel<false, false, true>);
+        else e = sqrt_metric ? ask(walk_det_kernel<true, false, true>) : ask(walk_det_kernel<false, false, true>);
+    } else {
+        if (is_mc) e = sqrt_metric ? ask(walk_mc_kernel<true>) : ask(walk_mc_kernel<false>);
+        else e = sqrt_metric ? ask(walk_det_kernel<true>) : ask(walk_det_kernel<false>);
+    }
     if (e != hipSuccess || n < 1) n = 1;
     return n;
 }

@@ -15,6 +15,15 @@
 // the k-th ncclRecv of b from a with the same byte count; an unmatched send or receive, or a size mismatch, is an error
 // on both sides instead of a hang.  A rank that fails or times out (FAKE_RCCL_TIMEOUT_S, default 120) raises a flag in
 // the control page and every peer's pending or next call fails too (ncclRemoteError).
+//
+// FAKE_RCCL_ASYNC=1 (round 4): the calls behave like RCCL's towards the CALLER -- they return at once, the operation runs
+// in stream order on the caller's stream and completes later.  Every call / outermost ncclGroupEnd records an event on its
+// stream, queues a one-lane GATE kernel behind it (it holds the stream until the batch is done, as the collective's own
+// kernel would) and hands the batch to the communicator's worker thread; the worker waits FAKE_RCCL_ASYNC_DELAY_MS (default
+// 30) on purpose, then for the event, moves the bytes over a stream of its own, and opens the gate.  A caller that reads a
+// result on the host before it has synchronised the stream, that frees or reuses a buffer early, or that launches a
+// consumer on another stream without an event, finds stale data here, on ONE GPU.  Errors of a batch surface at the next
+// call (as RCCL's asynchronous errors do): the failure tests run in the synchronous mode.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -22,14 +31,21 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
 
+#ifdef FAKE_RCCL_HOST_ONLY
 #include <hip/hip_runtime_api.h>
+#else
+#include <hip/hip_runtime.h>
+#endif
 #include <rccl/rccl.h>
 
 // FAKE_RCCL_HOST_ONLY (tests/fake_rccl/Makefile target `host`): the same library with buffers in HOST memory and no HIP
@@ -46,12 +62,26 @@ struct Control {                    // one page in /dev/shm/<id>.ctl, zero-fille
     std::atomic<uint32_t> arrived, generation, failed, members;
 };
 
+struct Job;
 struct Comm {
     int rank = 0, world = 1;
     Control *ctl = nullptr;
     std::string base;               // /dev/shm/<id>
     uint64_t seq = 0;               // batches executed so far: the same on every rank (collective call order)
     double timeout_s = 120;
+    // FAKE_RCCL_ASYNC: batches are executed by a worker thread behind a gate kernel on the caller's stream
+    bool async = false;
+    int delay_ms = 30;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job *> jobs;
+    bool stop = false;
+    std::atomic<int> async_error{0};        // first failed batch (sticky): reported by the next call
+    uint32_t *gate_host = nullptr, *gate_dev = nullptr;     // host-mapped word the gate kernels watch
+    uint32_t gate_seq = 0;
+    hipStream_t copy_stream = nullptr;
+    void *stage = nullptr, *stage_dev = nullptr;    // pinned, device-mapped staging buffer of the worker's copies
 };
 
 enum Kind { SEND, RECV, BCAST, ALLGATHER };
@@ -63,6 +93,12 @@ struct Op {
     size_t bytes;
     int peer;                       // peer (send / recv) or root (broadcast)
     hipStream_t stream;
+};
+
+struct Job {
+    std::vector<Op> ops;
+    hipEvent_t ready = nullptr;
+    uint32_t gate = 0;
 };
 
 thread_local int g_depth = 0;
@@ -148,14 +184,58 @@ std::string piece(const Comm *c, uint64_t seq, const char *tag, long long a, lon
     return c->base + buf;
 }
 
-ncclResult_t run_batch(std::vector<Op> &ops) {
+// device <-> host copies of a batch: synchronous calls in the synchronous mode; in the asynchronous mode the caller's stream
+// is held by the gate kernel, so the worker copies on a stream of its own
+#ifndef FAKE_RCCL_HOST_ONLY
+// byte copy by a kernel: device memory <-> the worker's pinned, device-mapped staging buffer (or device <-> device)
+__global__ void fake_rccl_copy_kernel(unsigned char *dst, const unsigned char *src, size_t n) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+hipError_t batch_copy(Comm *c, void *dst, const void *src, size_t n, hipMemcpyKind kind) {
+    if (!c->async) return hipMemcpy(dst, src, n, kind);
+    // NOT through the runtime's copy calls: its copies of one direction run in order behind each other (an SDMA engine, or
+    // the runtime's own blit queue, is a FIFO), and the CALLER's device-to-host copy that waits behind the gate kernel --
+    // in stream order, as it should -- holds every later copy, the worker's included: the batch that has to open the
+    // gate never gets its bytes (first versions: the 4.5 MB summary all-gather "took" 60 005 ms on both ranks, the gate's own
+    // time-out).  A kernel on the worker's stream reads and writes a pinned, device-mapped staging buffer instead.
+    constexpr size_t STAGE = 4u << 20;
+    if (!c->stage) {
+        if (hipHostMalloc(&c->stage, STAGE, hipHostMallocMapped) != hipSuccess) return hipErrorOutOfMemory;
+        if (hipHostGetDevicePointer(&c->stage_dev, c->stage, 0) != hipSuccess) return hipErrorOutOfMemory;
+    }
+    auto run = [&](void *d, const void *s_, size_t m) {
+        hipLaunchKernelGGL(fake_rccl_copy_kernel, dim3(256), dim3(256), 0, c->copy_stream, (unsigned char *) d, (const unsigned char *) s_, m);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? hipStreamSynchronize(c->copy_stream) : e;
+    };
+    if (kind == hipMemcpyDeviceToDevice) return run(dst, src, n);
+    for (size_t at = 0; at < n; at += STAGE) {
+        const size_t m = n - at < STAGE ? n - at : STAGE;
+        hipError_t e;
+        if (kind == hipMemcpyDeviceToHost) {
+            e = run(c->stage_dev, (const char *) src + at, m);
+            if (e == hipSuccess) std::memcpy((char *) dst + at, c->stage, m);
+        } else {
+            std::memcpy(c->stage, (const char *) src + at, m);
+            e = run((char *) dst + at, c->stage_dev, m);
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+#else
+#define batch_copy(c, dst, src, n, kind) (std::memcpy((dst), (src), (n)), hipSuccess)
+#endif
+
+ncclResult_t run_batch(std::vector<Op> &ops, bool streams_are_ready = false) {
     if (ops.empty()) return ncclSuccess;
     Comm *c = ops[0].comm;
     for (const Op &o : ops)
         if (o.comm != c) return fail(c, ncclInvalidUsage, "one group spans several communicators%s", "");
     for (const Op &o : ops) {
         (void) o;
-        if (hipStreamSynchronize(o.stream) != hipSuccess) return fail(c, ncclUnhandledCudaError, "hipStreamSynchronize failed%s", "");
+        if (!streams_are_ready && hipStreamSynchronize(o.stream) != hipSuccess) return fail(c, ncclUnhandledCudaError, "hipStreamSynchronize failed%s", "");
     }
     const uint64_t seq = c->seq++;
     std::vector<char> host;
@@ -171,7 +251,7 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
         else if (o.kind == ALLGATHER) path = piece(c, seq, "g", c->rank, 0, n_gather++);
         else continue;
         host.resize(o.bytes ? o.bytes : 1);
-        if (o.bytes && hipMemcpy(host.data(), o.src, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (o.bytes && batch_copy(c, host.data(), o.src, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(c, ncclUnhandledCudaError, "device-to-host copy of %s failed", path.c_str());
             break;
         }
@@ -181,7 +261,10 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
         }
         mine.push_back(path);
     }
+    static const bool verbose_steps = std::getenv("FAKE_RCCL_ASYNC_VERBOSE") != nullptr;
+    const auto t_pub = std::chrono::steady_clock::now();
     if (rc == ncclSuccess) rc = barrier(c);
+    const auto t_bar = std::chrono::steady_clock::now();
     // ---- consume
     n_bcast = n_gather = 0;
     for (size_t i = 0; rc == ncclSuccess && i < ops.size(); i++) {
@@ -194,7 +277,7 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
                                    : o.kind == BCAST ? piece(c, seq, "b", r, 0, k) : piece(c, seq, "g", r, 0, k);
             char *dst = (char *) o.dst + (o.kind == ALLGATHER ? (size_t) r * o.bytes : 0);
             if (o.kind == BCAST && r == c->rank) {          // the root: send buffer -> receive buffer when they differ
-                if (o.src != o.dst && o.bytes && hipMemcpy(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+                if (o.src != o.dst && o.bytes && batch_copy(c, o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess)
                     rc = fail(c, ncclUnhandledCudaError, "root copy of %s failed", path.c_str());
                 continue;
             }
@@ -203,11 +286,15 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
             const int st = read_file(path, host.data(), o.bytes, &got);
             if (st == -1) rc = fail(c, ncclInvalidUsage, "no matching operation on the peer for %s", path.c_str());
             else if (st == -2) rc = fail(c, ncclInvalidArgument, "size mismatch on %s: expected %lld bytes, peer gave %lld", path.c_str(), (long long) o.bytes, got);
-            else if (o.bytes && hipMemcpy(dst, host.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess)
+            else if (o.bytes && batch_copy(c, dst, host.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess)
                 rc = fail(c, ncclUnhandledCudaError, "host-to-device copy of %s failed", path.c_str());
             if (rc == ncclSuccess && o.kind == RECV) ::unlink(path.c_str());      // taken: what is left after the batch is unmatched
         }
     }
+    if (verbose_steps && c->async)
+        std::fprintf(stderr, "fake_rccl[rank %d]   batch seq %llu: barrier after publish %.0f ms, consume %.0f ms\n", c->rank, (unsigned long long) seq,
+                     std::chrono::duration<double, std::milli>(t_bar - t_pub).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bar).count());
     if (rc == ncclSuccess) rc = barrier(c);
     // ---- tidy; a send file that is still there was never received
     for (const std::string &p : mine) {
@@ -220,6 +307,84 @@ ncclResult_t run_batch(std::vector<Op> &ops) {
     return rc;
 }
 
+#ifndef FAKE_RCCL_HOST_ONLY
+// Holds the caller's stream until the worker has finished batch `want` (or a minute has passed: the grid always drains).
+__global__ void fake_rccl_gate_kernel(const uint32_t *flag, uint32_t want) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();              // 100 MHz
+    while ((int32_t) (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        if (wall_clock64() - t0 > 60ull * 100000000ull) break;
+        __builtin_amdgcn_s_sleep(100);
+    }
+}
+
+void worker_main(Comm *c) {
+    for (;;) {
+        Job *j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop || !c->jobs.empty(); });
+            if (c->jobs.empty()) return;
+            j = c->jobs.front();
+            c->jobs.pop_front();
+        }
+        static const bool verbose = std::getenv("FAKE_RCCL_ASYNC_VERBOSE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        std::this_thread::sleep_for(std::chrono::milliseconds(c->delay_ms));     // on purpose: the caller is long gone
+        ncclResult_t rc = ncclSuccess;
+        if (hipEventSynchronize(j->ready) != hipSuccess) rc = fail(c, ncclUnhandledCudaError, "hipEventSynchronize failed%s", "");
+        const double t_ready = ms();
+        size_t bytes = 0;
+        for (const Op &o : j->ops) bytes += o.bytes;
+        if (rc == ncclSuccess) rc = run_batch(j->ops, true);
+        if (verbose)
+            std::fprintf(stderr, "fake_rccl[rank %d] async batch %u: %zu ops, %zu bytes; inputs ready after %.0f ms, done after %.0f ms, rc %d\n",
+                         c->rank, j->gate, j->ops.size(), bytes, t_ready, ms(), (int) rc);
+        if (rc != ncclSuccess) {
+            int expected = 0;
+            c->async_error.compare_exchange_strong(expected, (int) rc);
+        }
+        __atomic_store_n(c->gate_host, j->gate, __ATOMIC_RELEASE);              // the gate opens whatever happened
+        (void) hipEventDestroy(j->ready);
+        delete j;
+    }
+}
+
+ncclResult_t run_batch_async(std::vector<Op> &ops) {
+    if (ops.empty()) return ncclSuccess;
+    Comm *c = ops[0].comm;
+    if (const int e = c->async_error.load()) return fail(c, (ncclResult_t) e, "an earlier asynchronous batch failed%s", "");
+    for (const Op &o : ops)
+        if (o.comm != c || o.stream != ops[0].stream) return fail(c, ncclInvalidUsage, "one group spans several communicators or streams%s", "");
+    Job *j = new Job();
+    j->ops.swap(ops);
+    j->gate = ++c->gate_seq;
+    if (hipEventCreateWithFlags(&j->ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(j->ready, j->ops[0].stream) != hipSuccess) {
+        delete j;
+        return fail(c, ncclUnhandledCudaError, "cannot record the batch's event%s", "");
+    }
+    hipLaunchKernelGGL(fake_rccl_gate_kernel, dim3(1), dim3(64), 0, j->ops[0].stream, (const uint32_t *) c->gate_dev, j->gate);
+    if (hipGetLastError() != hipSuccess) {
+        delete j;
+        return fail(c, ncclUnhandledCudaError, "cannot launch the gate kernel%s", "");
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->jobs.push_back(j);
+    }
+    c->cv.notify_one();
+    return ncclSuccess;
+}
+#endif
+
+ncclResult_t dispatch(std::vector<Op> &ops) {
+#ifndef FAKE_RCCL_HOST_ONLY
+    if (!ops.empty() && ops[0].comm && ops[0].comm->async) return run_batch_async(ops);
+#endif
+    return run_batch(ops);
+}
+
 ncclResult_t submit(const Op &o) {
     if (!o.comm) return ncclInvalidArgument;
     if (o.kind != ALLGATHER && (o.peer < 0 || o.peer >= o.comm->world)) return fail(o.comm, ncclInvalidArgument, "peer out of range%s", "");
@@ -228,7 +393,7 @@ ncclResult_t submit(const Op &o) {
     if (g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_pending);
-    return run_batch(ops);
+    return dispatch(ops);
 }
 
 }   // namespace
@@ -281,6 +446,23 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
         delete c;
         return rc;
     }
+#ifndef FAKE_RCCL_HOST_ONLY
+    if (const char *a = std::getenv("FAKE_RCCL_ASYNC")) {
+        if (std::atoi(a) != 0) {
+            if (const char *d = std::getenv("FAKE_RCCL_ASYNC_DELAY_MS")) c->delay_ms = std::atoi(d);
+            if (hipHostMalloc((void **) &c->gate_host, 64, hipHostMallocMapped) != hipSuccess
+                || hipHostGetDevicePointer((void **) &c->gate_dev, c->gate_host, 0) != hipSuccess
+                || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+                ::munmap(m, 4096);
+                delete c;
+                return ncclUnhandledCudaError;
+            }
+            *c->gate_host = 0;
+            c->async = true;
+            c->worker = std::thread(worker_main, c);
+        }
+    }
+#endif
     *comm = (ncclComm_t) c;
     return ncclSuccess;
 }
@@ -288,6 +470,19 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
 static ncclResult_t leave(ncclComm_t comm, bool abort) {
     Comm *c = (Comm *) comm;
     if (!c) return ncclInvalidArgument;
+#ifndef FAKE_RCCL_HOST_ONLY
+    if (c->async) {         // what is queued is finished first (its gates must open), then the worker goes
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->stop = true;
+        }
+        c->cv.notify_one();
+        if (c->worker.joinable()) c->worker.join();
+        (void) hipStreamDestroy(c->copy_stream);
+        (void) hipHostFree(c->gate_host);
+        if (c->stage) (void) hipHostFree(c->stage);
+    }
+#endif
     if (abort) c->ctl->failed.store(1);
     if (c->ctl->members.fetch_sub(1) == 1) ::unlink((c->base + ".ctl").c_str());
     ::munmap(c->ctl, 4096);
@@ -315,7 +510,7 @@ ncclResult_t ncclGroupEnd() {
     if (--g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_pending);
-    return run_batch(ops);
+    return dispatch(ops);
 }
 
 ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t s) {

@@ -85,3 +85,13 @@ def test_cold_args_only_in_kernels():
         assert marks == 0, "%s is a real call and reads the kernarg segment (a null pointer there)" % name
         assert any(k in name for k in ("mt_seed", "mt_twist", "band_slide", "select_long", "select_serial", "det_select_long")), name
     assert seen_kernels == 12
+
+
+def test_product_library_carries_no_test_hooks():
+    """The fault-injection switch of the exchange lives in the checked build only; the product neither
+    reads it nor can be talked onto another architecture."""
+    product = open(os.path.join(ROOT, "telomeri_amd", "lib", "libtelomeri_hip.so"), "rb").read()
+    assert b"TLM_EXCHANGE_FAULT" not in product and b"TLM_ALLOW_ANY_ARCH" not in product
+    checked = os.path.join(ROOT, "telomeri_amd", "lib_checked", "libtelomeri_hip.so")
+    if os.path.exists(checked):
+        assert b"TLM_EXCHANGE_FAULT" in open(checked, "rb").read()

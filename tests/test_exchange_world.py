@@ -21,6 +21,9 @@ from telomeri_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+# the fault-injection switch (TLM_EXCHANGE_FAULT) exists in the CHECKED build of the library only (make EXTRA=-DTLM_CHECKED)
+CHECKED_DIR = os.path.join(ROOT, "telomeri_amd", "lib_checked")
+CHECKED = os.path.join(CHECKED_DIR, "libtelomeri_hip.so")
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +33,10 @@ def fake_rccl():
     if not os.path.exists(FAKE):
         subprocess.run(["make", "-s", "-C", os.path.dirname(FAKE)], check=True)
     return FAKE
+
+
+def _async_env(on: bool) -> dict:
+    return {"FAKE_RCCL_ASYNC": "1" if on else "0"}
 
 
 def run_ranks(fake, dataset, world, tmp, extra_env=None, timeout=420):
@@ -63,9 +70,16 @@ def one_process(ctx, dataset):
     return dg, wp, sets, want
 
 
-@pytest.mark.parametrize("partition", ["sliced", "contiguous"])
-@pytest.mark.parametrize("dataset,world", [("toy", 2), ("quirks", 2), ("toy", 4), ("quirks", 3), ("hub", 2)])
-def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world, partition):
+# "async": the stand-in returns from every call at once and completes the operation later, in stream order, behind a delay
+# (FAKE_RCCL_ASYNC, tests/fake_rccl/fake_rccl.cpp): a missing stream dependency between a local kernel and a transfer, a
+# host read of a gathered size before its stream has drained, a buffer released early -- all of which the synchronous mode
+# executes "correctly" -- show here as wrong results on one GPU
+CASES = [(d, w, p, "sync") for p in ("sliced", "contiguous") for d, w in (("toy", 2), ("quirks", 2), ("toy", 4), ("quirks", 3), ("hub", 2))]
+CASES += [("toy", 2, "sliced", "async"), ("quirks", 3, "sliced", "async"), ("hub", 2, "contiguous", "async"), ("toy", 4, "contiguous", "async")]
+
+
+@pytest.mark.parametrize("dataset,world,partition,mode", CASES)
+def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world, partition, mode):
     dg, wp, sets, want = one_process(ctx, dataset)
     h = want.to_host()
     front, back, count, hsh = want.summary()
@@ -73,7 +87,7 @@ def test_exchange_with_several_ranks(ctx, fake_rccl, dataset, world, partition):
     n = len(h)
     assert n > 0
     with tempfile.TemporaryDirectory() as tmp:
-        outs = run_ranks(fake_rccl, dataset, world, tmp, {"TLM_TEST_PARTITION": partition})
+        outs = run_ranks(fake_rccl, dataset, world, tmp, dict(_async_env(mode == "async"), TLM_TEST_PARTITION=partition))
         for r, (rc, out) in enumerate(outs):
             err = os.path.join(tmp, "rank%d.err" % r)
             assert rc == 0, "rank %d: %s\n%s" % (r, open(err).read() if os.path.exists(err) else "", out[-2000:])
@@ -148,7 +162,8 @@ def test_ranks_fail_together(fake_rccl, point):
     communicator is aborted and later calls fail at once."""
     with tempfile.TemporaryDirectory() as tmp:
         # (rank 0 is the culprit: in the toy set the last anchor, rank 1's only one, has no accepted path -- nothing to send)
-        outs = run_ranks(fake_rccl, "toy", 2, tmp, {"TLM_EXCHANGE_FAULT": "0:" + point}, timeout=300)
+        outs = run_ranks(fake_rccl, "toy", 2, tmp, {"TLM_EXCHANGE_FAULT": "0:" + point, "TLM_LIB": CHECKED, "TLM_TEST_PARTITION": "contiguous"},
+                         timeout=300)
         logs = []
         for r, (rc, out) in enumerate(outs):
             assert rc == 0, "rank %d: %s" % (r, out[-2000:])
@@ -201,17 +216,17 @@ def _run_sh(d, args, env):
     return res, body
 
 
-@pytest.mark.parametrize("name", ["tiny", "quirks"])
-@pytest.mark.parametrize("mode", ["lazy", "full"])
-def test_host_program_with_two_ranks(fake_rccl, name, mode):
+@pytest.mark.parametrize("name,mode,collectives", [("tiny", "lazy", "sync"), ("tiny", "full", "sync"), ("quirks", "lazy", "sync"),
+                                                   ("quirks", "full", "sync"), ("tiny", "lazy", "async"), ("quirks", "full", "async")])
+def test_host_program_with_two_ranks(fake_rccl, name, mode, collectives):
     """telomeri_hip as a two-rank job (TLM_WORLD=2: every rank loads and builds, walks its bundle, joins the exchange, runs
     the host stages; rank 0 writes the scaffold): same report, same scaffold bytes as the one-process run."""
     with tempfile.TemporaryDirectory() as tmp:
         d, args = _dataset_dir(tmp, name)
         one, body_one = _run_sh(d, args, {})
         assert one.returncode == 0, one.stderr[-2000:]
-        two, body_two = _run_sh(d, args, {"TLM_GPUS": "2", "TLM_DEVICES": "0 0", "TLM_RCCL_LIB": fake_rccl, "TLM_EXCHANGE": mode,
-                                          "FAKE_RCCL_TIMEOUT_S": "90"})
+        two, body_two = _run_sh(d, args, dict(_async_env(collectives == "async"), TLM_GPUS="2", TLM_DEVICES="0 0", TLM_RCCL_LIB=fake_rccl,
+                                              TLM_EXCHANGE=mode, FAKE_RCCL_TIMEOUT_S="90"))
         rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
         assert two.returncode == 0, two.stderr[-2000:] + rank1[-2000:]
         assert "Gathered" in two.stdout and "from 2 ranks" in two.stdout and "from 2 ranks" in rank1
@@ -232,8 +247,10 @@ def test_host_program_ranks_end_together(fake_rccl):
     with tempfile.TemporaryDirectory() as tmp:
         d, args = _dataset_dir(tmp, "tiny")
         t0 = time.time()
+        # (the host program finds the library next to itself: LD_LIBRARY_PATH puts the checked build in front of that)
         res, body = _run_sh(d, args, {"TLM_GPUS": "2", "TLM_DEVICES": "0 0", "TLM_RCCL_LIB": fake_rccl, "TLM_EXCHANGE_FAULT": "1:prep",
-                                      "FAKE_RCCL_TIMEOUT_S": "90"})
+                                      "FAKE_RCCL_TIMEOUT_S": "90",
+                                      "LD_LIBRARY_PATH": CHECKED_DIR + ":" + os.environ.get("LD_LIBRARY_PATH", "")})
         assert res.returncode != 0 and body is None
         assert time.time() - t0 < 120
         rank1 = open(os.path.join(d, "telomeri_rank1.log")).read()
@@ -256,9 +273,9 @@ def _bench(fake, extra_env, timeout=420, extra_args=()):
     return res, (json.loads(lines[-1]) if lines else None), time.time() - t0
 
 
-@pytest.mark.parametrize("partition", ["sliced", "contiguous"])
-def test_bench_two_ranks_line_is_a_measured_line(fake_rccl, partition):
-    res, line, _ = _bench(fake_rccl, {}, extra_args=["--partition", partition])
+@pytest.mark.parametrize("partition,collectives", [("sliced", "sync"), ("contiguous", "sync"), ("sliced", "async")])
+def test_bench_two_ranks_line_is_a_measured_line(fake_rccl, partition, collectives):
+    res, line, _ = _bench(fake_rccl, _async_env(collectives == "async"), extra_args=["--partition", partition])
     assert res.returncode == 0, res.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert partition in line["config"]["partition"]
@@ -278,7 +295,7 @@ def test_bench_two_ranks_line_is_a_measured_line(fake_rccl, partition):
 def test_bench_rank_that_loses_its_communicator_ends_the_job(fake_rccl):
     """a failure in the middle of the grouped transfers aborts the communicator; the failing rank must LEAVE (the
     launcher ends the others) instead of waiting for its peers in the harness's gather until a collective timeout."""
-    res, line, seconds = _bench(fake_rccl, {"TLM_EXCHANGE_FAULT": "1:group", "TLM_EXCHANGE": "full"}, timeout=300)
+    res, line, seconds = _bench(fake_rccl, {"TLM_EXCHANGE_FAULT": "1:group", "TLM_EXCHANGE": "full", "TLM_LIB": CHECKED}, timeout=300)
     assert res.returncode != 0, res.stdout[-500:]
     assert line is None
     assert seconds < 150, "the job took %.0f s to end" % seconds

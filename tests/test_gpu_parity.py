@@ -19,6 +19,18 @@ def ctx():
     return capi.Context(0)
 
 
+@pytest.fixture(scope="module")
+def ctx_full():
+    """A context whose walks always launch the FULL instantiations of the kernels (TLM_WALK_FULL_KERNEL is read once, when a
+    context is made)."""
+    import os
+    os.environ["TLM_WALK_FULL_KERNEL"] = "1"
+    try:
+        return capi.Context(0)
+    finally:
+        del os.environ["TLM_WALK_FULL_KERNEL"]
+
+
 def _walk_both(ctx, dg, og, metric, wp, *, mc, unit_begin=0, unit_end=None):
     if mc:
         ps = dg.walk_mc(metric, wp, unit_begin, unit_end)
@@ -691,7 +703,7 @@ def test_walks_across_lane_widths(ctx):
 
 
 @pytest.mark.parametrize("seed", list(range(64)))
-def test_fuzz_small_graphs(ctx, seed, monkeypatch):
+def test_fuzz_small_graphs(ctx, ctx_full, seed):
     """Random small graphs with everything the generators above keep apart mixed together: nodes without a list,
     multi-edges, lists of one entry, several anchors next to each other or none reachable, metrics that are zero,
     negative zero, negative, huge, tiny or equal (ties in the deterministic ranks), random walk parameters."""
@@ -732,11 +744,10 @@ def test_fuzz_small_graphs(ctx, seed, monkeypatch):
     # instantiations of the kernels (csrc/api.hip); every fourth seed also goes through the full kernels, which these small
     # graphs would otherwise never reach on their short-list paths
     for full in ((False, True) if seed % 4 == 0 else (False,)):
-        if full:
-            monkeypatch.setenv("TLM_WALK_FULL_KERNEL", "1")
+        g = ctx_full.graph_from_csr(*args) if full else dg
         for metric in (capi.METRIC_ES, capi.METRIC_OS, capi.METRIC_ES_SQRT, capi.METRIC_OS_SQRT):
-            _walk_both(ctx, dg, og, metric, wp, mc=True)
-            _walk_both(ctx, dg, og, metric, None, mc=False)
+            _walk_both(ctx, g, og, metric, wp, mc=True)
+            _walk_both(ctx, g, og, metric, None, mc=False)
 
 
 @pytest.mark.parametrize("seed", list(range(8)))
