@@ -234,7 +234,7 @@ def test_chr1_graph_and_walks(ctx):
     rb = 2000
     wp = capi.WalkParams.default(rb_att=rb)
     anchors, det_off = g.anchor_table()
-    a0, a1 = 248, 251
+    a0, a1 = 230, 270                     # a 40-anchor bundle (it was 3 anchors)
     d0, d1 = int(det_off[a0]), int(det_off[a1])
     sets = g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, (a0 * rb, a1 * rb), (d0, d1))
     mc_anchor = lambda u: anchors[(u // rb).astype(np.int64)]
@@ -251,9 +251,20 @@ def test_chr1_graph_and_walks(ctx):
         del h
     assert sets[0].n_paths > 100 and long_steps > 0, "no accepted path crossed a node with more than 512 neighbours"
     og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
-    mc_units = [(a0 * rb, a0 * rb + 24), ((a0 + 1) * rb + 777, (a0 + 1) * rb + 801)]
-    det_units = [(d0, d0 + 16), (d1 - 16, d1)]
-    _oracle_sample(g, og, csr, wp, mc_units, det_units)
+    # EVERY unit of the bundle, all four builders, against the oracle: 160 000 Monte-Carlo + ~19 000 deterministic walks,
+    # ~1.2e11 evals -- half a minute of the oracle on the box's CPU share
+    from telomeri_amd import cpu_share
+    threads = max(1, min(16, cpu_share.cpu_share()))
+    owp = po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
+    evals = 0
+    for k, (kind, metric) in enumerate((("mc", po.METRIC_ES), ("mc", po.METRIC_OS), ("det", po.METRIC_ES), ("det", po.METRIC_OS))):
+        ops, octr, ostats = (og.walk_mc(metric, owp, po.SEED_PER_WALK, a0 * rb, a1 * rb, threads=threads) if kind == "mc"
+                             else og.walk_det(metric, d0, d1, threads=threads))
+        H.assert_stats_equal(sets[k].unit_stats(), ostats)
+        assert sets[k].counters.evals == octr.evals
+        H.assert_paths_equal(sets[k].to_host(), ops)
+        evals += int(octr.evals)
+    assert evals > 5e10
 
 
 def test_yeast_full_trials(ctx):
@@ -333,12 +344,27 @@ def test_full_config_scaffold_parity(ctx):
         n_reads = ds.n_reads
         names_of = lambda i: "read%07d" % (i + 1) if i < n_reads else "ctg%d" % (i - n_reads + 1)       # synth.Dataset.name_of
         assert names_of(0) == ds.name_of(0) and names_of(n_reads) == ds.name_of(n_reads)
+        # the records as host columns, for the oracle's own graph build below (6 GB)
+        host_ctg = ds.name_is_ctg().numpy().astype(np.uint8)
+        cols = lambda rec: [rec.q_id.cpu().numpy(), rec.t_id.cpu().numpy()] + [getattr(rec, c).cpu().numpy() for c in H.REC_COLS]
+        host_rr, host_cr = cols(ds.rr), cols(ds.cr)
         del ds
         torch.cuda.empty_cache()
         # ---- device: all four builders over all units
         sets = list(g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp))
         csr = g.download(cold=True)
-        og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
+        # ---- a4 at full size: the ORACLE's own graph, built from the 150.8 M records by its own filter,
+        # first-seen numbering and adjacency insertion (tlo_graph_add_records), equals the device's CSR bit for bit -- the
+        # oracle below then walks ITS graph, not a copy of the device's
+        t_graph = time.time()
+        og = po.Graph()
+        og.add_records(False, H.to_oracle_fp(capi.FilterParams.default()), host_ctg, *host_rr)
+        og.add_records(True, H.to_oracle_fp(capi.FilterParams.default()), host_ctg, *host_cr)
+        del host_rr, host_cr
+        ocsr = og.csr()
+        H.assert_csr_equal(csr, ocsr)
+        del ocsr
+        t_graph = time.time() - t_graph
         owp = po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
         osets = []
         evals = units = 0
@@ -382,14 +408,14 @@ def test_full_config_scaffold_parity(ctx):
         a, b = open(got_fa, "rb").read(), open(want_fa, "rb").read()
         assert len(a) == len(b) and a == b
         md5 = hashlib.md5(a).hexdigest()
-        print("\nfull-config scaffold parity: %d units' worth of %.3g evals by the oracle on %d threads in %.0f s; %d paths after filterUnique "
+        print("\nfull-config scaffold parity: the oracle's own graph from the records in %.0f s; %d units' worth of %.3g evals by the oracle on %d threads in %.0f s; %d paths after filterUnique "
               "(%d adjacent duplicates); scaffold %d bytes md5 %s; telomeri_post %.0f s, telomeri_hip %.1f s; whole test %.0f s" % (
-                  units, evals, threads, t_oracle, n_paths, dropped, len(a), md5, t_post, t_hip, time.time() - t_start))
+                  t_graph, units, evals, threads, t_oracle, n_paths, dropped, len(a), md5, t_post, t_hip, time.time() - t_start))
         rec = os.path.join(root, "gpurun_out", "full_config_scaffold_parity.json")
         try:
             os.makedirs(os.path.dirname(rec), exist_ok=True)
             import json
-            json.dump({"config": "athaliana", "units": units, "evals": evals, "oracle_threads": threads, "oracle_s": t_oracle, "paths": n_paths,
+            json.dump({"config": "athaliana", "oracle_own_graph_from_records_s": t_graph, "units": units, "evals": evals, "oracle_threads": threads, "oracle_s": t_oracle, "paths": n_paths,
                        "adjacent_duplicates": dropped, "scaffold_bytes": len(a), "scaffold_md5": md5, "telomeri_post_s": t_post,
                        "telomeri_hip_s": t_hip, "test_s": time.time() - t_start}, open(rec, "w"))
         except OSError:
