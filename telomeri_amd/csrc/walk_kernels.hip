@@ -1,5 +1,6 @@
 // telomeri_amd/csrc/walk_kernels.hip -- see walk_kernels.h.
 #include "walk_kernels.h"
+#include <type_traits>
 
 // Diagnostic build (make EXTRA=-DTLM_TIMING): shader-clock cycles per phase of a Monte-Carlo step, summed over all
 // waves of a launch and printed on stderr by tlm_launch_walk_mc.  The phases are separated by full vmcnt waits, so
@@ -1332,64 +1333,62 @@ struct DetPick {
 template <int K, bool SQRT, bool REL>
 __device__ __forceinline__ bool det_select_fast(const uint32_t (&nb)[K], const uint32_t (&mb)[K], const uint32_t (&vis)[K],
                                                 int lane, uint32_t deg, uint32_t skip_n_best, uint32_t lo, DetPick &r) {
-    uint32_t ob[K], orr = 0u;
+    uint32_t ob[K], orr = 0u, lmin = ~0u, lall = 0u;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         ob[k] = SQRT ? __float_as_uint(sqrtf(__uint_as_float(mb[k]))) : mb[k];
         orr |= SQRT ? (ob[k] | mb[k]) : ob[k];
+        lmin = min(lmin, ob[k]);
+        lall = max(lall, ob[k]);
     }
     if (__builtin_expect(__ballot((int) orr < 0) != 0, 0)) return false;
-    uint32_t key[K], lc = 0u, lmin = ~0u;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        key[k] = (ob[k] | 0x80000000u) & ~vis[k];           // 0: visited
-        lc = max(lc, key[k]);
-        lmin = min(lmin, ob[k]);
-    }
     if ((int) deg - K * lane < K) lmin = ~0u;
     const uint32_t omin_full = wave_min_u32(lmin);
-    uint32_t oc = wave_max_u32(lc);
-    uint32_t p = 0xFFFFFFFFu, e = 0u;
-    auto first_of = [&](uint32_t want) {
-        p = 0xFFFFFFFFu;
+    // Round 4: NO ARRAY OF KEYS.  Positions are lane-major (lane l owns K*l .. K*l+K-1), so the first position of the wave's
+    // largest key lies in the FIRST LANE that holds it, at that lane's smallest k.  Every lane therefore keeps, while its
+    // entries go by, its largest key, the first k that has it and the neighbour there (a compare and three selects per
+    // entry, on the vector side); one DPP maximum, one ballot and two v_readlane make the choice.  Before: key[K] beside
+    // nb[K] / mb[K] / vis[K] -- 48 values per lane at K = 12 -- and a ballot, a find-first, a v_readlane and a scalar
+    // minimum PER k for the first position, again for rank 0 and again for the pushed entry: ~270 scalar instructions per
+    // step on the chr1-shaped graph, scalar pipe 83 % busy (profiles/r03_chr1_summary.json).
+    // Rank 0 (:299: skipped for the rest of the walk after a go-back) = the first position of the list's largest metric,
+    // visited or not.  It is found FIRST and taken out of the candidates, instead of choosing, comparing and choosing again.
+    uint32_t xk = 0xFFu;                                        // this lane's excluded k (0xFF: none)
+    const bool skip = skip_n_best != 0u;
+    if (skip) {
+        const uint32_t omax = wave_max_u32(lall);
+        uint32_t kb = 0xFFu;
+#pragma unroll
+        for (int k = K - 1; k >= 0; k--) kb = ob[k] == omax ? (uint32_t) k : kb;
+        const uint64_t bm = __ballot(kb != 0xFFu);              // never empty
+        const int bfl = (__ffsll((unsigned long long) bm) - 1) & 63;
+        if (lane == bfl) xk = kb;
+    }
+    const bool past = (uint32_t) (K * lane) >= deg;             // (the copies of lane 0's entries go with an excluded entry)
+    uint32_t lc = 0u, ksel = 0u, nsel = 0u;
+    auto stream = [&](auto excl) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint64_t hm = __ballot(key[k] == want);
-            const int fl = (__ffsll((unsigned long long) hm) - 1) & 63;
-            const uint32_t pk = hm ? (uint32_t) K * (uint32_t) fl + (uint32_t) k : 0xFFFFFFFFu;
-            const uint32_t ek = readlane_u32(nb[k], fl);
-            if (pk < p) {
-                p = pk;
-                e = ek;
-            }
+            uint32_t key = (ob[k] | 0x80000000u) & ~vis[k];     // 0: visited
+            if (decltype(excl)::value) key = (past || xk == (uint32_t) k) ? 0u : key;
+            const bool g = key > lc;                            // strictly: the first k keeps it
+            lc = g ? key : lc;
+            ksel = g ? (uint32_t) k : ksel;
+            nsel = g ? nb[k] : nsel;
         }
     };
-    if (oc != 0u) first_of(oc);
-    if (oc != 0u && skip_n_best != 0u) {                     // :299: rank 0 is skipped for the rest of the walk
-        uint32_t lall = 0u;
-#pragma unroll
-        for (int k = 0; k < K; k++) lall = max(lall, ob[k]);
-        const uint32_t omax = wave_max_u32(lall);
-        uint32_t best_i = 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const uint64_t hm = __ballot(ob[k] == omax);
-            if (hm) best_i = min(best_i, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
-        }
-        if (p == best_i) {
-            const uint32_t bl = best_i / (uint32_t) K, bk = best_i - bl * (uint32_t) K;
-            lc = 0u;
-            const bool past = (uint32_t) (K * lane) >= deg;     // (the copies of lane 0's entries must go with it)
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (past || ((uint32_t) lane == bl && (uint32_t) k == bk)) key[k] = 0u;
-                lc = max(lc, key[k]);
-            }
-            oc = wave_max_u32(lc);
-            if (oc != 0u) first_of(oc);
-        }
+    if (skip) stream(std::true_type{});
+    else stream(std::false_type{});
+    const uint32_t oc = wave_max_u32(lc);
+    if (oc == 0u) {                                             // nothing unvisited: :318
+        r.go_back = true;
+        return true;
     }
-    if (oc == 0u || p >= deg) {                             // nothing unvisited but (at most) row padding: :318
+    const uint64_t hm = __ballot(lc == oc);
+    const int fl = (__ffsll((unsigned long long) hm) - 1) & 63;
+    const uint32_t p = (uint32_t) K * (uint32_t) fl + readlane_u32(ksel, fl);
+    const uint32_t e = readlane_u32(nsel, fl);
+    if (p >= deg) {                                             // ... but row padding
         r.go_back = true;
         return true;
     }
@@ -1397,14 +1396,20 @@ __device__ __forceinline__ bool det_select_fast(const uint32_t (&nb)[K], const u
     r.chosen = p;
     r.chosen_nbr = REL ? e + lo : e & 0x7FFFFFFFu;
     r.chosen_anchor = REL ? false : (e >> 31) != 0;
-    // ---- :340-347 (the anchor bit belongs to the neighbour: equal words <=> equal neighbours)
+    // ---- :340-347 (the anchor bit belongs to the neighbour: equal words <=> equal neighbours); the chosen entry itself
+    // matches, so the ballot is never empty
+    uint32_t kp = 0xFFu;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const uint64_t hm = __ballot(nb[k] == e);
-        if (hm) r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
-    }
+    for (int k = K - 1; k >= 0; k--) kp = nb[k] == e ? (uint32_t) k : kp;
+    const uint64_t pm = __ballot(kp != 0xFFu);
+    const int pfl = (__ffsll((unsigned long long) pm) - 1) & 63;
+    r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) pfl + readlane_u32(kp, pfl));
     return true;
 }
+
+template <bool SQRT>
+__device__ __noinline__ DetPick det_select_long_general(const uint2 *ents_tab, uint32_t *vs_win, uint32_t vs_lo, uint32_t *vs_bm, int lane,
+                                                        uint32_t row, uint32_t deg, uint32_t skip_n_best);
 
 // Lists of up to 64*K entries, K consecutive entries per lane, everything in registers: one read of the list per step.
 // REL: the row is read in its compact form (metric + 16-bit relative id; `nb` then holds ids relative to the band base
@@ -1413,79 +1418,31 @@ template <int K, bool SQRT, bool REL = false>
 __device__ __forceinline__ DetPick det_select_regs(const WalkArgs &a, const Visited &vs, int lane, uint32_t row,
                                                    uint32_t deg, uint32_t skip_n_best, uint32_t node) {
     DetPick r{false, 0xFFFFFFFFu, 0u, false, 0xFFFFFFFFu};
-    uint32_t nb[K], mb[K], o[K], vis[K];
-    // lanes past the list repeat lane 0's entries: masked by cnt
+    uint32_t nb[K], mb[K], vis[K];
+    // (lanes past the list repeat lane 0's entries, or read the zero block in front of the compact rows)
     if (REL) lane_load_c<K>(a.met, a.d16, row, deg, lane, node - vs.lo - 32768u, nb, mb);
     else lane_load<K>(a.ents, row, 0u, deg, lane, nb, mb);
-    const int cnt = (int) deg - K * lane;                     // entries of this lane inside the list (<= 0: none)
-    const uint32_t pos0 = (uint32_t) (K * lane);
     if (REL) lane_probe_rel<K>(vs, nb, vis);
     else lane_probe<K>(vs, nb, vis);
     if (det_select_fast<K, SQRT, REL>(nb, mb, vis, lane, deg, skip_n_best, vs.lo, r)) return r;
-    // ---- rank 0 and rank deg-1 (:289-296)
-    uint32_t lmax = 0u, lmin = ~0u;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        o[k] = det_ord_of<SQRT>(mb[k]);
-        if (k < cnt) {
-            lmax = max(lmax, o[k]);
-            lmin = min(lmin, o[k]);
-        }
-    }
-    const uint32_t omax = wave_max_u32(lmax), omin = wave_min_u32(lmin);
-    uint32_t best_i = 0xFFFFFFFFu, worst_i = 0u;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const uint64_t bm = __ballot(k < cnt && o[k] == omax), wm = __ballot(k < cnt && o[k] == omin);
-        if (bm) best_i = min(best_i, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
-        if (wm) worst_i = max(worst_i, (uint32_t) K * (uint32_t) (63 - __clzll((unsigned long long) wm)) + (uint32_t) k);
-    }
-    const uint32_t excluded_i = skip_n_best != 0 ? best_i : 0xFFFFFFFFu;        // after a go-back (:299)
-    // ---- the best eligible entry (:299-315)
-    uint32_t lc = 0u;
-    bool el[K], any = false;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        el[k] = k < cnt && vis[k] == 0u && pos0 != worst_i - (uint32_t) k && pos0 != excluded_i - (uint32_t) k;   // :308
-        if (el[k]) lc = max(lc, o[k]);
-        any |= el[k];
-    }
-    if (!__ballot(any)) {
-        r.go_back = true;                                   // :318
-        return r;
-    }
-    const uint32_t oc = wave_max_u32(lc);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const uint64_t hm = __ballot(el[k] && o[k] == oc);
-        if (hm) {
-            const int fl = __ffsll((unsigned long long) hm) - 1;
-            const uint32_t p = (uint32_t) K * (uint32_t) fl + (uint32_t) k;
-            if (p < r.chosen) {
-                r.chosen = p;
-                const uint32_t e = readlane_u32(nb[k], fl);
-                r.chosen_nbr = REL ? e + vs.lo : e & 0x7FFFFFFFu;
-                r.chosen_anchor = REL ? false : (e >> 31) != 0;
-            }
-        }
-    }
-    // ---- :340-347
-    const uint32_t chosen_key = REL ? r.chosen_nbr - vs.lo : r.chosen_nbr;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const uint64_t hm = __ballot(k < cnt && (REL ? nb[k] : nb[k] & 0x7FFFFFFFu) == chosen_key);
-        if (hm) r.pushed = min(r.pushed, (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
-    }
-    return r;
+    // A negative metric in the list, or a choice that may be rank deg-1: the general form decides.  It reads the list again,
+    // as 8-byte rows (every row has them), in a function of its own: nothing of this step has to stay in registers for it
+    // (round 4; before, the general form ran on nb / mb / vis here, which kept all three arrays alive to the end of the
+    // common path above).
+    return det_select_long_general<SQRT>(a.ents, vs.win, vs.lo, vs.bm, lane, row, deg, skip_n_best);
 }
 
 // Longer lists, the general form: chunks of 256 entries, the first one kept in registers, the others re-read pass by pass
 // (five passes over the list).  Since round 4 only the fallback of det_select_long below: lists with a negative metric, and
 // the case where the choice may be rank deg-1.
 template <bool SQRT>
-__device__ __forceinline__ DetPick det_select_long_general(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
-                                   uint32_t skip_n_best) {
+__device__ __noinline__ DetPick det_select_long_general(const uint2 *ents_tab, uint32_t *vs_win, uint32_t vs_lo, uint32_t *vs_bm, int lane,
+                                                        uint32_t row, uint32_t deg, uint32_t skip_n_best) {
     struct { const uint2 *ents; } a{ents_tab};
+    Visited vs;
+    vs.win = vs_win;
+    vs.lo = vs_lo;
+    vs.bm = vs_bm;
     bool go_back = false;
     uint32_t chosen = 0;
     // the first 256 entries stay in registers through all passes; longer lists re-read the rest (L1 / L2)
@@ -1619,7 +1576,7 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
                 }
             }
         }
-        if (__builtin_expect(__ballot((int) orr < 0) != 0, 0)) return det_select_long_general<SQRT>(ents_tab, vs, lane, row, deg, skip_n_best);
+        if (__builtin_expect(__ballot((int) orr < 0) != 0, 0)) return det_select_long_general<SQRT>(ents_tab, vs.win, vs.lo, vs.bm, lane, row, deg, skip_n_best);
         oc = wave_max_u32(lc);
         if (round == 0) {
             omin = wave_min_u32(lmin);
@@ -1665,7 +1622,7 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
         }
         if (p >= deg) return DetPick{true, 0u, 0u, false, 0u};
         if (__builtin_expect(!(omin < (oc & 0x7FFFFFFFu)), 0))                       // may be rank deg-1: the general form decides
-            return det_select_long_general<SQRT>(ents_tab, vs, lane, row, deg, skip_n_best);
+            return det_select_long_general<SQRT>(ents_tab, vs.win, vs.lo, vs.bm, lane, row, deg, skip_n_best);
         // ---- pass C (:340-347): the first entry, in list order, that names the chosen neighbour (the anchor bit belongs to the
         // neighbour: equal words <=> equal neighbours); it lies at or before the choice
         uint32_t pushed = p;
