@@ -40,7 +40,7 @@ extern "C" {
  * tlm_counters.layout_bytes / step_class, tlm_ctx_release_workspaces, tlm_graph_info.phase_host_ms / sync_wait_ms.
  * 4 (additions only): walks over a LIST of units (tlm_walk_list, tlm_walk_builders_list) and the sliced partition
  * (tlm_dist_unit_share); the exchange calls return paths_ order (ascending builder | unit) whatever the partition. */
-#define TLM_ABI_VERSION 4
+#define TLM_ABI_VERSION 5
 
 enum {
     TLM_OK = 0,
@@ -424,6 +424,28 @@ typedef struct {
     double device_ms;              /* HIP events around the exchange on the context's stream */
     double wall_ms;
 } tlm_exchange_info;
+/* (ABI 5) THE SHARDED LOAD.  OverlapGraph::load (OverlapGraph.cpp:94-131) reads every overlap file whole; with N ranks on
+ * one node that is N uploads of the same text through one host's memory bus, and the load does not shrink with N.  Here
+ * rank r brings only ITS pieces of each file to its device -- pieces of TLM_TEXT_PIECE bytes, the contiguous run
+ * tlm_dist_text_pieces names -- and the ranks swap their runs device to device (every rank sends its run to every peer and
+ * receives every peer's run straight into its place in the text buffer, one grouped exchange over the xGMI mesh).  From
+ * there on every rank holds the SAME BYTES a single process holds: tokeniser, name numbering (first-seen order), filter,
+ * graph build run exactly as at world 1, so the graph is the one-process graph by construction.
+ *   tlm_paf_add_file            does all of it by itself when the context has a communicator of more than one rank
+ *                               (TLM_LOAD_REPLICATED=1 in the environment: every rank uploads the whole file, as before);
+ *   with an upload helper       tlm_paf_text_begin, tlm_upload_file_window_range on the helper's side for the pieces
+ *                               [piece_begin, piece_end) and tlm_paf_text_piece for each of them, then tlm_paf_text_share
+ *                               (COLLECTIVE: every rank of the communicator calls it for the same file; `failed` != 0 =
+ *                               this rank could not bring its pieces: every rank then returns an error, none hangs), then
+ *                               tlm_paf_text_commit. */
+#define TLM_TEXT_PIECE (1ull << 30)
+int tlm_dist_text_pieces(const tlm_ctx *ctx, uint64_t bytes, uint64_t *piece_begin, uint64_t *piece_end);
+int tlm_paf_text_share(tlm_paf *p, int failed, tlm_exchange_info *info);
+int tlm_upload_file_window_range(tlm_ctx *ctx, const char *path, uint64_t bytes, uint64_t piece_begin, uint64_t piece_end,
+                                 tlm_upload_piece_fn arrived, tlm_upload_piece_fn slot_free, void *user);
+/* what the last tlm_paf_add_file / tlm_paf_text_share of this handle moved between the ranks (zeros at world 1) */
+int tlm_paf_share_info(const tlm_paf *p, tlm_exchange_info *info);
+
 /* sets[0..n_sets): this rank's Path sets, one per builder call, in call order (the same n_sets on every rank).
  * *out: the sets of all ranks, builder by builder, inside a builder in rank order (= unit order); unit[i] carries the
  * builder in its top byte as tlm_pathset_concat does.  With world == 1 this IS tlm_pathset_concat. */

@@ -185,6 +185,8 @@ def lib() -> C.CDLL:
     L.tlm_paf_records.argtypes = [V, C.c_int, P(_Records)]
     L.tlm_paf_build_graph.argtypes = [V, P(FilterParams), P(V)]
     L.tlm_paf_timing.argtypes = [V, P(C.c_double), P(C.c_double), P(C.c_double)]
+    L.tlm_paf_share_info.argtypes = [V, P(ExchangeInfo)]
+    L.tlm_dist_text_pieces.argtypes = [V, C.c_uint64, P(C.c_uint64), P(C.c_uint64)]
     L.tlm_dist_unique_id.argtypes = [V]
     L.tlm_dist_init.argtypes = [V, C.c_int, C.c_int, V]
     L.tlm_dist_finalize.argtypes = [V]
@@ -753,6 +755,12 @@ class PafTokens:
         h = C.c_void_p()
         _check(lib().tlm_paf_build_graph(self._h, C.byref(fp), C.byref(h)), "tlm_paf_build_graph")
         return Graph(self.ctx, h)
+
+    def share_info(self) -> "ExchangeInfo":
+        """What the sharded load (ABI 5) moved between the ranks for this handle's files (zeros at world 1)."""
+        info = ExchangeInfo()
+        _check(lib().tlm_paf_share_info(self._h, C.byref(info)), "tlm_paf_share_info")
+        return info
 
 
 def dist_unique_id() -> bytes:

@@ -347,6 +347,70 @@ extern "C" int tlm_dist_anchor_range(const tlm_graph *g, int rank, int world, ui
  * rank gets the same share of every anchor's work whatever the anchors weigh: hostile config, 8 ranks: max / mean 1.007
  * against 1.64 for contiguous bundles (profiles/r04_predicted_scaling_athaliana_hard.json).  units: ascending, or null to
  * ask for the count alone. */
+// ---- (ABI 5) the SHARDED LOAD: every rank brings its share of the overlap text to its device, the ranks swap the shares.
+// Which 1 GiB pieces of a text of `bytes` bytes rank `rank` of `world` uploads: a contiguous run, plain arithmetic.
+extern "C" int tlm_dist_text_pieces(const tlm_ctx *ctx, uint64_t bytes, uint64_t *piece_begin, uint64_t *piece_end) {
+    TLM_CHECK(ctx && piece_begin && piece_end, TLM_EINVAL, "tlm_dist_text_pieces: null argument");
+    const uint64_t n = (bytes + TLM_TEXT_PIECE - 1) / TLM_TEXT_PIECE;
+    const uint64_t world = (uint64_t) (ctx->world > 0 ? ctx->world : 1), rank = (uint64_t) ctx->rank;
+    *piece_begin = n * rank / world;
+    *piece_end = n * (rank + 1) / world;
+    return TLM_OK;
+}
+
+// COLLECTIVE.  `text` (device, `bytes` bytes, the same size on every rank) holds this rank's pieces; afterwards it holds all of
+// them.  Every rank sends its run to every peer and receives every peer's run STRAIGHT INTO ITS PLACE, inside one
+// ncclGroupStart/End -- the same full-mesh form as tlm_pathset_allgather: every pair of GPUs on its own xGMI link, no ring, no
+// staging, runs of different lengths.  `piece`: TLM_TEXT_PIECE (smaller in the checked build's tests).  `local_rc`: what bringing the own pieces came to; swapped first (agree), so that a rank
+// whose upload failed takes everybody out instead of leaving them inside the group.
+int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int local_rc, tlm_exchange_info *info) {
+    if (info) *info = tlm_exchange_info{};
+    if (ctx->world <= 1 && !ctx->comm) return local_rc;
+    TLM_CHECK(!ctx->comm_broken, TLM_EPEER, "tlm_text_share: the communicator was aborted after an earlier failure");
+    RcclApi *api = rccl_api();
+    if (!api) return TLM_EHIP;
+    TLM_CHECK(ctx->comm, TLM_EINVAL, "tlm_text_share: the context has no communicator");
+    TLM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (int rc = agree(ctx, api, local_rc ? local_rc : (fault_here(ctx, "text") ? TLM_EHIP : TLM_OK), "the sharded load (text upload)")) return rc;
+    const uint64_t n = (bytes + piece - 1) / piece;
+    const uint64_t world = (uint64_t) ctx->world;
+    auto run_of = [&](uint64_t r, uint64_t &b0, uint64_t &b1) {        // (tlm_dist_text_pieces, in bytes)
+        b0 = std::min<uint64_t>(bytes, (n * r / world) * piece);
+        b1 = std::min<uint64_t>(bytes, (n * (r + 1) / world) * piece);
+    };
+    uint64_t m0, m1;
+    run_of((uint64_t) ctx->rank, m0, m1);
+    uint64_t sent = 0, received = 0;
+    {
+        Collective col{ctx, api};
+        if (int rc = col.group_start()) return rc;
+        for (uint64_t r = 0; r < world; r++) {
+            if ((int) r == ctx->rank) continue;
+            uint64_t b0, b1;
+            run_of(r, b0, b1);
+            if (m1 > m0) {
+                TLM_NCCL(api, api->Send(text + m0, m1 - m0, ncclUint8, (int) r, (ncclComm_t) ctx->comm, s));
+                sent += m1 - m0;
+            }
+            if (b1 > b0) {
+                TLM_NCCL(api, api->Recv(text + b0, b1 - b0, ncclUint8, (int) r, (ncclComm_t) ctx->comm, s));
+                received += b1 - b0;
+            }
+        }
+        if (int rc = col.group_end()) return rc;
+        TLM_HIP(hipStreamSynchronize(s));
+        col.done();
+    }
+    if (info) {
+        info->bytes_sent = sent;
+        info->bytes_received = received;
+        info->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return TLM_OK;
+}
+
 extern "C" int tlm_dist_unit_share(const tlm_graph *g, const tlm_walk_params *p, int rank, int world, int deterministic,
                                    uint64_t *units, uint64_t *n_units) {
     TLM_CHECK(g && n_units && world >= 1 && rank >= 0 && rank < world && (deterministic || p), TLM_EINVAL,

@@ -584,7 +584,31 @@ struct tlm_paf {
     double upload_ms = 0, parse_ms = 0, finish_ms = 0;
     char *pending = nullptr;             // text buffer handed out by tlm_paf_text_alloc, not yet committed
     uint64_t pending_bytes = 0;
+    tlm_exchange_info share{};           // what the sharded load moved between the ranks, summed over the files
 };
+
+// The piece of the sharded load and of the uploads: TLM_TEXT_PIECE.  CHECKED BUILD ONLY (tests): TLM_TEXT_PIECE_LOG2 makes the
+// pieces of tlm_paf_add_file small, so that a text of a few hundred KB is brought in runs of several pieces by several ranks
+// (never together with the upload helper, whose window slots are TLM_TEXT_PIECE).
+static uint64_t text_piece_bytes() {
+#ifdef TLM_CHECKED
+    if (const char *e = getenv("TLM_TEXT_PIECE_LOG2")) {
+        const int b = atoi(e);
+        if (b >= 12 && b <= 30) return 1ull << b;
+    }
+#endif
+    return TLM_TEXT_PIECE;
+}
+
+// does this handle's context load its files in shares?  (a communicator of more than one rank, and no request for the old way)
+static bool sharded_load(const tlm_paf *p) {
+    return p->ctx->comm && p->ctx->world > 1 && !getenv("TLM_LOAD_REPLICATED");
+}
+static void add_share(tlm_paf *p, const tlm_exchange_info &x) {
+    p->share.bytes_sent += x.bytes_sent;
+    p->share.bytes_received += x.bytes_received;
+    p->share.wall_ms += x.wall_ms;
+}
 
 extern "C" int tlm_paf_create(tlm_ctx *ctx, tlm_paf **out) {
     TLM_CHECK(ctx && out, TLM_EINVAL, "tlm_paf_create: null argument");
@@ -695,15 +719,25 @@ struct PieceSink {           // where the 1 GiB pieces of an upload go (default:
     char *at(uint64_t k, uint64_t piece) const { return base + (n_slots ? k % n_slots : k) * piece; }
 };
 
-static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStream_t s, const char *path, tlm_ctx *defer_to) {
+// Pieces [k0, k1) only (the sharded load: a rank brings its run of pieces); the default is the whole file.
+static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStream_t s, const char *path, tlm_ctx *defer_to,
+                          uint64_t k0 = 0, uint64_t k1 = ~0ull) {
     bool uploaded = false;
     {
         const auto tr = std::chrono::steady_clock::now();
-        char *m = (char *) ::mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
-        if (m != (char *) MAP_FAILED) {
+        const uint64_t PIECE = text_piece_bytes();
+        const uint64_t n_all = (bytes + PIECE - 1) / PIECE;
+        k1 = std::min(k1, n_all);
+        k0 = std::min(k0, k1);
+        if (k0 == k1) return true;                  // nothing of this file is ours to bring
+        // only the run's bytes are mapped (the mapping's offset is a multiple of the piece size, hence of the page size);
+        // `m` is biased so that m[b] is byte b of the FILE for every b of the run
+        const uint64_t map_lo = k0 * PIECE, map_bytes = std::min<uint64_t>(bytes, k1 * PIECE) - map_lo;
+        char *m_run = (char *) ::mmap(nullptr, map_bytes, PROT_READ, MAP_SHARED, fd, (off_t) map_lo);
+        if (m_run != (char *) MAP_FAILED) {
+            char *m = m_run - map_lo;
             const unsigned workers = std::max(1u, std::min(tlm_cpu_share(), 32u));
-            constexpr uint64_t PIECE = 1ull << 30;
-            const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
+            const uint64_t n_pieces = k1;           // (loops below run k0 <= k < n_pieces; arrays are indexed by k)
             auto fault_in = [&](uint64_t k) {        // touch one byte of every page of piece k, all cores
                 const uint64_t b0 = k * PIECE, b1 = std::min(bytes, b0 + PIECE);
                 std::atomic<uint64_t> next{b0};
@@ -721,12 +755,12 @@ static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStre
             bool ok = true;
             double t_fault = 0, t_reg = 0;
             std::vector<hipEvent_t> done(n_pieces, nullptr);
-            uint64_t registered = 0;
+            uint64_t registered = k0;               // pieces [k0, registered) are registered with the device
             std::thread ahead;                      // faults of the next piece
             auto t0f = std::chrono::steady_clock::now();
-            fault_in(0);
+            fault_in(k0);
             t_fault += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0f).count();
-            uint64_t told = 0;                      // pieces [0, told) have been reported as arrived
+            uint64_t told = k0;                     // pieces [k0, told) have been reported as arrived
             auto report = [&](uint64_t upto, bool wait) {       // pieces < upto whose copies are complete
                 while (ok && told < upto && done[told]) {
                     if (wait) { if (hipEventSynchronize(done[told]) != hipSuccess) ok = false; }
@@ -735,13 +769,13 @@ static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStre
                     told++;
                 }
             };
-            for (uint64_t k = 0; ok && k < n_pieces; k++) {
+            for (uint64_t k = k0; ok && k < n_pieces; k++) {
                 const uint64_t b0 = k * PIECE, len = std::min(bytes, b0 + PIECE) - b0;
                 if (k + 1 < n_pieces) ahead = std::thread([&, k] { fault_in(k + 1); });
                 const auto t0r = std::chrono::steady_clock::now();
                 ok = hipHostRegister(m + b0, len, hipHostRegisterDefault) == hipSuccess;
                 t_reg += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0r).count();
-                if (ok && sink.n_slots && k >= sink.n_slots) {          // the slot's previous piece must have been taken over
+                if (ok && sink.n_slots && k - k0 >= sink.n_slots) {     // the slot's previous piece must have been taken over
                     report(k - sink.n_slots + 1, true);
                     if (ok && sink.before && !sink.before(k)) ok = false;
                 }
@@ -768,8 +802,8 @@ static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStre
             // unmapping 15 GB of populated pages takes longer than the copies did (0.65 s) and holds up every allocation
             // of the process meanwhile: deferred to the context, which does it when the device has just been given a long
             // kernel (the walks), or when it goes
-            for (uint64_t k = 0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);   // (instant while the device idles)
-            if (defer_to) tlm_ctx_defer(defer_to, [m, bytes] {
+            for (uint64_t k = k0; k < registered; k++) (void) hipHostUnregister(m + k * PIECE);   // (instant while the device idles)
+            if (defer_to) tlm_ctx_defer(defer_to, [m_run, map_bytes] {
                 const auto t1 = std::chrono::steady_clock::now();
                 // 0.55 s for the 3.8 M page-table entries of a 15.6 GB file, one core, whatever the thread count.  Two
                 // things were tried against it (gpurun_out/r02_child): dropping the entries 64 MB at a time
@@ -779,7 +813,7 @@ static bool upload_mapped(int fd, uint64_t bytes, const PieceSink &sink, hipStre
                 // slabs, DMA per slab) -- the cores of a one-GPU box copy at 11 GB/s, 1.4 s against the 0.31 s of the
                 // registered mapping.  One munmap it stays; in about one run of four it stops the queues once, for as
                 // long as it takes (walk kernels 1.33-1.37 s), and the wall-clock is the same: the host waits either way.
-                ::munmap(m, bytes);
+                ::munmap(m_run, map_bytes);
                 if (getenv("TLM_HOST_TIMING"))
                     fprintf(stderr, "[host timing] behind the scenes: unmapping %.0f ms\n",
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
@@ -810,13 +844,22 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
     const int f = p->n_files;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = tlm_pool_alloc((void **) &p->text[f], bytes + 64, s);
+    // the sharded load (ABI 5): this rank brings its run of pieces only, the ranks swap their runs below
+    const bool sharded = sharded_load(p);
+    const uint64_t piece = text_piece_bytes(), n_pieces_all = (bytes + piece - 1) / piece;
+    uint64_t k0 = 0, k1 = n_pieces_all;
+    if (sharded) {          // (tlm_dist_text_pieces, with this build's piece)
+        k0 = n_pieces_all * (uint64_t) p->ctx->rank / (uint64_t) p->ctx->world;
+        k1 = n_pieces_all * ((uint64_t) p->ctx->rank + 1) / (uint64_t) p->ctx->world;
+    }
+    const uint64_t run_lo = std::min<uint64_t>(bytes, k0 * piece), run_hi = std::min<uint64_t>(bytes, k1 * piece);
     bool uploaded = false;
     if (rc == TLM_OK && bytes && !getenv("TLM_UPLOAD_SLABS")) {
         PieceSink sink;
         sink.base = p->text[f];
-        uploaded = upload_mapped(fd, bytes, sink, s, path, p->ctx);
+        uploaded = upload_mapped(fd, bytes, sink, s, path, p->ctx, k0, k1);
     }
-    if (rc == TLM_OK && bytes && !uploaded) {
+    if (rc == TLM_OK && run_hi > run_lo && !uploaded) {
         // pinned slabs filled by parallel preads (the page cache copies at memory speed), H2D copies behind them:
         // the readers of slab k+1 work while slab k crosses PCIe
         constexpr size_t PIECE = 4u << 20;
@@ -834,9 +877,9 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
             ok = hipHostMalloc((void **) &slab[k], SLAB, hipHostMallocDefault) == hipSuccess
                  && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
         t_pin = ms_since(tp);
-        uint64_t at = 0;
-        for (int k = 0; ok && at < bytes; k = (k + 1) % N_SLABS) {
-            const size_t len = (size_t) std::min<uint64_t>(SLAB, bytes - at);
+        uint64_t at = run_lo;
+        for (int k = 0; ok && at < run_hi; k = (k + 1) % N_SLABS) {
+            const size_t len = (size_t) std::min<uint64_t>(SLAB, run_hi - at);
             tp = now();
             ok = hipEventSynchronize(done[k]) == hipSuccess;        // the slab's previous copy has left it
             t_wait += ms_since(tp);
@@ -882,6 +925,16 @@ extern "C" int tlm_paf_add_file(tlm_paf *p, const char *path, int anchors, uint6
         }
     }
     ::close(fd);
+    if (sharded) {          // COLLECTIVE, whatever this rank's upload came to: a failure here takes every rank out together
+        tlm_exchange_info x{};
+        rc = tlm_text_share(p->ctx, p->text[f], bytes, piece, rc, &x);
+        add_share(p, x);
+        if (rc != TLM_OK) p->poisoned = true;
+        if (getenv("TLM_HOST_TIMING"))
+            fprintf(stderr, "[host timing] sharded load of %s: rank %d of %d brought pieces [%llu, %llu) of %llu, swap %.0f ms (%.2f GB in)\n",
+                    path, p->ctx->rank, p->ctx->world, (unsigned long long) k0, (unsigned long long) k1,
+                    (unsigned long long) n_pieces_all, x.wall_ms, x.bytes_received / 1e9);
+    }
     if (rc != TLM_OK) return rc;
     p->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     p->bytes[f] = bytes;
@@ -937,6 +990,24 @@ extern "C" int tlm_paf_text_piece(tlm_paf *p, uint64_t piece) {
     return TLM_OK;
 }
 
+// COLLECTIVE (see the header): the pending text holds this rank's pieces; afterwards all of them
+extern "C" int tlm_paf_text_share(tlm_paf *p, int failed, tlm_exchange_info *info) {
+    TLM_CHECK(p && p->pending, TLM_EINVAL, "tlm_paf_text_share: no text was begun");
+    tlm_exchange_info x{};
+    if (failed) tlm_set_error("tlm_paf_text_share: this rank could not bring its pieces of the text to the device");
+    const int rc = tlm_text_share(p->ctx, p->pending, p->pending_bytes, TLM_TEXT_PIECE, failed ? TLM_EHIP : TLM_OK, &x);
+    add_share(p, x);
+    if (info) *info = x;
+    if (rc != TLM_OK) p->poisoned = true;
+    return rc;
+}
+
+extern "C" int tlm_paf_share_info(const tlm_paf *p, tlm_exchange_info *info) {
+    TLM_CHECK(p && info, TLM_EINVAL, "tlm_paf_share_info: null argument");
+    *info = p->share;
+    return TLM_OK;
+}
+
 extern "C" void tlm_paf_text_abort(tlm_paf *p) {
     if (!p || !p->pending) return;
     tlm_pool_free(p->pending);
@@ -969,6 +1040,11 @@ extern "C" int tlm_upload_window_open(tlm_ctx *ctx, const uint8_t *handle) {
 
 extern "C" int tlm_upload_file_window(tlm_ctx *ctx, const char *path, uint64_t bytes, tlm_upload_piece_fn arrived,
                                       tlm_upload_piece_fn slot_free, void *user) {
+    return tlm_upload_file_window_range(ctx, path, bytes, 0, ~0ull, arrived, slot_free, user);
+}
+
+extern "C" int tlm_upload_file_window_range(tlm_ctx *ctx, const char *path, uint64_t bytes, uint64_t piece_begin, uint64_t piece_end,
+                                            tlm_upload_piece_fn arrived, tlm_upload_piece_fn slot_free, void *user) {
     TLM_CHECK(ctx && path && arrived && slot_free, TLM_EINVAL, "tlm_upload_file_window: null argument");
     TLM_CHECK(ctx->peer_window, TLM_EINVAL, "tlm_upload_file_window: tlm_upload_window_open has not been called");
     TLM_HIP(hipSetDevice(ctx->device));
@@ -981,7 +1057,7 @@ extern "C" int tlm_upload_file_window(tlm_ctx *ctx, const char *path, uint64_t b
         sink.n_slots = TLM_UPLOAD_SLOTS;
         sink.before = [&](uint64_t k) { return slot_free(k, user) == 0; };
         sink.arrived = [&](uint64_t k) { return arrived(k, user) == 0; };
-        ok = upload_mapped(fd, bytes, sink, ctx->stream, path, nullptr);
+        ok = upload_mapped(fd, bytes, sink, ctx->stream, path, nullptr, piece_begin, piece_end);
     }
     if (fd >= 0) ::close(fd);
     if (!ok) {

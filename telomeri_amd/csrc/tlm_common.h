@@ -147,6 +147,9 @@ int tlm_pathset_summary_dev(const tlm_pathset *ps, hipStream_t s, uint32_t *fron
 int tlm_pathset_gather_dev(const tlm_pathset *ps, hipStream_t s, uint64_t n, const uint64_t *index_dev, const uint64_t *dst_off_dev,
                            uint32_t *nodes_dev, uint32_t *slots_dev);
 
+// the sharded load's swap of text pieces (exchange.hip; see tlm_paf_text_share in the header)
+int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int local_rc, tlm_exchange_info *info);
+
 // graph build (csr_build.hip)
 int tlm_graph_finish(tlm_ctx *ctx, tlm_graph *g);   // node_flags, anchors, det_off, info
 

@@ -103,7 +103,8 @@ int OverlapGraph::device_ordinal() {
 
 // ---- the upload helper (a second process; see start_upload_helper in the header) --------------------------------
 // Protocol (lines): "G" -> the helper creates its context and says "READY".  "W <ipc handle, hex>" -> "OK": the window of device
-// memory both use.  "U <bytes> <path>" -> "P <k>" for every 1 GiB piece that has arrived in its slot, answered with "A" once
+// memory both use.  "U <bytes> <path>" (or "R <bytes> <first piece> <end piece> <path>": a run of pieces, the sharded load of
+// a job of several ranks) -> "P <k>" for every 1 GiB piece that has arrived in its slot, answered with "A" once
 // the piece has been copied to its place when the slot will be needed again, then "OK".  "F <path>" -> "OK <index file>
 // <ms>": a sequence file scanned (answers collected later).  "ERR <message>" to anything that failed.
 namespace {
@@ -268,7 +269,7 @@ int OverlapGraph::upload_helper_main() {
     std::string line;
     for (int c; (c = std::getchar()) != EOF;) {
         if (c != '\n') { line.push_back((char) c); continue; }
-        unsigned long long bytes = 0;
+        unsigned long long bytes = 0, piece0 = 0, piece1 = ~0ull;
         char hex[2 * TLM_IPC_HANDLE_BYTES + 1];
         int used = 0;
         if (std::sscanf(line.c_str(), "W %128s", hex) == 1 && std::strlen(hex) == 2 * TLM_IPC_HANDLE_BYTES) {
@@ -280,8 +281,9 @@ int OverlapGraph::upload_helper_main() {
             }
             if (tlm_upload_window_open(ctx, handle) == TLM_OK) std::printf("OK\n");
             else std::printf("ERR %s\n", tlm_last_error());
-        } else if (std::sscanf(line.c_str(), "U %llu %n", &bytes, &used) == 1 && used > 0) {
-            const char *path = line.c_str() + used;
+        } else if ((std::sscanf(line.c_str(), "U %llu %n", &bytes, &used) == 1 && used > 0)
+                   || (std::sscanf(line.c_str(), "R %llu %llu %llu %n", &bytes, &piece0, &piece1, &used) == 3 && used > 0)) {
+            const char *path = line.c_str() + used;         // ("R": pieces [piece0, piece1) only -- the sharded load)
             // piece k is in its slot: say so; before a slot is written again: wait for the word that its piece was taken over
             auto arrived = [](uint64_t k, void *) -> int {
                 std::printf("P %llu\n", (unsigned long long) k);
@@ -292,7 +294,7 @@ int OverlapGraph::upload_helper_main() {
                 return std::fgets(ack, sizeof(ack), stdin) && ack[0] == 'A' ? 0 : 1;
             };
             if (std::getenv("TLM_HELPER_FAIL")) std::printf("ERR refused (TLM_HELPER_FAIL: tests of the fallback)\n");
-            else if (tlm_upload_file_window(ctx, path, bytes, arrived, slot_free, nullptr) == TLM_OK) std::printf("OK\n");
+            else if (tlm_upload_file_window_range(ctx, path, bytes, piece0, piece1, arrived, slot_free, nullptr) == TLM_OK) std::printf("OK\n");
             else std::printf("ERR %s\n", tlm_last_error());
         } else if (line.size() > 2 && line[0] == 'F' && line[1] == ' ') {
             // scan a sequence file here (the mapping and its taking down are this process's) and leave the index in a file
@@ -741,16 +743,34 @@ bool OverlapGraph::tokenize_on_device(char *filepath, bool anchors, ulong &recor
             std::fprintf(stderr, "[host timing] upload helper: context + paf handle %.0f ms, text buffer %.0f ms, ready + window %.0f ms\n",
                          std::chrono::duration<double, std::milli>(t_h0 - t_begin).count(), ms_ready, since(t_h1));
         const auto t_up = std::chrono::steady_clock::now();
-        const uint64_t bytes = (uint64_t) st.st_size, n_pieces = (bytes + (1ull << 30) - 1) >> 30;
-        const std::string req = "U " + std::to_string(bytes) + " " + filepath + "\n";
-        bool ok = std::fputs(req.c_str(), g_helper.to) >= 0 && std::fflush(g_helper.to) == 0;
+        const uint64_t bytes = (uint64_t) st.st_size;
+        // The sharded load (a job of several ranks; include/telomeri_hip.h, ABI 5): the helper brings THIS rank's run of
+        // pieces only, the ranks then swap their runs device to device (tlm_paf_text_share) -- OverlapGraph::load reads
+        // the whole file on every rank (OverlapGraph.cpp:94-131), which is N uploads of the same text through one host.
+        uint64_t k0 = 0, k1 = (bytes + TLM_TEXT_PIECE - 1) / TLM_TEXT_PIECE;
+        const bool sharded = tlm_dist_world(context()) > 1 && !std::getenv("TLM_LOAD_REPLICATED");
+        if (sharded) (void) tlm_dist_text_pieces(context(), bytes, &k0, &k1);
+        const std::string req = (sharded ? "R " + std::to_string(bytes) + " " + std::to_string(k0) + " " + std::to_string(k1) : "U " + std::to_string(bytes))
+                                + " " + filepath + "\n";
+        bool ok = k0 == k1 || (std::fputs(req.c_str(), g_helper.to) >= 0 && std::fflush(g_helper.to) == 0);
         char reply[512] = "";
-        while (ok) {                        // "P <k>": piece k is in its slot; "OK": the file is through
+        while (ok && k0 < k1) {             // "P <k>": piece k is in its slot; "OK": the file (or this rank's run of it) is through
             if (!std::fgets(reply, sizeof(reply), g_helper.from)) { ok = false; break; }
             if (std::strncmp(reply, "OK", 2) == 0) break;
             unsigned long long k = 0;
             if (std::sscanf(reply, "P %llu", &k) != 1 || tlm_paf_text_piece(paf_, k) != TLM_OK) { ok = false; break; }
-            if (k + TLM_UPLOAD_SLOTS < n_pieces) ok = std::fputs("A\n", g_helper.to) >= 0 && std::fflush(g_helper.to) == 0;
+            if (k + TLM_UPLOAD_SLOTS < k1) ok = std::fputs("A\n", g_helper.to) >= 0 && std::fflush(g_helper.to) == 0;
+        }
+        if (ok && sharded) {
+            if (std::getenv("TLM_HOST_TIMING"))
+                std::fprintf(stderr, "[host timing] sharded load of %s: pieces [%llu, %llu) brought by the helper process in %.0f ms\n", filepath,
+                             (unsigned long long) k0, (unsigned long long) k1, since(t_up));
+            tlm_exchange_info x{};
+            const auto t_s = std::chrono::steady_clock::now();
+            if (tlm_paf_text_share(paf_, 0, &x) != TLM_OK) die("tlm_paf_text_share");      // (a peer failed, or the swap did: the job ends)
+            if (std::getenv("TLM_HOST_TIMING"))
+                std::fprintf(stderr, "[host timing] sharded load of %s: swap with the other ranks %.0f ms (%.2f GB in)\n", filepath, since(t_s),
+                             x.bytes_received / 1e9);
         }
         if (ok) {
             if (std::getenv("TLM_HOST_TIMING"))

@@ -84,9 +84,13 @@ def scratch_dir(need_bytes: int) -> str:
     raise OSError("no scratch directory with %.0f GB free" % (need_bytes / 1e9))
 
 
-def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(), keep: bool = False) -> dict:
+def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(), keep: bool = False, ranks: int = 1,
+        replicated: bool = False) -> dict:
     """Render `config` as text, run telomeri_hip on it, return the timing block.  `ds`: an already generated
-    telomeri_amd.synth.Dataset of that config (bench.py has one on the GPU)."""
+    telomeri_amd.synth.Dataset of that config (bench.py has one on the GPU).
+    ranks > 1: a REHEARSAL of the multi-rank job on ONE GPU -- `ranks` copies of the program share device 0 (and its PCIe
+    link, and this box's CPU share) through tests/fake_rccl; the block is rank 0's, `rank_timing` holds the load lines of
+    every rank.  replicated: TLM_LOAD_REPLICATED=1 (every rank uploads the whole text, round 3's load)."""
     from telomeri_amd import synth
     binary = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_hip")
     if not os.path.exists(binary):
@@ -128,7 +132,35 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
         if prof:
             cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", prof, "--"] + cmd
         t_spawn = time.time()
-        res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, TLM_HOST_TIMING="1"))
+        env = dict(os.environ, TLM_HOST_TIMING="1")
+        if ranks > 1:
+            fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+            if not os.path.exists(fake):
+                subprocess.run(["make", "-s", "-C", os.path.dirname(fake)], check=True)
+            env.update(TLM_WORLD=str(ranks), TLM_DEVICE="0", TLM_RENDEZVOUS=os.path.join(tmp, "rendezvous"), TLM_RCCL_LIB=fake,
+                       FAKE_RCCL_TIMEOUT_S="600")
+            if replicated:
+                env["TLM_LOAD_REPLICATED"] = "1"
+            # (outputs into files: a rank whose pipe is full while nobody reads it would stop, and its peers with it)
+            logs = [(open(os.path.join(tmp, "rank%d.out" % r), "w+"), open(os.path.join(tmp, "rank%d.err" % r), "w+")) for r in range(ranks)]
+            procs = [subprocess.Popen(cmd[:-1] + [fasta if r == 0 else fasta + ".rank%d" % r], stdout=logs[r][0], stderr=logs[r][1],
+                                      env=dict(env, TLM_RANK=str(r))) for r in range(ranks)]
+            for p in procs:
+                p.wait()
+            outs = []
+            for o, e in logs:
+                o.seek(0), e.seek(0)
+                outs.append((o.read(), e.read()))
+                o.close(), e.close()
+            res = subprocess.CompletedProcess(cmd, max(p.returncode for p in procs), outs[0][0], outs[0][1])
+            out["ranks"] = ranks
+            out["load"] = "replicated" if replicated else "sharded"
+            out["rank_timing"] = [[ln[len("[host timing] "):] for ln in e.splitlines()
+                                   if ln.startswith("[host timing]") and ("sharded load" in ln or "text upload" in ln or "tokenise" in ln)]
+                                  for _, e in outs]
+            out["rank_load_s"] = [float(x[0]) if x else None for x in (re.findall(r"Done \(([0-9.e+-]+)s\)", o) for o, _ in outs)]
+        else:
+            res = subprocess.run(cmd, capture_output=True, text=True, env=env)
         t_done = time.time()
         out["scaffold_wall_s"] = round(t_done - t0, 3)
         # the program does not wait for its upload helper (a second process that holds a device context): when THAT has
@@ -182,4 +214,11 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(sys.argv[1] if len(sys.argv) > 1 else "athaliana")))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", nargs="?", default="athaliana")
+    ap.add_argument("--ranks", type=int, default=1, help="rehearse a job of this many ranks on ONE GPU (tests/fake_rccl)")
+    ap.add_argument("--replicated", action="store_true", help="with --ranks: every rank uploads the whole text (round 3's load)")
+    ap.add_argument("--no-scaffold", action="store_true", help="stop after the path build")
+    a = ap.parse_args()
+    print(json.dumps(run(a.config, ranks=a.ranks, replicated=a.replicated, extra_args=("--no-scaffold",) if a.no_scaffold else ())))

@@ -107,6 +107,45 @@ def fault_run(capi, ctx, sets, rank: int, outdir: str) -> int:
     return 0
 
 
+def load_graph(ctx, files, fp_mode="avg"):
+    """The sharded load's subject: the PAF files of a graph through tlm_paf_add_file (every rank of a communicator brings its
+    run of pieces of each file and the ranks swap them), names, graph.  -> dict of host arrays + the handle's share info."""
+    from telomeri_amd import capi
+    paf = capi.PafTokens(ctx)
+    recs = []
+    for path, anchors in files:
+        n, clean = paf.add_file(path, anchors)
+        assert clean, path
+        recs.append(n)
+    names, is_ctg = paf.finish()
+    cols = [paf.columns(f) for f in range(len(files))]
+    g = paf.build_graph(capi.FilterParams.default(fp_mode))
+    csr = g.download(cold=True)
+    out = {"records": np.array(recs, np.int64), "names": np.array(names), "is_ctg": is_ctg}
+    for f, c in enumerate(cols):
+        out.update({"f%d_%s" % (f, k): v for k, v in c.items()})
+    for k in ("row_ptr", "nbr", "q_start", "q_end", "t_start", "t_end", "strand", "node_len", "node_anchor"):
+        out["csr_" + k] = getattr(csr, k)
+    for k in ("os", "si", "es"):
+        out["csr_" + k] = getattr(csr, k).view(np.uint32)
+    info = paf.share_info()
+    out["share"] = np.array([info.bytes_sent, info.bytes_received], np.int64)
+    return out
+
+
+def load_run(capi, ctx, rank: int, outdir: str) -> int:
+    """dataset "load:<rr path>:<cr path>": the sharded load alone (tests/test_exchange_world.py::test_sharded_load_*)."""
+    rr, cr = sys.argv[1].split(":")[1:3]
+    try:
+        out = load_graph(ctx, [(rr, False), (cr, True)])
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+        return 0
+    except capi.TlmError as e:
+        with open(os.path.join(outdir, "rank%d.err" % rank), "w") as f:
+            f.write(str(e))
+        return 3
+
+
 def main() -> int:
     dataset, rank, world, idfile, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     from telomeri_amd import capi
@@ -125,6 +164,8 @@ def main() -> int:
                 time.sleep(0.05)
             uid = open(idfile, "rb").read()
         ctx.dist_init(rank, world, uid)
+        if dataset.startswith("load:"):
+            return load_run(capi, ctx, rank, outdir)
         dg, wp = make_graph(ctx, dataset)
         sets = rank_sets(dg, wp, rank, world)
         out = {"local_paths": np.array([s.n_paths for s in sets], np.int64)}

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 20
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
-    assert L.tlm_abi_version() == 4
+    assert L.tlm_abi_version() == 5
 
 
 def test_walk_seed_matches_oracle():

@@ -300,3 +300,110 @@ def test_bench_rank_that_loses_its_communicator_ends_the_job(fake_rccl):
     assert line is None
     assert seconds < 150, "the job took %.0f s to end" % seconds
     assert "the communicator is gone" in res.stderr or "ended with status" in res.stderr
+
+
+# ---- the sharded load (ABI 5) ---------------------------------------------------------------------
+# OverlapGraph::load reads every overlap file whole (OverlapGraph.cpp:94-131); in a job of N ranks every rank brings only its
+# run of pieces of each file to its device and the ranks swap the runs (csrc/exchange.hip: tlm_text_share).  From the full
+# text on, every rank runs the one-process code, so everything must EQUAL the one-process result: record counts, columns,
+# names in first-seen order, the graph bit for bit.
+
+def _load_files(tmp, name):
+    import golden_util as G
+    return G.gunzip_to(tmp, name + "_rr.paf.gz"), G.gunzip_to(tmp, name + "_cr.paf.gz")
+
+
+@pytest.mark.parametrize("name,world,piece_log2,collectives", [("tiny", 2, 16, "sync"), ("hard_tiny", 3, 16, "sync"), ("quirks", 4, 14, "sync"),
+                                                               ("hard_tiny", 2, 17, "async"), ("tiny", 2, 30, "sync")])
+def test_sharded_load_equals_one_process(ctx, fake_rccl, name, world, piece_log2, collectives):
+    """Pieces of 16-128 KB (checked build's TLM_TEXT_PIECE_LOG2) make a text of a few hundred KB a matter of many pieces: every
+    rank uploads a run of them -- runs of different lengths, a last piece that is short, a cr file of ONE piece that only rank 0
+    brings -- and receives the others' runs in place.  piece_log2 = 30 is the product's piece: rank 0 brings everything."""
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = _load_files(tmp, name)
+        want = W.load_graph(ctx, [(rr, False), (cr, True)])
+        assert want["share"].tolist() == [0, 0]
+        outs = run_ranks(fake_rccl, "load:%s:%s" % (rr, cr), world, tmp,
+                         dict(_async_env(collectives == "async"), TLM_LIB=CHECKED, TLM_TEXT_PIECE_LOG2=str(piece_log2)))
+        for r, (rc, out) in enumerate(outs):
+            err = os.path.join(tmp, "rank%d.err" % r)
+            assert rc == 0, out[-3000:] + (open(err).read() if os.path.exists(err) else "")
+        total = os.path.getsize(rr) + os.path.getsize(cr)
+        received = 0
+        for r in range(world):
+            got = np.load(os.path.join(tmp, "rank%d.npz" % r))
+            assert set(got.files) == set(want.keys())
+            for k, v in want.items():
+                if k != "share":
+                    np.testing.assert_array_equal(got[k], v, err_msg="rank %d: %s" % (r, k))
+            sent, recv = got["share"].tolist()
+            # a rank receives what it did not bring itself; it sends what it brought to each of the others
+            piece = 1 << piece_log2
+            own = 0
+            for path in (rr, cr):
+                b = os.path.getsize(path)
+                n = (b + piece - 1) // piece
+                own += min(b, (n * (r + 1) // world) * piece) - min(b, (n * r // world) * piece)
+            assert recv == total - own and sent == own * (world - 1), (r, sent, recv, own, total)
+            received += recv
+        assert received == (world - 1) * total
+
+
+def test_sharded_load_fails_together(ctx, fake_rccl):
+    """A rank that cannot bring its pieces (injected: TLM_EXCHANGE_FAULT=<rank>:text, checked build) takes every rank out of
+    the load with an error; none is left waiting in the swap."""
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = _load_files(tmp, "tiny")
+        outs = run_ranks(fake_rccl, "load:%s:%s" % (rr, cr), 3, tmp, dict(TLM_LIB=CHECKED, TLM_TEXT_PIECE_LOG2="16", TLM_EXCHANGE_FAULT="1:text"),
+                         timeout=200)
+        errs = [open(os.path.join(tmp, "rank%d.err" % r)).read() for r in range(3)]
+        assert [rc for rc, _ in outs] == [3, 3, 3], outs
+        assert "injected failure at 'text' on rank 1" in errs[1]
+        assert all("rank 1 failed in the sharded load" in errs[r] for r in (0, 2)), errs
+
+
+def test_host_program_sharded_load_of_several_pieces(fake_rccl):
+    """telomeri_hip as a two-rank job on a text of four 1 GiB pieces: rank 0's helper process brings pieces 0-1, rank 1's
+    pieces 2-3 (protocol line "R"), the ranks swap them (tlm_paf_text_share), and both load what one process loads."""
+    import re
+    import golden_util as G
+    binary = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_hip")
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=scratch) as tmp:
+        rr, cr = os.path.join(tmp, "rr.paf"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
+        block = "".join("r%d\t9000\t10\t8000\t+\tr%d\t9500\t20\t8100\t7000\t8100\t60\ta\tb\tc\td\n" % (k, k + 1) for k in range(4096)).encode()
+        reps = (3300 << 20) // len(block) + 1
+        with open(rr, "wb") as fh:
+            for _ in range(reps):
+                fh.write(block)
+        assert os.path.getsize(rr) > 3 * (1 << 30)
+        common = dict(os.environ, TLM_HOST_TIMING="1")
+        one = subprocess.run([binary, "--no-scaffold", "--rb-att", "2", rr, cr, "r", "c", "o"], capture_output=True, text=True, timeout=900, env=common)
+        assert one.returncode == 0 and "(device)" in one.stdout, one.stderr[-2000:]
+        rv = os.path.join(tmp, "rendezvous")
+        # (outputs into files: a rank whose pipe is full while nobody reads it would stop, and its peer with it)
+        logs = [(open(os.path.join(tmp, "rank%d.out" % r), "w+"), open(os.path.join(tmp, "rank%d.err" % r), "w+")) for r in range(2)]
+        procs = [subprocess.Popen([binary, "--no-scaffold", "--rb-att", "2", rr, cr, "r", "c", "o"], stdout=logs[r][0], stderr=logs[r][1],
+                                  env=dict(common, TLM_WORLD="2", TLM_RANK=str(r), TLM_DEVICE="0", TLM_RENDEZVOUS=rv, TLM_RCCL_LIB=fake_rccl,
+                                           FAKE_RCCL_TIMEOUT_S="300")) for r in range(2)]
+        try:
+            for p in procs:
+                p.wait(timeout=900)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        res = []
+        for o, e in logs:
+            o.seek(0), e.seek(0)
+            res.append((o.read(), e.read()))
+            o.close(), e.close()
+        keep = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(("Loaded", "-"))]
+        for r, (out, err) in enumerate(res):
+            assert procs[r].returncode == 0, err[-3000:]
+            m = re.search(r"sharded load of \S*rr\.paf: pieces \[(\d+), (\d+)\) brought by the helper process", err)
+            assert m and (int(m.group(1)), int(m.group(2))) == ((0, 2) if r == 0 else (2, 4)), err[-3000:]
+            assert "swap with the other ranks" in err
+            assert keep(out) == keep(one.stdout) and keep(out), (out[:2000], one.stdout[:2000])
+            m = re.search(r"Loaded (\d+)/(\d+) edges from \S*rr\.paf", out)
+            assert m and int(m.group(2)) == reps * 4096
