@@ -85,7 +85,7 @@ def main() -> None:
     ap.add_argument("--anchors-per-gpu", type=int, default=0, help="0 = the whole config is walked; K = K whole anchors per rank")
     ap.add_argument("--partition", choices=("sliced", "contiguous"), default="sliced",
                     help="N > 1: a slice of every anchor's units per rank (default) or bundles of whole anchors")
-    ap.add_argument("--no-scaffold", action="store_true", help="skip the PAF-in / FASTA-out wall-clock leg (N = 1 only)")
+    ap.add_argument("--no-scaffold", action="store_true", help="skip the PAF-in / FASTA-out wall-clock leg")
     ap.add_argument("--scaffold-config", default=None, help="config of the scaffold leg (default: --config)")
     ap.add_argument("--rb-att", type=int, default=2000)
     ap.add_argument("--bt-att", type=int, default=60)
@@ -332,6 +332,9 @@ def main() -> None:
 
     if rank != 0:
         if world > 1:
+            if not args.no_scaffold:        # this rank's part of the scaffold leg (rank 0 gets there after its own reporting)
+                g = None
+                scaffold_leg_all_ranks(args, {}, ctx, dev, local_rank, rank, world, cdev, dist, torch)
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -493,10 +496,59 @@ def main() -> None:
         except Exception as e:      # reported, never fatal for the metric line
             out["scaffold_wall_s"] = None
             out["scaffold"] = {"error": repr(e)}
+    if world > 1 and not args.no_scaffold:
+        g = None
+        scaffold_leg_all_ranks(args, out, ctx, dev, local_rank, rank, world, cdev, dist, torch)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scaffold_leg_all_ranks(args, out, ctx, dev, local_rank, rank, world, cdev, dist, torch):
+    """The metric's second half at N > 1: the C++ host program as an N-rank job, one process per GPU (rank r of this bench
+    starts rank r of the job on ITS device), on the text rank 0 has rendered: sharded load (every rank uploads 1/N of the
+    overlap text, one swap over xGMI), sliced walks, the lazy exchange, host stages on every rank, rank 0 writes the
+    scaffold.  Outside the timed region; every phase's failure is reported in the line and never fatal; every rank takes
+    every collective of this function whatever happened to it."""
+    import gc
+    import shutil
+    from telomeri_amd import scaffold_bench as sb
+    gc.collect()
+    ctx.trim()
+    torch.cuda.empty_cache()
+    box = [None]
+    if rank == 0:
+        try:
+            box = [sb.prepare(args.scaffold_config or args.config, device=str(dev))]
+        except Exception as e:
+            out["scaffold_wall_s"] = None
+            out["scaffold"] = {"error": "rendering the input failed: " + repr(e)}
+    dist.broadcast_object_list(box, src=0)
+    prep = box[0]
+    if prep is None:
+        return
+    res, wall = None, 0.0
+    try:
+        renv = {"TLM_WORLD": world, "TLM_RANK": rank, "TLM_DEVICE": local_rank, "TLM_RENDEZVOUS": os.path.join(prep["tmp"], "rendezvous"),
+                "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE", str(world))}
+        res = sb.execute(prep, rank_env=renv, timeout_s=float(os.environ.get("TLM_SCAFFOLD_TIMEOUT_S", "240")))
+        wall = float(res.get("scaffold_wall_s") or 0.0)
+        ok = 1 if res.get("exit") == 0 else 0
+    except Exception as e:
+        res, ok = {"error": repr(e)}, 0
+    t = torch.tensor([wall, float(ok), float(res.get("stages_s", {}).get("load_s", 0.0) if isinstance(res, dict) else 0.0)], dtype=torch.float64, device=cdev)
+    tmax, tmin = t.clone(), t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        all_ok = tmin[1].item() > 0.5
+        out["scaffold_wall_s"] = round(tmax[0].item(), 3) if all_ok else None       # the job's wall-clock = its slowest rank's
+        out["scaffold"] = dict(res, ranks=world, all_ranks_ok=all_ok, load_s_min_max_over_ranks=[tmin[2].item(), tmax[2].item()],
+                               is_="telomeri_hip as a job of %d ranks, one per GPU (rank 0's block; scaffold_wall_s = the slowest rank)" % world)
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(prep["tmp"], ignore_errors=True)
 
 
 STEP_CLASS_NAMES = ("compact_k4", "compact_k6", "compact_k8", "compact_k12", "row8_k4", "row8_k6", "row8_k8", "row8_k12",

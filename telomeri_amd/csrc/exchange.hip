@@ -390,13 +390,17 @@ int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int
             if ((int) r == ctx->rank) continue;
             uint64_t b0, b1;
             run_of(r, b0, b1);
-            if (m1 > m0) {
-                TLM_NCCL(api, api->Send(text + m0, m1 - m0, ncclUint8, (int) r, (ncclComm_t) ctx->comm, s));
-                sent += m1 - m0;
+            // piece by piece (runs are whole pieces but for the text's end): no single transfer of more than 2^30 elements,
+            // whatever a layer underneath does with its counts; the k-th send to a peer meets its k-th receive from here
+            for (uint64_t at = m0; at < m1; at += piece) {
+                const uint64_t len = std::min<uint64_t>(piece, m1 - at);
+                TLM_NCCL(api, api->Send(text + at, len, ncclUint8, (int) r, (ncclComm_t) ctx->comm, s));
+                sent += len;
             }
-            if (b1 > b0) {
-                TLM_NCCL(api, api->Recv(text + b0, b1 - b0, ncclUint8, (int) r, (ncclComm_t) ctx->comm, s));
-                received += b1 - b0;
+            for (uint64_t at = b0; at < b1; at += piece) {
+                const uint64_t len = std::min<uint64_t>(piece, b1 - at);
+                TLM_NCCL(api, api->Recv(text + at, len, ncclUint8, (int) r, (ncclComm_t) ctx->comm, s));
+                received += len;
             }
         }
         if (int rc = col.group_end()) return rc;

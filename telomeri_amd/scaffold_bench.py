@@ -84,13 +84,9 @@ def scratch_dir(need_bytes: int) -> str:
     raise OSError("no scratch directory with %.0f GB free" % (need_bytes / 1e9))
 
 
-def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(), keep: bool = False, ranks: int = 1,
-        replicated: bool = False) -> dict:
-    """Render `config` as text, run telomeri_hip on it, return the timing block.  `ds`: an already generated
-    telomeri_amd.synth.Dataset of that config (bench.py has one on the GPU).
-    ranks > 1: a REHEARSAL of the multi-rank job on ONE GPU -- `ranks` copies of the program share device 0 (and its PCIe
-    link, and this box's CPU share) through tests/fake_rccl; the block is rank 0's, `rank_timing` holds the load lines of
-    every rank.  replicated: TLM_LOAD_REPLICATED=1 (every rank uploads the whole text, round 3's load)."""
+def prepare(config: str = "athaliana", ds=None, device: str = "cuda") -> dict:
+    """Render `config` as text in a scratch directory.  -> {"tmp", "rr", "cr", "reads", "contigs", "fasta", "out": the first
+    keys of the timing block}.  `ds`: an already generated telomeri_amd.synth.Dataset of that config."""
     from telomeri_amd import synth
     binary = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_hip")
     if not os.path.exists(binary):
@@ -105,11 +101,12 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
     out = {"config": config, "records": n_rec, "reads": ds.n_reads, "contigs": ds.n_contigs,
            "program": "telomeri_amd/bin/telomeri_hip <rr.paf> <cr.paf> <reads.fasta> <contigs.fasta> <out.fasta> (reference "
                       "argv and defaults; lean graph + packed paths)"}
+    prep = {"tmp": tmp, "binary": binary, "out": out}
     try:
-        rr, cr = os.path.join(tmp, "rr_overlaps.paf"), os.path.join(tmp, "cr_overlaps.paf")
-        reads, contigs, fasta = os.path.join(tmp, "reads.fasta"), os.path.join(tmp, "contigs.fasta"), os.path.join(tmp, "HERA_result.fasta")
-        nb = write_paf(ds, ds.rr, rr) + write_paf(ds, ds.cr, cr)
-        nb += write_fasta(ds, reads, contigs)
+        prep.update(rr=os.path.join(tmp, "rr_overlaps.paf"), cr=os.path.join(tmp, "cr_overlaps.paf"), reads=os.path.join(tmp, "reads.fasta"),
+                    contigs=os.path.join(tmp, "contigs.fasta"), fasta=os.path.join(tmp, "HERA_result.fasta"))
+        nb = write_paf(ds, ds.rr, prep["rr"]) + write_paf(ds, ds.cr, prep["cr"])
+        nb += write_fasta(ds, prep["reads"], prep["contigs"])
         out["input_bytes"] = nb
         out["input_written_s"] = round(time.time() - t0, 2)
         # nothing of this process stays on the device while the program under test runs (the generator's tensors and the
@@ -123,17 +120,57 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
                 torch.cuda.empty_cache()
         except ImportError:
             pass
+    except BaseException:
+        shutil.rmtree(tmp, ignore_errors=True)
+        raise
+    return prep
+
+
+def execute(prep: dict, extra_args=(), ranks: int = 1, replicated: bool = False, rank_env: dict = None, timeout_s: float = None) -> dict:
+    """Run telomeri_hip on a prepared input and return the timing block.
+    ranks > 1: a REHEARSAL of the multi-rank job on ONE GPU -- `ranks` copies of the program share device 0 (and its PCIe
+    link, and this box's CPU share) through tests/fake_rccl; the block is rank 0's, `rank_timing` holds the load lines of
+    every rank.  replicated: TLM_LOAD_REPLICATED=1 (every rank uploads the whole text, round 3's load).
+    rank_env: THIS call is one rank of a real multi-process job (bench.py at N > 1: one call per rank, each on its own GPU):
+    the TLM_WORLD / TLM_RANK / TLM_DEVICE / TLM_RENDEZVOUS variables of that rank; rank 0 keeps the scaffold file."""
+    out = dict(prep["out"])
+    tmp, fasta = prep["tmp"], prep["fasta"]
+    if True:
         # (the program's walk kernels take 780-790 ms in most runs and 1320-1360 ms in about one run of five, on the same
-        # box, whatever this process keeps on the device and whether or not it waits here: DESIGN.md §6)
+        # box, whatever this process keeps on the device and whether or not it waits here: docs/measurement_log.md)
         time.sleep(float(os.environ.get("TLM_SCAFFOLD_SETTLE_S", "0")))
         t0 = time.time()
-        cmd = [binary] + list(extra_args) + [rr, cr, reads, contigs, fasta]
+        my_fasta = fasta
+        if rank_env and int(rank_env.get("TLM_RANK", "0")) != 0:
+            my_fasta = fasta + ".rank" + str(rank_env["TLM_RANK"])
+        cmd = [prep["binary"]] + list(extra_args) + [prep["rr"], prep["cr"], prep["reads"], prep["contigs"], my_fasta]
         prof = os.environ.get("TLM_SCAFFOLD_ROCPROF")      # a directory: kernel trace + stats of the host program's run
         if prof:
             cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", prof, "--"] + cmd
         t_spawn = time.time()
         env = dict(os.environ, TLM_HOST_TIMING="1")
-        if ranks > 1:
+        if rank_env:
+            env.update({k: str(v) for k, v in rank_env.items()})
+            if replicated:
+                env["TLM_LOAD_REPLICATED"] = "1"
+            out["ranks"] = int(rank_env.get("TLM_WORLD", "1"))
+            out["load"] = "replicated" if replicated else "sharded"
+            # (output into files: the report is long, and nobody reads a pipe while the program runs)
+            with open(os.path.join(tmp, "rank%s.out" % rank_env.get("TLM_RANK", "0")), "w+") as fo, \
+                    open(os.path.join(tmp, "rank%s.err" % rank_env.get("TLM_RANK", "0")), "w+") as fe:
+                p = subprocess.Popen(cmd, stdout=fo, stderr=fe, env=env)
+                try:
+                    rc = p.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+                    rc = -9
+                    out["timed_out_after_s"] = timeout_s
+                fo.seek(0), fe.seek(0)
+                res = subprocess.CompletedProcess(cmd, rc, fo.read(), fe.read())
+            out["rank_timing"] = [ln[len("[host timing] "):] for ln in res.stderr.splitlines()
+                                  if ln.startswith("[host timing]") and ("sharded load" in ln or "text upload" in ln or "tokenise" in ln)]
+        elif ranks > 1:
             fake = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
             if not os.path.exists(fake):
                 subprocess.run(["make", "-s", "-C", os.path.dirname(fake)], check=True)
@@ -199,18 +236,27 @@ def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(),
         m = re.search(r"- total_num: (\d+)", res.stdout)
         if m:
             out["paths"] = int(m.group(1))
-        if res.returncode == 0 and os.path.exists(fasta):       # (no file with --no-scaffold in extra_args)
-            out["scaffold_bytes"] = os.path.getsize(fasta)
+        if res.returncode == 0 and os.path.exists(my_fasta):    # (no file with --no-scaffold in extra_args, or on a rank other than 0)
+            out["scaffold_bytes"] = os.path.getsize(my_fasta)
             chain = [ln for ln in res.stdout.splitlines() if ln.startswith("ctg") and "-" in ln]
             out["scaffold_nodes"] = chain[-1].count("-") + 1 if chain else 0
-        else:
+        elif res.returncode != 0 or not rank_env:
             out["stderr_tail"] = res.stderr[-400:]
+    return out
+
+
+def run(config: str = "athaliana", ds=None, device: str = "cuda", extra_args=(), keep: bool = False, ranks: int = 1,
+        replicated: bool = False) -> dict:
+    """prepare + execute + tidy: render `config` as text, run telomeri_hip on it, return the timing block."""
+    prep = prepare(config, ds=ds, device=device)
+    try:
+        out = execute(prep, extra_args=extra_args, ranks=ranks, replicated=replicated)
         if keep:
-            out["dir"] = tmp
+            out["dir"] = prep["tmp"]
+        return out
     finally:
         if not keep:
-            shutil.rmtree(tmp, ignore_errors=True)
-    return out
+            shutil.rmtree(prep["tmp"], ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -260,11 +260,11 @@ def test_host_program_ranks_end_together(fake_rccl):
 
 # ---- bench.py as a two-rank job on one GPU (gloo for the harness's own small collectives, the library's exchange through
 # ---- the stand-in): the N > 1 line is a measured line, and a rank that loses its communicator ends the job -----------------
-def _bench(fake, extra_env, timeout=420, extra_args=()):
+def _bench(fake, extra_env, timeout=420, extra_args=(), scaffold=False):
     import json
     import time
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "toy", "--gpus", "2", "--share-gpu", "--dist-backend", "gloo",
-           "--steps", "2", "--warmup", "1", "--rb-att", "40", "--no-scaffold", "--cpu-seconds", "1"] + list(extra_args)
+           "--steps", "2", "--warmup", "1", "--rb-att", "40", "--cpu-seconds", "1"] + ([] if scaffold else ["--no-scaffold"]) + list(extra_args)
     env = dict(os.environ, TLM_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_S="60", **extra_env)
     env.pop("WORLD_SIZE", None)
     t0 = time.time()
@@ -290,6 +290,19 @@ def test_bench_two_ranks_line_is_a_measured_line(fake_rccl, partition, collectiv
     assert 0 < rk["frac_min"] <= rk["frac_max"]
     if partition == "sliced":       # every rank walks half of every anchor's trials: equal unit counts, near-equal work
         assert rk["mc_evals_max"] / rk["mc_evals_min"] < 1.6
+
+
+def test_bench_two_ranks_scaffold_leg(fake_rccl):
+    """The second half of the metric at N > 1: every bench rank starts ITS rank of the host program on the text rank 0 has
+    rendered (sharded load, sliced walks, lazy exchange, rank 0 writes the scaffold); the line carries the slowest rank's
+    wall-clock.  Here two ranks on one GPU through the stand-in -- the code path the driver's SCALE run takes."""
+    res, line, _ = _bench(fake_rccl, {}, scaffold=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    sc = line["scaffold"]
+    assert sc["ranks"] == 2 and sc["load"] == "sharded", sc
+    assert sc["all_ranks_ok"] is True and sc["exit"] == 0, sc
+    assert line["scaffold_wall_s"] > 0 and sc["scaffold_bytes"] > 0 and sc["paths"] > 0
+    assert any("sharded load" in ln for ln in sc["rank_timing"]), sc["rank_timing"]
 
 
 def test_bench_rank_that_loses_its_communicator_ends_the_job(fake_rccl):
