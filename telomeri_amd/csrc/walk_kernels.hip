@@ -1543,11 +1543,11 @@ __device__ __noinline__ DetPick det_select_long_general(const uint2 *ents_tab, u
 // such a list five times (HBM traffic of the launch: 2.0x the bytes its steps ask for, profiles/r04_hard_summary.json).
 // With every metric's sign bit clear the fp32 bit patterns order as operator> does, and the two exclusions of :299-308 are
 // checked after the choice, so:
-//   pass A (whole list, 512 entries a time, probes included): the largest unvisited key, the smallest and the largest
-//          metric of the list;
-//   pass B (up to the first hit): the first position of that key -- the choice (:299-315) -- and, after a go-back, of
-//          the list's maximum (rank 0: if that IS the choice, pass A again without it);
+//   pass A (whole list, 512 entries a time, probes included): the largest unvisited key WITH its first position and
+//          neighbour -- the choice (:299-315) --, the smallest metric of the list and, after a go-back, the first position
+//          of the largest (rank 0: if that IS the choice, pass A again without it);
 //   pass C (up to the first hit, never past the choice): the first entry with the chosen neighbour (:340-347).
+// (The first form of this round had a pass B between them that re-read the list up to the first hit to find the position.)
 // Everything else -- a negative metric anywhere, a choice that may be rank deg-1 -- goes to the general form.
 template <bool SQRT>
 __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const Visited &vs, int lane, uint32_t row, uint32_t deg,
@@ -1555,11 +1555,16 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
     constexpr int K = 8;
     constexpr uint32_t C = 64u * K;
     auto ord_bits = [](uint32_t mb) { return SQRT ? __float_as_uint(sqrtf(__uint_as_float(mb))) : mb; };
-    // ---- pass A: lc = largest key among the unvisited entries (key = metric bits | bit 31), extrema of the metric
+    // ---- pass A (the only pass with probes): every lane keeps, over ALL chunks, its largest unvisited key with the first
+    // position that has it and the neighbour there (det_select_fast's running choice; a lane meets its positions in
+    // increasing order, so "strictly larger" keeps the first), the extrema of the metric and -- after a go-back -- the first
+    // position of its largest metric.  The wave's choice is then the smallest kept position among the lanes that hold the
+    // wave maximum: no second pass over the list to find it (round 4, second form; the first re-read the list up to the hit).
     uint32_t excluded = 0xFFFFFFFFu;                    // position knocked out after a go-back (rank 0), if it was the choice
-    uint32_t oc = 0u, omin = ~0u, omax = 0u;
+    uint32_t oc = 0u, omin = ~0u, omax = 0u, best_i = 0xFFFFFFFFu;
+    const bool skip = skip_n_best != 0u;
     for (int round = 0; round < 2; round++) {
-        uint32_t lc = 0u, lmin = ~0u, lall = 0u, orr = 0u;
+        uint32_t lc = 0u, psel = 0xFFFFFFFFu, nsel = 0u, lmin = ~0u, lall = 0u, pall = 0xFFFFFFFFu, orr = 0u;
         for (uint32_t base = 0; base < deg; base += C) {
             uint32_t nb[K], mb[K], vis[K];
             lane_load<K>(ents_tab, row, base, deg, lane, nb, mb);
@@ -1571,8 +1576,14 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
                 if (pos < deg) {
                     orr |= SQRT ? (ob | mb[k]) : ob;
                     lmin = min(lmin, ob);
+                    if (skip && round == 0 && ob > lall) pall = pos;
                     lall = max(lall, ob);
-                    if (pos != excluded) lc = max(lc, (ob | 0x80000000u) & ~vis[k]);
+                    const uint32_t key = pos != excluded ? (ob | 0x80000000u) & ~vis[k] : 0u;
+                    if (key > lc) {
+                        lc = key;
+                        psel = pos;
+                        nsel = nb[k];
+                    }
                 }
             }
         }
@@ -1580,43 +1591,16 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
         oc = wave_max_u32(lc);
         if (round == 0) {
             omin = wave_min_u32(lmin);
-            omax = wave_max_u32(lall);
-        }
-        if (oc == 0u) return DetPick{true, 0u, 0u, false, 0u};                      // :318: nothing unvisited
-        // ---- pass B: first position of the key (and of the list's maximum, when rank 0 is excluded)
-        uint32_t p = 0xFFFFFFFFu, e = 0u, best_i = 0xFFFFFFFFu;
-        const bool want_best = round == 0 && skip_n_best != 0u && (oc & 0x7FFFFFFFu) == omax;     // only then can the choice be rank 0
-        for (uint32_t base = 0; base < deg && (p == 0xFFFFFFFFu || (want_best && best_i == 0xFFFFFFFFu)); base += C) {
-            uint32_t nb[K], mb[K], vis[K];
-            lane_load<K>(ents_tab, row, base, deg, lane, nb, mb);
-            bool maybe = false;
-#pragma unroll
-            for (int k = 0; k < K; k++) maybe |= ord_bits(mb[k]) == (oc & 0x7FFFFFFFu);
-            if (!__ballot(maybe)) continue;             // no entry of this chunk carries the metric: no probes needed
-            lane_probe<K>(vs, nb, vis);
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const uint32_t pos = base + (uint32_t) K * (uint32_t) lane + (uint32_t) k;
-                const uint32_t ob = ord_bits(mb[k]);
-                const bool valid = pos < deg;
-                if (p == 0xFFFFFFFFu || want_best) {
-                    const uint64_t hm = __ballot(valid && pos != excluded && ((ob | 0x80000000u) & ~vis[k]) == oc);
-                    if (hm) {
-                        const int fl = __ffsll((unsigned long long) hm) - 1;
-                        const uint32_t pk = base + (uint32_t) K * (uint32_t) fl + (uint32_t) k;
-                        if (pk < p) {
-                            p = pk;
-                            e = readlane_u32(nb[k], fl);
-                        }
-                    }
-                    if (want_best) {
-                        const uint64_t bm = __ballot(valid && ob == omax);
-                        if (bm) best_i = min(best_i, base + (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) bm) - 1) + (uint32_t) k);
-                    }
-                }
+            if (skip) {
+                omax = wave_max_u32(lall);
+                best_i = wave_min_u32(lall == omax ? pall : 0xFFFFFFFFu);          // rank 0: first position of the largest metric
             }
         }
-        if (want_best && p == best_i) {                 // the choice is rank 0, skipped for the rest of the walk (:299): once more without it
+        if (oc == 0u) return DetPick{true, 0u, 0u, false, 0u};                      // :318: nothing unvisited
+        const uint32_t p = wave_min_u32(lc == oc ? psel : 0xFFFFFFFFu);
+        const uint64_t hm = __ballot(lc == oc && psel == p);
+        const uint32_t e = readlane_u32(nsel, (__ffsll((unsigned long long) hm) - 1) & 63);
+        if (round == 0 && skip && p == best_i) {        // the choice is rank 0, skipped for the rest of the walk (:299): once more without it
             excluded = best_i;
             continue;
         }
@@ -1629,12 +1613,16 @@ __device__ __forceinline__ DetPick det_select_long(const uint2 *ents_tab, const 
         for (uint32_t base = 0; base <= p; base += C) {
             uint32_t nb[K], mb[K];
             lane_load<K>(ents_tab, row, base, deg, lane, nb, mb);
-            uint32_t best = 0xFFFFFFFFu;
+            uint32_t best = 0xFFFFFFFFu, kp = 0xFFu;    // (lane-major inside a chunk: the first lane with a match, its smallest k)
 #pragma unroll
-            for (int k = 0; k < K; k++) {
+            for (int k = K - 1; k >= 0; k--) {
                 const uint32_t pos = base + (uint32_t) K * (uint32_t) lane + (uint32_t) k;
-                const uint64_t hm = __ballot(pos < deg && nb[k] == e);
-                if (hm) best = min(best, base + (uint32_t) K * (uint32_t) (__ffsll((unsigned long long) hm) - 1) + (uint32_t) k);
+                kp = (pos < deg && nb[k] == e) ? (uint32_t) k : kp;
+            }
+            const uint64_t hm = __ballot(kp != 0xFFu);
+            if (hm) {
+                const int fl = __ffsll((unsigned long long) hm) - 1;
+                best = base + (uint32_t) K * (uint32_t) fl + readlane_u32(kp, fl);
             }
             if (best != 0xFFFFFFFFu) {
                 pushed = best;
