@@ -440,6 +440,9 @@ typedef struct {
  *                               tlm_paf_text_commit. */
 #define TLM_TEXT_PIECE (1ull << 30)
 int tlm_dist_text_pieces(const tlm_ctx *ctx, uint64_t bytes, uint64_t *piece_begin, uint64_t *piece_end);
+/* the same rule as plain arithmetic (no context, no device: tests check it on the CPU): pieces [n r / world, n (r + 1) / world)
+ * of the n = ceil(bytes / TLM_TEXT_PIECE) pieces, as bytes of the text */
+int tlm_dist_text_run(uint64_t bytes, int rank, int world, uint64_t *byte_begin, uint64_t *byte_end);
 int tlm_paf_text_share(tlm_paf *p, int failed, tlm_exchange_info *info);
 int tlm_upload_file_window_range(tlm_ctx *ctx, const char *path, uint64_t bytes, uint64_t piece_begin, uint64_t piece_end,
                                  tlm_upload_piece_fn arrived, tlm_upload_piece_fn slot_free, void *user);

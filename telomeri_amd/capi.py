@@ -187,6 +187,7 @@ def lib() -> C.CDLL:
     L.tlm_paf_timing.argtypes = [V, P(C.c_double), P(C.c_double), P(C.c_double)]
     L.tlm_paf_share_info.argtypes = [V, P(ExchangeInfo)]
     L.tlm_dist_text_pieces.argtypes = [V, C.c_uint64, P(C.c_uint64), P(C.c_uint64)]
+    L.tlm_dist_text_run.argtypes = [C.c_uint64, C.c_int, C.c_int, P(C.c_uint64), P(C.c_uint64)]
     L.tlm_dist_unique_id.argtypes = [V]
     L.tlm_dist_init.argtypes = [V, C.c_int, C.c_int, V]
     L.tlm_dist_finalize.argtypes = [V]

@@ -349,6 +349,14 @@ extern "C" int tlm_dist_anchor_range(const tlm_graph *g, int rank, int world, ui
  * ask for the count alone. */
 // ---- (ABI 5) the SHARDED LOAD: every rank brings its share of the overlap text to its device, the ranks swap the shares.
 // Which 1 GiB pieces of a text of `bytes` bytes rank `rank` of `world` uploads: a contiguous run, plain arithmetic.
+extern "C" int tlm_dist_text_run(uint64_t bytes, int rank, int world, uint64_t *byte_begin, uint64_t *byte_end) {
+    TLM_CHECK(byte_begin && byte_end && world >= 1 && rank >= 0 && rank < world, TLM_EINVAL, "tlm_dist_text_run: bad argument");
+    const uint64_t n = (bytes + TLM_TEXT_PIECE - 1) / TLM_TEXT_PIECE;
+    *byte_begin = std::min<uint64_t>(bytes, (n * (uint64_t) rank / (uint64_t) world) * TLM_TEXT_PIECE);
+    *byte_end = std::min<uint64_t>(bytes, (n * ((uint64_t) rank + 1) / (uint64_t) world) * TLM_TEXT_PIECE);
+    return TLM_OK;
+}
+
 extern "C" int tlm_dist_text_pieces(const tlm_ctx *ctx, uint64_t bytes, uint64_t *piece_begin, uint64_t *piece_end) {
     TLM_CHECK(ctx && piece_begin && piece_end, TLM_EINVAL, "tlm_dist_text_pieces: null argument");
     const uint64_t n = (bytes + TLM_TEXT_PIECE - 1) / TLM_TEXT_PIECE;
@@ -374,6 +382,24 @@ int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int
     hipStream_t s = ctx->stream;
     const auto t0 = std::chrono::steady_clock::now();
     if (int rc = agree(ctx, api, local_rc ? local_rc : (fault_here(ctx, "text") ? TLM_EHIP : TLM_OK), "the sharded load (text upload)")) return rc;
+    {   // every rank must be looking at the same file: the sizes are swapped too (a rank with another size would leave its
+        // peers with sends and receives that never meet); words [0, 2) = mine, [64, 64 + 2 world) = everybody's
+        uint64_t mine = bytes, all[TLM_EXCHANGE_MAX_BLOCKS] = {0};
+        uint64_t *d = (uint64_t *) ctx->xchg_scratch;
+        TLM_CHECK((size_t) ctx->world <= TLM_EXCHANGE_MAX_BLOCKS && 8 * (32 + (size_t) ctx->world) <= TLM_XCHG_SCRATCH_BYTES, TLM_ELIMIT,
+                  "tlm_text_share: too many ranks");
+        {
+            Collective col{ctx, api};
+            TLM_HIP(hipMemcpyAsync(d, &mine, 8, hipMemcpyHostToDevice, s));
+            TLM_NCCL(api, api->AllGather(d, d + 32, 8, ncclUint8, (ncclComm_t) ctx->comm, s));
+            TLM_HIP(hipMemcpyAsync(all, d + 32, 8 * (size_t) ctx->world, hipMemcpyDeviceToHost, s));
+            TLM_HIP(hipStreamSynchronize(s));
+            col.done();
+        }
+        for (int r = 0; r < ctx->world; r++)
+            TLM_CHECK(all[r] == bytes, TLM_EINVAL, "the sharded load: rank %d sees %llu bytes of text, rank %d sees %llu (not the same file?)",
+                      ctx->rank, (unsigned long long) bytes, r, (unsigned long long) all[r]);
+    }
     const uint64_t n = (bytes + piece - 1) / piece;
     const uint64_t world = (uint64_t) ctx->world;
     auto run_of = [&](uint64_t r, uint64_t &b0, uint64_t &b1) {        // (tlm_dist_text_pieces, in bytes)

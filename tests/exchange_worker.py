@@ -136,6 +136,8 @@ def load_graph(ctx, files, fp_mode="avg"):
 def load_run(capi, ctx, rank: int, outdir: str) -> int:
     """dataset "load:<rr path>:<cr path>": the sharded load alone (tests/test_exchange_world.py::test_sharded_load_*)."""
     rr, cr = sys.argv[1].split(":")[1:3]
+    if os.environ.get("TLM_TEST_OTHER_FILE_RANK") == str(rank):        # this rank is shown another file under the same role
+        rr += ".other"
     try:
         out = load_graph(ctx, [(rr, False), (cr, True)])
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)

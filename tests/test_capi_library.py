@@ -95,3 +95,25 @@ def test_product_library_carries_no_test_hooks():
     checked = os.path.join(ROOT, "telomeri_amd", "lib_checked", "libtelomeri_hip.so")
     if os.path.exists(checked):
         assert b"TLM_EXCHANGE_FAULT" in open(checked, "rb").read()
+
+
+def test_sharded_load_runs_partition_the_text():
+    """tlm_dist_text_run (ABI 5; plain arithmetic, no device): the ranks' runs of 1 GiB pieces are contiguous, disjoint, cover
+    [0, bytes) in rank order, start on piece boundaries and differ by at most one piece -- what csrc/exchange.hip's swap and
+    the hosts' uploads both rely on (the sends of rank a to b must meet the receives of b from a, length for length)."""
+    L = capi.lib()
+    piece = 1 << 30
+    for world in (1, 2, 3, 4, 7, 8):
+        for nbytes in (0, 1, piece - 1, piece, piece + 1, 3 * piece + 5, 15 * piece + 123, 16 * piece, 57 * piece + 1, 1000 * piece - 7):
+            at, sizes = 0, []
+            for r in range(world):
+                b0, b1 = C.c_uint64(), C.c_uint64()
+                assert L.tlm_dist_text_run(nbytes, r, world, C.byref(b0), C.byref(b1)) == 0
+                assert b0.value == at and b1.value >= b0.value, (world, nbytes, r, b0.value, b1.value)
+                assert b0.value % piece == 0 or b0.value == nbytes
+                at = b1.value
+                sizes.append(-(-(b1.value - b0.value) // piece))
+            assert at == nbytes
+            assert max(sizes) - min(sizes) <= 1, (world, nbytes, sizes)
+    b0, b1 = C.c_uint64(), C.c_uint64()
+    assert L.tlm_dist_text_run(10, 2, 2, C.byref(b0), C.byref(b1)) != 0        # rank outside the world

@@ -375,6 +375,20 @@ def test_sharded_load_fails_together(ctx, fake_rccl):
         assert all("rank 1 failed in the sharded load" in errs[r] for r in (0, 2)), errs
 
 
+def test_sharded_load_refuses_ranks_that_see_different_files(ctx, fake_rccl):
+    """The ranks swap the size of the text before any piece moves: a rank that sees another file (here: a shorter one) makes
+    EVERY rank return an error -- sends and receives of different lengths would never meet."""
+    with tempfile.TemporaryDirectory() as tmp:
+        rr, cr = _load_files(tmp, "tiny")
+        with open(rr, "rb") as f, open(rr + ".other", "wb") as o:
+            o.write(f.read()[:100_000])
+        outs = run_ranks(fake_rccl, "load:%s:%s" % (rr, cr), 2, tmp, dict(TLM_LIB=CHECKED, TLM_TEXT_PIECE_LOG2="16", TLM_TEST_OTHER_FILE_RANK="1"),
+                         timeout=200)
+        errs = [open(os.path.join(tmp, "rank%d.err" % r)).read() for r in range(2)]
+        assert [rc for rc, _ in outs] == [3, 3], outs
+        assert all("not the same file" in e for e in errs), errs
+
+
 def test_host_program_sharded_load_of_several_pieces(fake_rccl):
     """telomeri_hip as a two-rank job on a text of four 1 GiB pieces: rank 0's helper process brings pieces 0-1, rank 1's
     pieces 2-3 (protocol line "R"), the ranks swap them (tlm_paf_text_share), and both load what one process loads."""
