@@ -532,6 +532,8 @@ def scaffold_leg_all_ranks(args, out, ctx, dev, local_rank, rank, world, cdev, d
     try:
         renv = {"TLM_WORLD": world, "TLM_RANK": rank, "TLM_DEVICE": local_rank, "TLM_RENDEZVOUS": os.path.join(prep["tmp"], "rendezvous"),
                 "LOCAL_WORLD_SIZE": os.environ.get("LOCAL_WORLD_SIZE", str(world))}
+        if args.share_gpu:      # a rehearsal on ONE GPU: every rank's processes pile up on it (the boxes allow six): no helper processes
+            renv["TLM_NO_UPLOAD_HELPER"] = "1"
         res = sb.execute(prep, rank_env=renv, timeout_s=float(os.environ.get("TLM_SCAFFOLD_TIMEOUT_S", "240")))
         wall = float(res.get("scaffold_wall_s") or 0.0)
         ok = 1 if res.get("exit") == 0 else 0
