@@ -390,8 +390,10 @@ def test_sharded_load_refuses_ranks_that_see_different_files(ctx, fake_rccl):
 
 
 def test_host_program_sharded_load_of_several_pieces(fake_rccl):
-    """telomeri_hip as a two-rank job on a text of four 1 GiB pieces: rank 0's helper process brings pieces 0-1, rank 1's
-    pieces 2-3 (protocol line "R"), the ranks swap them (tlm_paf_text_share), and both load what one process loads."""
+    """telomeri_hip as a two-rank job on a text of seven 1 GiB pieces: rank 0's helper process brings pieces 0-2, rank 1's
+    pieces 3-6 (protocol line "R") -- four pieces through the three slots of its window, so piece 6 waits for the word that
+    piece 3, the FIRST of its run, has been taken over --, the ranks swap their runs (tlm_paf_text_share), and both load what
+    one process loads."""
     import re
     import golden_util as G
     binary = os.path.join(ROOT, "telomeri_amd", "bin", "telomeri_hip")
@@ -399,11 +401,11 @@ def test_host_program_sharded_load_of_several_pieces(fake_rccl):
     with tempfile.TemporaryDirectory(dir=scratch) as tmp:
         rr, cr = os.path.join(tmp, "rr.paf"), G.gunzip_to(tmp, "tiny_cr.paf.gz")
         block = "".join("r%d\t9000\t10\t8000\t+\tr%d\t9500\t20\t8100\t7000\t8100\t60\ta\tb\tc\td\n" % (k, k + 1) for k in range(4096)).encode()
-        reps = (3300 << 20) // len(block) + 1
+        reps = (6400 << 20) // len(block) + 1
         with open(rr, "wb") as fh:
             for _ in range(reps):
                 fh.write(block)
-        assert os.path.getsize(rr) > 3 * (1 << 30)
+        assert 6 * (1 << 30) < os.path.getsize(rr) < 7 * (1 << 30)
         common = dict(os.environ, TLM_HOST_TIMING="1")
         one = subprocess.run([binary, "--no-scaffold", "--rb-att", "2", rr, cr, "r", "c", "o"], capture_output=True, text=True, timeout=900, env=common)
         assert one.returncode == 0 and "(device)" in one.stdout, one.stderr[-2000:]
@@ -429,7 +431,7 @@ def test_host_program_sharded_load_of_several_pieces(fake_rccl):
         for r, (out, err) in enumerate(res):
             assert procs[r].returncode == 0, err[-3000:]
             m = re.search(r"sharded load of \S*rr\.paf: pieces \[(\d+), (\d+)\) brought by the helper process", err)
-            assert m and (int(m.group(1)), int(m.group(2))) == ((0, 2) if r == 0 else (2, 4)), err[-3000:]
+            assert m and (int(m.group(1)), int(m.group(2))) == ((0, 3) if r == 0 else (3, 7)), err[-3000:]
             assert "swap with the other ranks" in err
             assert keep(out) == keep(one.stdout) and keep(out), (out[:2000], one.stdout[:2000])
             m = re.search(r"Loaded (\d+)/(\d+) edges from \S*rr\.paf", out)
