@@ -341,12 +341,6 @@ extern "C" int tlm_dist_anchor_range(const tlm_graph *g, int rank, int world, ui
     return TLM_OK;
 }
 
-/* The SLICED partition (ABI 4; the default of the hosts since round 4): rank r of `world` walks, of EVERY anchor, the slice
- * [rb * r / world, rb * (r + 1) / world) of its Monte-Carlo trials and the slice [d * r / world, d * (r + 1) / world) of its
- * d deterministic units.  Trials of one anchor are independent walks of the same neighbourhood (per-walk seeds), so every
- * rank gets the same share of every anchor's work whatever the anchors weigh: hostile config, 8 ranks: max / mean 1.007
- * against 1.64 for contiguous bundles (profiles/r04_predicted_scaling_athaliana_hard.json).  units: ascending, or null to
- * ask for the count alone. */
 // ---- (ABI 5) the SHARDED LOAD: every rank brings its share of the overlap text to its device, the ranks swap the shares.
 // Which 1 GiB pieces of a text of `bytes` bytes rank `rank` of `world` uploads: a contiguous run, plain arithmetic.
 extern "C" int tlm_dist_text_run(uint64_t bytes, int rank, int world, uint64_t *byte_begin, uint64_t *byte_end) {
@@ -369,8 +363,9 @@ extern "C" int tlm_dist_text_pieces(const tlm_ctx *ctx, uint64_t bytes, uint64_t
 // COLLECTIVE.  `text` (device, `bytes` bytes, the same size on every rank) holds this rank's pieces; afterwards it holds all of
 // them.  Every rank sends its run to every peer and receives every peer's run STRAIGHT INTO ITS PLACE, inside one
 // ncclGroupStart/End -- the same full-mesh form as tlm_pathset_allgather: every pair of GPUs on its own xGMI link, no ring, no
-// staging, runs of different lengths.  `piece`: TLM_TEXT_PIECE (smaller in the checked build's tests).  `local_rc`: what bringing the own pieces came to; swapped first (agree), so that a rank
-// whose upload failed takes everybody out instead of leaving them inside the group.
+// staging, runs of different lengths.  `piece`: TLM_TEXT_PIECE (smaller in the checked build's tests).  `local_rc`: what
+// bringing the own pieces came to; swapped first (agree), so that a rank whose upload failed takes everybody out instead of
+// leaving them inside the group.
 int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int local_rc, tlm_exchange_info *info) {
     if (info) *info = tlm_exchange_info{};
     if (ctx->world <= 1 && !ctx->comm) return local_rc;
@@ -383,7 +378,7 @@ int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int
     const auto t0 = std::chrono::steady_clock::now();
     if (int rc = agree(ctx, api, local_rc ? local_rc : (fault_here(ctx, "text") ? TLM_EHIP : TLM_OK), "the sharded load (text upload)")) return rc;
     {   // every rank must be looking at the same file: the sizes are swapped too (a rank with another size would leave its
-        // peers with sends and receives that never meet); words [0, 2) = mine, [64, 64 + 2 world) = everybody's
+        // peers with sends and receives that never meet); scratch bytes [0, 8) = mine, [256, 256 + 8 world) = everybody's
         uint64_t mine = bytes, all[TLM_EXCHANGE_MAX_BLOCKS] = {0};
         uint64_t *d = (uint64_t *) ctx->xchg_scratch;
         TLM_CHECK((size_t) ctx->world <= TLM_EXCHANGE_MAX_BLOCKS && 8 * (32 + (size_t) ctx->world) <= TLM_XCHG_SCRATCH_BYTES, TLM_ELIMIT,
@@ -441,6 +436,12 @@ int tlm_text_share(tlm_ctx *ctx, char *text, uint64_t bytes, uint64_t piece, int
     return TLM_OK;
 }
 
+/* The SLICED partition (ABI 4; the default of the hosts since round 4): rank r of `world` walks, of EVERY anchor, the slice
+ * [rb * r / world, rb * (r + 1) / world) of its Monte-Carlo trials and the slice [d * r / world, d * (r + 1) / world) of its
+ * d deterministic units.  Trials of one anchor are independent walks of the same neighbourhood (per-walk seeds), so every
+ * rank gets the same share of every anchor's work whatever the anchors weigh: hostile config, 8 ranks: max / mean 1.007
+ * against 1.64 for contiguous bundles (profiles/r04_predicted_scaling_athaliana_hard.json).  units: ascending, or null to
+ * ask for the count alone. */
 extern "C" int tlm_dist_unit_share(const tlm_graph *g, const tlm_walk_params *p, int rank, int world, int deterministic,
                                    uint64_t *units, uint64_t *n_units) {
     TLM_CHECK(g && n_units && world >= 1 && rank >= 0 && rank < world && (deterministic || p), TLM_EINVAL,
