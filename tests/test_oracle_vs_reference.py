@@ -51,6 +51,15 @@ def test_fresh_datasets(seed, args):
     _compare(ds, args)
 
 
+def test_mid_size_dataset():
+    """The oracle against the unmodified reference where the reference's O(N) nodeIndex scan still allows it: 16 000 reads,
+    30 contigs, 456 000 records -> ~0.9 M adjacency entries, and every path of all four builders (shared-stream Monte-Carlo,
+    200 trials per anchor) -- sixty times the size of the other live sets (the reference needs ~25 s for it)."""
+    ds = synth.make_dataset("mid", seed=61, genome_len=9_000_000, n_contigs=30, contig_len=60_000, n_reads=16_000,
+                            read_len_lo=4_000, read_len_hi=14_000)
+    _compare(ds, ["--rb-att", "200"])
+
+
 def test_quirks_dataset_other_seed():
     _compare(H.quirks_dataset(seed=9), ["--rb-att", "30", "--bt-att", "4"])
 
