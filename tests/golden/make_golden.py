@@ -13,6 +13,8 @@ Fixtures
                              synthetic inputs (telomeri_amd.synth / tests.helpers), the reference's
                              graph + the four builders' path lists (ref_dump format), and the
                              arguments used
+  mid.json                   the reference PROGRAM (--rb-att 0) on a 16 000-read dataset that synth regenerates from its
+                             seed: report, exit code, scaffold md5 (no input fixture stored)
   mt19937.json               std::mt19937(5489) raw outputs and uniform_real_distribution<double>
                              values from libstdc++ (a 10-line C++ program compiled here)
 """
@@ -78,8 +80,35 @@ def run_program(cli, files, fasta_out) -> dict:
     return rec
 
 
+MID = dict(seed=61, genome_len=9_000_000, n_contigs=30, contig_len=60_000, n_reads=16_000, read_len_lo=4_000, read_len_hi=14_000)
+
+
+def make_mid(tmp: str) -> None:
+    """mid.json: the whole reference PROGRAM with the Monte-Carlo builders switched off (--rb-att 0) on a dataset sixty times
+    the size of the other sets -- 16 000 reads, 30 contigs, 456 000 overlap records; the reference needs ~25 s for it (its
+    O(N) nodeIndex scan).  No input fixture is stored: telomeri_amd.synth regenerates the dataset from its seed
+    (tests/test_reference_main_on_hip.py writes the same text).  What is frozen: the report, the exit code, the scaffold's
+    size and md5."""
+    ds = synth.make_dataset("mid", **MID)
+    rr, cr = os.path.join(tmp, "mid_rr.paf"), os.path.join(tmp, "mid_cr.paf")
+    reads, contigs = os.path.join(tmp, "mid_reads.fa"), os.path.join(tmp, "mid_contigs.fa")
+    synth.write_paf(ds, ds.rr, rr)
+    synth.write_paf(ds, ds.cr, cr)
+    synth.write_fasta(ds, reads, contigs)
+    det_only = run_program(["--rb-att", "0"], [rr, cr, reads, contigs], os.path.join(tmp, "det.fa"))
+    inputs = {os.path.basename(f): hashlib.md5(open(f, "rb").read()).hexdigest() for f in (rr, cr, reads, contigs)}
+    json.dump({"dataset": MID, "records": [len(ds.rr), len(ds.cr)], "inputs_md5": inputs, "program_det_only": det_only},
+              open(os.path.join(HERE, "mid.json"), "w"), indent=1, sort_keys=True)
+    print("mid", det_only["exit"], det_only.get("bytes"), len(det_only["stdout"]), "report lines")
+
+
 def main() -> None:
     assert po.have_ref(), "build the reference first: make -C oracle ref"
+    if "--mid" in sys.argv:         # only the mid-size program record
+        tmp = tempfile.mkdtemp(prefix="tlm_golden_")
+        make_mid(tmp)
+        shutil.rmtree(tmp)
+        return
     tmp = tempfile.mkdtemp(prefix="tlm_golden_")
     empty = os.path.join(tmp, "empty.paf")
     open(empty, "w").close()
@@ -157,6 +186,8 @@ def main() -> None:
                    "program_det_only": det_only},
                   open(os.path.join(HERE, name + ".json"), "w"), indent=1, sort_keys=True)
         print(name, len(d.node_name), d.adj.shape[0], {b: len(p) for b, p in d.builders.items()})
+
+    make_mid(tmp)
 
     # --- 3. libstdc++ RNG vectors
     src = os.path.join(tmp, "rng.cpp")

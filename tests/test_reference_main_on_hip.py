@@ -133,6 +133,48 @@ def test_report_and_scaffold_equal_the_reference_program(name, lean):
             assert [ln for ln in _normalise(res.stderr) if not ln.startswith("[")] == want["stderr"]
 
 
+def _mid_inputs(tmp):
+    """The 16 000-read dataset of tests/golden/mid.json, regenerated from its seed (no fixture is stored for it); the text
+    must be the text the golden run was made on."""
+    from telomeri_amd import synth
+    meta = G.load_json("mid.json")
+    ds = synth.make_dataset("mid", **meta["dataset"])
+    files = [os.path.join(tmp, n) for n in ("mid_rr.paf", "mid_cr.paf", "mid_reads.fa", "mid_contigs.fa")]
+    synth.write_paf(ds, ds.rr, files[0])
+    synth.write_paf(ds, ds.cr, files[1])
+    synth.write_fasta(ds, files[2], files[3])
+    for f in files:
+        assert hashlib.md5(open(f, "rb").read()).hexdigest() == meta["inputs_md5"][os.path.basename(f)], f
+    return meta, files
+
+
+def test_mid_size_inputs_are_reproducible():
+    """CPU tier: the generator gives the bytes the reference was run on (tests/golden/make_golden.py --mid)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        meta, files = _mid_inputs(tmp)
+        assert meta["records"] == [455862, 3642] and os.path.getsize(files[0]) > 40_000_000
+
+
+@pytest.mark.gpu
+@needs_binary
+@pytest.mark.parametrize("lean", [False, True])
+def test_mid_size_report_and_scaffold_equal_the_reference_program(lean):
+    """The reference's own main() on the HIP path at sixty times the size of the other sets: 16 000 reads, 30 contigs,
+    456 000 records through the device tokeniser, filter, graph build, the deterministic kernels (--rb-att 0), the post-passes
+    and the host stages -- the whole report and the 352 KB scaffold equal what the UNMODIFIED reference binary printed and
+    wrote (it needs 25 s for it; frozen in tests/golden/mid.json)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        meta, files = _mid_inputs(tmp)
+        want = meta["program_det_only"]
+        out = os.path.join(tmp, "det.fa")
+        res = subprocess.run([ON_HIP] + want["args"] + files + [out], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, TLM_HOST_LEAN="1" if lean else "0"))
+        assert res.returncode == want["exit"] == 0, res.stderr[-2000:]
+        assert _normalise(res.stdout) == want["stdout"]
+        body = open(out, "rb").read()
+        assert len(body) == want["bytes"] and hashlib.md5(body).hexdigest() == want["md5"]
+
+
 @pytest.mark.gpu
 @needs_binary
 def test_bundled_fixture_report_equals_the_reference_program():
