@@ -74,7 +74,8 @@ def one_process(ctx, dataset):
 # (FAKE_RCCL_ASYNC, tests/fake_rccl/fake_rccl.cpp): a missing stream dependency between a local kernel and a transfer, a
 # host read of a gathered size before its stream has drained, a buffer released early -- all of which the synchronous mode
 # executes "correctly" -- show here as wrong results on one GPU
-CASES = [(d, w, p, "sync") for p in ("sliced", "contiguous") for d, w in (("toy", 2), ("quirks", 2), ("toy", 4), ("quirks", 3), ("hub", 2))]
+CASES = [(d, w, p, "sync") for p in ("sliced", "contiguous") for d, w in (("toy", 2), ("quirks", 2), ("toy", 4), ("quirks", 3), ("hub", 2))
+         if (d, w, p) != ("toy", 4, "contiguous")]     # (25 s; four ranks run sliced, three contiguous)
 CASES += [("toy", 2, "sliced", "async"), ("quirks", 3, "sliced", "async"), ("hub", 2, "contiguous", "async")]
 
 

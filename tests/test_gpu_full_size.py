@@ -234,7 +234,7 @@ def test_chr1_graph_and_walks(ctx):
     rb = 2000
     wp = capi.WalkParams.default(rb_att=rb)
     anchors, det_off = g.anchor_table()
-    a0, a1 = 238, 262                     # a 24-anchor bundle (3 anchors in round 3; 40 ran once: profiles/probes/chain_r04x.txt)
+    a0, a1 = 242, 258                     # a 16-anchor bundle (3 anchors in round 3; 40 and 24 ran in round 4: profiles/probes/chain_r04x.txt, _r04ar)
     d0, d1 = int(det_off[a0]), int(det_off[a1])
     sets = g.walk_builders(capi.METRIC_ES, capi.METRIC_OS, wp, (a0 * rb, a1 * rb), (d0, d1))
     mc_anchor = lambda u: anchors[(u // rb).astype(np.int64)]
@@ -251,8 +251,8 @@ def test_chr1_graph_and_walks(ctx):
         del h
     assert sets[0].n_paths > 100 and long_steps > 0, "no accepted path crossed a node with more than 512 neighbours"
     og = po.Graph.from_csr(csr.row_ptr, csr.nbr, csr.q_start, csr.t_start, csr.os, csr.es, csr.node_len, csr.node_anchor)
-    # EVERY unit of the bundle, all four builders, against the oracle: 96 000 Monte-Carlo + ~11 000 deterministic walks,
-    # ~7e10 evals -- a third of a minute of the oracle on the box's CPU share (the whole GPU tier stays under ten minutes)
+    # EVERY unit of the bundle, all four builders, against the oracle: 64 000 Monte-Carlo + ~7 500 deterministic walks,
+    # ~4.6e10 evals -- a quarter of a minute of the oracle on the box's CPU share (the whole GPU tier stays near nine minutes)
     from telomeri_amd import cpu_share
     threads = max(1, min(16, cpu_share.cpu_share()))
     owp = po.WalkParams(wp.rebuild_attempts, wp.backtrack_attempts, wp.len_threshold)
@@ -264,7 +264,7 @@ def test_chr1_graph_and_walks(ctx):
         assert sets[k].counters.evals == octr.evals
         H.assert_paths_equal(sets[k].to_host(), ops)
         evals += int(octr.evals)
-    assert evals > 3e10
+    assert evals > 2e10
 
 
 def test_yeast_full_trials(ctx):
