@@ -123,8 +123,7 @@ void PathGroup::calculateConsensusPath() {              // PathGroup.cpp:58-79
 void PathGroup::calculateValidPathNumber() {            // PathGroup.cpp:83-93
     valid_path_number = 0;
     if (!consensus) return;
-    for (const Path *p : pig_)
-        if (*consensus == *p) valid_path_number++;
+    valid_path_number = (int) consensus->count_equal(pig_);     // operator== on every member, the device-resident ones in one fetch
 }
 
 // ---- PathManager: groups (src/PathManager.cpp:505-624) ------------------------------------------------

@@ -27,6 +27,11 @@ public:
     long length() const { return length_; }
     void setLength(long l) { length_ = l; }   // the device reports Path::length(); updateLength() recomputes it
     bool operator==(const Path &o) const;     // Path.cpp:46-49: node sequence only
+    /** How many of `members` equal *this (operator== on each, itself included when it is among them) -- what
+     *  PathGroup::calculateValidPathNumber counts (PathGroup.cpp:83-93).  Members of a device Path set whose node count and
+     *  sequence hash equal this path's are settled on their node lists, fetched in ONE request instead of one per member
+     *  (a group of the hostile config holds thousands of paths equal to its consensus). */
+    size_t count_equal(const std::vector<const Path *> &members) const;
     bool materialised() const { return have_nodes_; }
     size_t node_count() const { return have_nodes_ ? nodes_.size() : n_nodes_; }
     friend std::ostream &operator<<(std::ostream &s, const Path &p);

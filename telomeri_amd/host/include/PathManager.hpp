@@ -73,6 +73,9 @@ public:
     void set_packed(bool on) { packed_ = on; }
     void materialise(const Path &p) const;
     void materialise(const std::vector<const Path *> &ps) const;
+    /** Path::count_equal for paths of this manager that are still on the device: node lists of `ref` and of the
+     *  candidates in one fetch (a collective when the paths were gathered), compared here; nothing is materialised. */
+    size_t count_equal_on_device(const Path &ref, const std::vector<const Path *> &candidates) const;
     void materialiseAll();
     /** Test hook (CPU-only validation of the host stages): take paths produced elsewhere. */
     void adoptPaths(std::vector<Path> &&p) { paths_ = std::move(p); }

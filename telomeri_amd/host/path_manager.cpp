@@ -32,6 +32,20 @@ bool Path::operator==(const Path &o) const {       // Path.cpp:46-49: the node s
     return std::equal(nodes_.begin(), nodes_.end(), o.nodes_.begin());
 }
 
+size_t Path::count_equal(const std::vector<const Path *> &members) const {
+    size_t n = 0;
+    std::vector<const Path *> on_device;        // same manager, same count and hash, node lists still on the device
+    for (const Path *p : members) {
+        if (p == this) { n++; continue; }
+        if (p->node_count() != node_count()) continue;
+        if (owner_ && p->owner_ && hash_ != p->hash_) continue;
+        if (owner_ && p->owner_ == owner_ && !p->have_nodes_) on_device.push_back(p);
+        else if (*this == *p) n++;
+    }
+    if (!on_device.empty()) n += owner_->count_equal_on_device(*this, on_device);
+    return n;
+}
+
 std::ostream &operator<<(std::ostream &s, const Path &p) {      // "*n3-n17-...": Path.cpp:24-43
     if (!p.have_nodes_) p.owner_->materialise(p);
     for (size_t i = 0; i < p.nodes_.size(); i++) {
@@ -322,6 +336,28 @@ void PathManager::fetch_lists(const std::vector<const Path *> &v, std::vector<ui
             a += v[j]->n_nodes_;
         }
     }
+}
+
+size_t PathManager::count_equal_on_device(const Path &ref, const std::vector<const Path *> &candidates) const {
+    // one request: the reference path first (unless its nodes are here already), then the candidates
+    std::vector<const Path *> v;
+    if (!ref.have_nodes_) v.push_back(&ref);
+    v.insert(v.end(), candidates.begin(), candidates.end());
+    std::vector<uint32_t> nodes, slots;
+    fetch_lists(v, nodes, slots);
+    const size_t len = ref.node_count();
+    std::vector<uint32_t> want(len);
+    size_t at = 0;
+    if (ref.have_nodes_) {
+        for (size_t j = 0; j < len; j++) want[j] = (uint32_t) ref.nodes_[j]->index;
+    } else {
+        std::copy(nodes.begin(), nodes.begin() + (long) len, want.begin());
+        at = len;
+    }
+    size_t n = 0;
+    for (size_t k = 0; k < candidates.size(); k++, at += len)        // (every candidate has the reference's node count)
+        if (std::equal(want.begin(), want.end(), nodes.begin() + (long) at)) n++;
+    return n;
 }
 
 void PathManager::materialise(const std::vector<const Path *> &want) const {
