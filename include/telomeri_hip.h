@@ -39,7 +39,9 @@ extern "C" {
  * TLM_EPEER and the fail-together contract of the exchange calls, TLM_RCCL_LIB, tlm_ctx_set_walk_accounting with
  * tlm_counters.layout_bytes / step_class, tlm_ctx_release_workspaces, tlm_graph_info.phase_host_ms / sync_wait_ms.
  * 4 (additions only): walks over a LIST of units (tlm_walk_list, tlm_walk_builders_list) and the sliced partition
- * (tlm_dist_unit_share); the exchange calls return paths_ order (ascending builder | unit) whatever the partition. */
+ * (tlm_dist_unit_share); the exchange calls return paths_ order (ascending builder | unit) whatever the partition.
+ * 5 (additions only): the sharded load of a multi-rank job (tlm_dist_text_pieces / _run, tlm_paf_text_share,
+ * tlm_upload_file_window_range, tlm_paf_share_info; tlm_paf_add_file shares by itself in a context with a communicator). */
 #define TLM_ABI_VERSION 5
 
 enum {
